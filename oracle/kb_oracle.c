@@ -1,0 +1,594 @@
+/*
+ * kb_oracle.c -- CPU ORACLE (test infrastructure, NOT product code; see kb_oracle.h).
+ *
+ * Restates, in fp32 like Box2D, one substep of gym-kilobots'
+ *     KilobotsEnv.step            gym_kilobots/envs/kilobots_env.py:168-190
+ * for `num_envs` independent worlds of `num_bots` kilobots (+ circular objects):
+ *     light.step                  gym_kilobots/lib/light.py:59-75, 237-253, 300-316
+ *     light.value_and_gradients   gym_kilobots/lib/light.py:176-189
+ *     kb.step (5 drive laws)      gym_kilobots/lib/kilobot.py:86-127,191-203,253-258,294-300,318-333
+ *     world.Step(dt, 10, 10)      kilobots_env.py:187 -> Box2D 2.3.1 (external; restated from
+ *                                 its published algorithm: b2World::Step / b2Island::Solve /
+ *                                 b2ContactSolver / b2CollideCircles / b2CollideEdgeAndCircle)
+ *
+ * Deliberate, documented differences from Box2D (DESIGN.md "Contact order"):
+ *   - Box2D visits contacts in the order its dynamic-tree broadphase happened to create them
+ *     (an implementation artefact, not reproducible without Box2D).  The oracle defines a
+ *     canonical Gauss-Seidel order instead: contacts are sorted by (class, group, A, B) where
+ *     class/group come from a uniform grid (see contact_class()).  Groups of one class never
+ *     share a body, which is what lets the HIP kernel run a class in parallel and still be
+ *     order-identical to this sequential code.
+ *   - circle-circle and circle-wall contacts are treated as exactly central (Box2D's
+ *     cross(r, n) is ~1e-8 there), so kilobots never receive torque from contacts.
+ *   - arena walls are the four infinite lines of the closed chain loop of
+ *     kilobots_env.py:46-51 with exact axis normals.
+ *   - no sleeping (world is created with doSleep=True, kilobots_env.py:45).
+ */
+#include "kb_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ---- Box2D constants (b2Settings.h, 2.3.1) ------------------------------------------- */
+#define B2_PI 3.14159265359f
+#define B2_LINEAR_SLOP 0.005f
+#define B2_POLYGON_RADIUS (2.0f * B2_LINEAR_SLOP)
+#define B2_BAUMGARTE 0.2f
+#define B2_MAX_LINEAR_CORRECTION 0.2f
+#define B2_MAX_TRANSLATION 2.0f
+#define B2_MAX_TRANSLATION_SQ (B2_MAX_TRANSLATION * B2_MAX_TRANSLATION)
+#define B2_MAX_ROTATION (0.5f * B2_PI)
+#define B2_MAX_ROTATION_SQ (B2_MAX_ROTATION * B2_MAX_ROTATION)
+#define B2_EPSILON 1.19209290e-07f
+#define WORLD_SCALE 25.0f              /* body.py:7 */
+
+#define CELL_SIZE 0.875f               /* world units; >= 2 * bot radius (0.825) */
+#define MAX_CELLS 8192
+
+#define KEY_WALL 0x10000u
+#define KEY_OBJ 0x20000u
+#define KEY_EMPTY 0xFFFFFFFFu
+
+/* contact classes (canonical order) */
+#define CLS_SAME 0
+#define CLS_E 1   /* +1 for odd base-cell parity */
+#define CLS_N 3
+#define CLS_NE 5
+#define CLS_NW 7
+#define CLS_WALL 9
+#define CLS_BOT_OBJ 10          /* + object index */
+
+/* ---- sin/cos: Cephes single-precision algorithm (public domain, S. Moshier), restated ---- */
+void kbo_sincosf(float xx, float *sp, float *cp) {
+    const float DP1 = 0.78515625f, DP2 = 2.4187564849853515625e-4f, DP3 = 3.77489497744594108e-8f;
+    const float FOPI = 1.27323954473516f;
+    float x = fabsf(xx);
+    int j = (int)(FOPI * x);
+    float y = (float)j;
+    if (j & 1) { j += 1; y += 1.0f; }
+    j &= 7;
+    float ssign = xx < 0.0f ? -1.0f : 1.0f, csign = 1.0f;
+    if (j > 3) { ssign = -ssign; csign = -csign; j -= 4; }
+    if (j > 1) csign = -csign;
+    x = ((x - y * DP1) - y * DP2) - y * DP3;
+    float z = x * x;
+    float pc = ((2.443315711809948E-005f * z - 1.388731625493765E-003f) * z + 4.166664568298827E-002f) * z * z
+               - 0.5f * z + 1.0f;
+    float ps = ((-1.9515295891E-4f * z + 8.3321608736E-3f) * z - 1.6666654611E-1f) * z * x + x;
+    if (j == 1 || j == 2) { *sp = ssign * pc; *cp = csign * ps; }
+    else { *sp = ssign * ps; *cp = csign * pc; }
+}
+
+static inline float clampf(float a, float lo, float hi) { return fmaxf(lo, fminf(a, hi)); }
+
+/* ---- derived per-config parameters ------------------------------------------------------- */
+typedef struct {
+    float xmin, ymin, xmax, ymax;   /* arena, world units */
+    float cell, inv_cell; int gw, gh;
+    float r_bot, im_bot;            /* world radius, inverse mass */
+    float kl_bot, ka_bot;           /* Pade damping factors 1/(1+h c), b2Island.cpp */
+    float h;
+    float r_obj[KBO_MAX_OBJECTS], im_obj[KBO_MAX_OBJECTS], ii_obj[KBO_MAX_OBJECTS];
+    float kl_obj, ka_obj;
+} derived_t;
+
+static void derive(const kbo_config *c, derived_t *d) {
+    float W = c->world_width * WORLD_SCALE, H = c->world_height * WORLD_SCALE;
+    d->xmin = -0.5f * W; d->xmax = 0.5f * W; d->ymin = -0.5f * H; d->ymax = 0.5f * H;
+    float cell = CELL_SIZE;
+    float dmin = 2.0f * c->bot_radius * WORLD_SCALE;
+    while (cell < dmin) cell *= 2.0f;
+    for (;;) {
+        d->inv_cell = 1.0f / cell;
+        d->gw = (int)ceilf(W * d->inv_cell); if (d->gw < 1) d->gw = 1;
+        d->gh = (int)ceilf(H * d->inv_cell); if (d->gh < 1) d->gh = 1;
+        if ((long)d->gw * d->gh <= MAX_CELLS) break;
+        cell *= 2.0f;
+    }
+    d->cell = cell;
+    d->h = c->dt;
+    d->r_bot = c->bot_radius * WORLD_SCALE;
+    /* b2CircleShape::ComputeMass: mass = density * pi * r^2 */
+    float m = c->bot_density * B2_PI * d->r_bot * d->r_bot;
+    d->im_bot = m > 0.0f ? 1.0f / m : 0.0f;
+    d->kl_bot = 1.0f / (1.0f + d->h * c->bot_linear_damping);
+    d->ka_bot = 1.0f / (1.0f + d->h * c->bot_angular_damping);
+    for (int k = 0; k < KBO_MAX_OBJECTS; ++k) {
+        d->r_obj[k] = c->obj_radius[k] * WORLD_SCALE;
+        float mo = c->obj_density * B2_PI * d->r_obj[k] * d->r_obj[k];
+        d->im_obj[k] = mo > 0.0f ? 1.0f / mo : 0.0f;
+        /* I = mass * (0.5 r^2 + |p|^2), p = 0 */
+        float io = mo * (0.5f * d->r_obj[k] * d->r_obj[k]);
+        d->ii_obj[k] = io > 0.0f ? 1.0f / io : 0.0f;
+    }
+    d->kl_obj = 1.0f / (1.0f + d->h * c->obj_linear_damping);
+    d->ka_obj = 1.0f / (1.0f + d->h * c->obj_angular_damping);
+}
+
+/* ---- light sensing: CircularGradientLight.value_and_gradients, light.py:176-189 ------------- */
+static void light_circular(float sx, float sy, float lx, float ly, float R, float *val, float *gx, float *gy) {
+    float dx = -1.0f * (sx - lx), dy = -1.0f * (sy - ly);
+    float n = sqrtf(dx * dx + dy * dy);
+    float v = 1.0f - n / R;
+    v = fmaxf(fminf(v, 1.0f), 0.0f);
+    *val = v * 255.0f;
+    if (n > 0.0f) { dx = dx / n; dy = dy / n; }     /* reference: NaN at n == 0; oracle: zero gradient */
+    else { dx = 0.0f; dy = 0.0f; }
+    if (n > R) { dx *= 0.0f; dy *= 0.0f; }
+    *gx = dx; *gy = dy;
+}
+
+/* ---- Kilobot.step motor law, kilobot.py:86-127 (world-unit body velocity out) ---------------- */
+static void motor_law(int ml, int mr, float th, float h, float *vx, float *vy, float *w) {
+    const float max_lin = 0.01f, max_ang = 0.5f * 3.14159265358979323846f;
+    float s, c; kbo_sincosf(th, &s, &c);
+    if (ml && mr) {
+        /* kilobot.py:97-101: evident intent (the reference raises TypeError at :127) */
+        float lin = (float)(mr + ml) / 510.0f * max_lin;
+        *vx = (s * lin) * WORLD_SCALE; *vy = (c * lin) * WORLD_SCALE;
+        *w = (float)(mr - ml) / 510.0f * max_ang;
+    } else if (mr || ml) {
+        /* kilobot.py:103-121: pivot about the opposite leg */
+        float av, lx, ly = -0.009f;
+        if (mr) { av = (float)mr / 255.0f * max_ang; lx = -0.013f; }
+        else { av = -(float)ml / 255.0f * max_ang; lx = 0.013f; }
+        float ds, dc; kbo_sincosf(av * h, &ds, &dc);
+        float tx = lx - (dc * lx - ds * ly), ty = ly - (ds * lx + dc * ly);
+        tx *= WORLD_SCALE; ty *= WORLD_SCALE;
+        float wx = c * tx - s * ty, wy = s * tx + c * ty;      /* b2Body::GetWorldVector */
+        wx = wx / WORLD_SCALE / h; wy = wy / WORLD_SCALE / h;
+        *vx = wx * WORLD_SCALE; *vy = wy * WORLD_SCALE; *w = av;
+    } else {
+        *vx = 0.0f; *vy = 0.0f; *w = 0.0f;                     /* reference: TypeError */
+    }
+}
+
+/* ---- contacts ----------------------------------------------------------------------------- */
+typedef struct {
+    int a, b;           /* body indices: bot 0..N-1, object N+m; wall contacts: a = -1-w (static), b = body */
+    int cls; int group;
+    float nx, ny;       /* velocity-phase normal (A -> B) */
+    float acc;          /* accumulated normal impulse */
+    float ima, imb;
+    float ra, rb;
+    int owner, slot;    /* warm-start slot (owner bot, slot index) or -1 */
+} contact_t;
+
+static int contact_cmp(const void *pa, const void *pb) {
+    const contact_t *x = (const contact_t *)pa, *y = (const contact_t *)pb;
+    if (x->cls != y->cls) return x->cls < y->cls ? -1 : 1;
+    if (x->group != y->group) return x->group < y->group ? -1 : 1;
+    int xa = x->a < 0 ? -1 - x->a : x->a, ya = y->a < 0 ? -1 - y->a : y->a;   /* walls: ascending edge index */
+    if (xa != ya) return xa < ya ? -1 : 1;
+    if (x->b != y->b) return x->b < y->b ? -1 : 1;
+    return 0;
+}
+
+typedef struct {
+    int N, M, S;
+    float *px, *py, *vx, *vy, *bw;    /* working copies, bots then objects */
+    int *cell, *cx, *cy;
+    int *cell_start, *cell_items;
+    contact_t *con; int ncon, cap;
+    int *parent; unsigned char *active, *next_active;
+    int status;
+} work_t;
+
+static int uf_find(int *p, int i) { while (p[i] != i) { p[i] = p[p[i]]; i = p[i]; } return i; }
+static void uf_union(int *p, int a, int b) {
+    a = uf_find(p, a); b = uf_find(p, b);
+    if (a == b) return;
+    if (a < b) p[b] = a; else p[a] = b;
+}
+
+static float ws_lookup(const kbo_state *st, int e, int N, int S, int owner, unsigned key) {
+    int cnt = st->ws_cnt[(size_t)e * N + owner];
+    for (int s = 0; s < cnt && s < S; ++s) {
+        size_t idx = ((size_t)e * S + s) * N + owner;
+        if (st->ws_key[idx] == key) return st->ws_acc[idx];
+    }
+    return -1.0f;  /* accumulated impulses are >= 0 */
+}
+
+static void add_contact(work_t *w, int a, int b, int cls, int group, float ima, float imb,
+                        float ra, float rb, float acc, int owner, int slot) {
+    if (w->ncon >= w->cap) { w->status |= 1; return; }
+    contact_t *c = &w->con[w->ncon++];
+    c->a = a; c->b = b; c->cls = cls; c->group = group; c->ima = ima; c->imb = imb;
+    c->ra = ra; c->rb = rb; c->acc = acc; c->owner = owner; c->slot = slot; c->nx = 0; c->ny = 0;
+}
+
+/* b2CollideCircles + canonical class/group; emits contacts owned by bot `a` in emission order */
+static void detect_env(const kbo_config *cfg, const derived_t *d, const kbo_state *st, int e, work_t *w) {
+    const int N = w->N, S = w->S;
+    const int ncell = d->gw * d->gh;
+    /* cells */
+    memset(w->cell_start, 0, sizeof(int) * (ncell + 1));
+    for (int b = 0; b < N; ++b) {
+        int cx = (int)floorf((w->px[b] - d->xmin) * d->inv_cell);
+        int cy = (int)floorf((w->py[b] - d->ymin) * d->inv_cell);
+        cx = cx < 0 ? 0 : (cx >= d->gw ? d->gw - 1 : cx);
+        cy = cy < 0 ? 0 : (cy >= d->gh ? d->gh - 1 : cy);
+        w->cx[b] = cx; w->cy[b] = cy; w->cell[b] = cy * d->gw + cx;
+        w->cell_start[w->cell[b] + 1]++;
+    }
+    for (int c = 0; c < ncell; ++c) w->cell_start[c + 1] += w->cell_start[c];
+    {   /* stable fill: ascending bot id inside each cell */
+        int *fill = (int *)malloc(sizeof(int) * ncell);
+        memcpy(fill, w->cell_start, sizeof(int) * ncell);
+        for (int b = 0; b < N; ++b) w->cell_items[fill[w->cell[b]]++] = b;
+        free(fill);
+    }
+    const float rr = d->r_bot + d->r_bot, rr2 = rr * rr;
+    static const int ddx[5] = {0, 1, 0, 1, -1}, ddy[5] = {0, 0, 1, 1, 1};
+    static const int dcls[5] = {CLS_SAME, CLS_E, CLS_N, CLS_NE, CLS_NW};
+    w->ncon = 0;
+    for (int a = 0; a < N; ++a) {
+        int nslot = 0;
+        for (int k = 0; k < 5; ++k) {
+            int ox = w->cx[a] + ddx[k], oy = w->cy[a] + ddy[k];
+            if (ox < 0 || ox >= d->gw || oy < 0 || oy >= d->gh) continue;
+            int oc = oy * d->gw + ox;
+            for (int it = w->cell_start[oc]; it < w->cell_start[oc + 1]; ++it) {
+                int b = w->cell_items[it];
+                if (k == 0 && b <= a) continue;
+                float dx = w->px[b] - w->px[a], dy = w->py[b] - w->py[a];
+                float dd = dx * dx + dy * dy;
+                if (dd > rr2) continue;                          /* b2CollideCircles */
+                int cls = dcls[k];
+                if (k == 1 || k == 3 || k == 4) cls += (w->cx[a] & 1);
+                else if (k == 2) cls += (w->cy[a] & 1);
+                float acc = ws_lookup(st, e, N, S, a, (unsigned)b);
+                if (acc < 0.0f) acc = ws_lookup(st, e, N, S, b, (unsigned)a);
+                if (acc < 0.0f) acc = 0.0f;
+                int slot = nslot < S ? nslot : -1;
+                if (slot < 0) w->status |= 2;
+                nslot++;
+                add_contact(w, a, b, cls, w->cell[a], d->im_bot, d->im_bot, d->r_bot, d->r_bot, acc, a, slot);
+            }
+        }
+        /* walls: b2CollideEdgeAndCircle (region AB), edges of the chain loop kilobots_env.py:48-51:
+         * 0 left (x = xmin), 1 bottom (y = ymin), 2 right (x = xmax), 3 top (y = ymax) */
+        const float rw = B2_POLYGON_RADIUS + d->r_bot, rw2 = rw * rw;
+        for (int wl = 0; wl < 4; ++wl) {
+            float dist = wl == 0 ? w->px[a] - d->xmin : wl == 1 ? w->py[a] - d->ymin
+                       : wl == 2 ? d->xmax - w->px[a] : d->ymax - w->py[a];
+            if (dist * dist > rw2) continue;
+            float acc = ws_lookup(st, e, N, S, a, KEY_WALL + (unsigned)wl);
+            if (acc < 0.0f) acc = 0.0f;
+            int slot = nslot < S ? nslot : -1;
+            if (slot < 0) w->status |= 2;
+            nslot++;
+            add_contact(w, -1 - wl, a, CLS_WALL, a, 0.0f, d->im_bot, B2_POLYGON_RADIUS, d->r_bot, acc, a, slot);
+        }
+    }
+    qsort(w->con, w->ncon, sizeof(contact_t), contact_cmp);
+    (void)cfg;
+}
+
+/* wall geometry helper: signed inward distance and inward normal of wall wl at point (x,y) */
+static inline float wall_dist(const derived_t *d, int wl, float x, float y, float *nx, float *ny) {
+    switch (wl) {
+    case 0: *nx = 1.0f; *ny = 0.0f; return x - d->xmin;
+    case 1: *nx = 0.0f; *ny = 1.0f; return y - d->ymin;
+    case 2: *nx = -1.0f; *ny = 0.0f; return d->xmax - x;
+    default: *nx = 0.0f; *ny = -1.0f; return d->ymax - y;
+    }
+}
+
+/* b2Island::Solve for one env (all islands; islands only matter for the position-iteration early-out) */
+static void world_step_env(const kbo_config *cfg, const derived_t *d, kbo_state *st, int e, work_t *w) {
+    const int N = w->N, S = w->S;
+    const float h = d->h;
+    detect_env(cfg, d, st, e, w);
+
+    /* integrate velocities: no forces; Pade damping (b2Island.cpp: v *= 1/(1 + h*c)) */
+    for (int b = 0; b < N; ++b) {
+        float kl = (cfg->drive_mode == KBO_DRIVE_SIMPLE_PHOTOTAXIS) ? 1.0f / (1.0f + h * 0.0f) : d->kl_bot;
+        w->vx[b] *= kl; w->vy[b] *= kl; w->bw[b] *= d->ka_bot;
+    }
+
+    /* b2ContactSolver::InitializeVelocityConstraints: normals from current poses */
+    for (int i = 0; i < w->ncon; ++i) {
+        contact_t *c = &w->con[i];
+        if (c->a < 0) {
+            float nx, ny; float dist = wall_dist(d, -1 - c->a, w->px[c->b], w->py[c->b], &nx, &ny);
+            if (dist < 0.0f) { nx = -nx; ny = -ny; }      /* b2CollideEdgeAndCircle: flip towards the centre */
+            c->nx = nx; c->ny = ny;
+        } else {
+            float dx = w->px[c->b] - w->px[c->a], dy = w->py[c->b] - w->py[c->a];
+            if (dx * dx + dy * dy > B2_EPSILON * B2_EPSILON) {   /* b2WorldManifold::Initialize */
+                float len = sqrtf(dx * dx + dy * dy);
+                float inv = 1.0f / len;
+                c->nx = dx * inv; c->ny = dy * inv;
+            } else { c->nx = 1.0f; c->ny = 0.0f; }
+        }
+    }
+    /* WarmStart */
+    for (int i = 0; i < w->ncon; ++i) {
+        contact_t *c = &w->con[i];
+        float Px = c->acc * c->nx, Py = c->acc * c->ny;
+        if (c->a >= 0) { w->vx[c->a] -= c->ima * Px; w->vy[c->a] -= c->ima * Py; }
+        w->vx[c->b] += c->imb * Px; w->vy[c->b] += c->imb * Py;
+    }
+    /* SolveVelocityConstraints (friction 0, restitution 0, one point) */
+    for (int it = 0; it < cfg->vel_iters; ++it) {
+        for (int i = 0; i < w->ncon; ++i) {
+            contact_t *c = &w->con[i];
+            float vax = 0.0f, vay = 0.0f;
+            if (c->a >= 0) { vax = w->vx[c->a]; vay = w->vy[c->a]; }
+            float dvx = w->vx[c->b] - vax, dvy = w->vy[c->b] - vay;
+            float vn = dvx * c->nx + dvy * c->ny;
+            float k = c->ima + c->imb;
+            float nm = k > 0.0f ? 1.0f / k : 0.0f;
+            float lambda = -(nm * vn);
+            float newimp = fmaxf(c->acc + lambda, 0.0f);
+            lambda = newimp - c->acc;
+            c->acc = newimp;
+            float Px = lambda * c->nx, Py = lambda * c->ny;
+            if (c->a >= 0) { w->vx[c->a] = vax - c->ima * Px; w->vy[c->a] = vay - c->ima * Py; }
+            w->vx[c->b] += c->imb * Px; w->vy[c->b] += c->imb * Py;
+        }
+    }
+    /* StoreImpulses -> warm-start cache of the next substep */
+    memset(st->ws_cnt + (size_t)e * N, 0, (size_t)N);
+    for (int i = 0; i < w->ncon; ++i) {
+        contact_t *c = &w->con[i];
+        if (c->slot < 0) continue;
+        size_t idx = ((size_t)e * S + c->slot) * N + c->owner;
+        unsigned key = c->a < 0 ? KEY_WALL + (unsigned)(-1 - c->a) : (unsigned)c->b;
+        st->ws_key[idx] = key; st->ws_acc[idx] = c->acc;
+        size_t ci = (size_t)e * N + c->owner;
+        if (st->ws_cnt[ci] < c->slot + 1) st->ws_cnt[ci] = (uint8_t)(c->slot + 1);
+    }
+    /* integrate positions */
+    for (int b = 0; b < N; ++b) {
+        float tx = h * w->vx[b], ty = h * w->vy[b];
+        if (tx * tx + ty * ty > B2_MAX_TRANSLATION_SQ) {
+            float ratio = B2_MAX_TRANSLATION / sqrtf(tx * tx + ty * ty);
+            w->vx[b] *= ratio; w->vy[b] *= ratio;
+        }
+        float rot = h * w->bw[b];
+        if (rot * rot > B2_MAX_ROTATION_SQ) {
+            float ratio = B2_MAX_ROTATION / fabsf(rot);
+            w->bw[b] *= ratio;
+        }
+        w->px[b] += h * w->vx[b]; w->py[b] += h * w->vy[b];
+        st->theta[(size_t)e * N + b] += h * w->bw[b];
+    }
+    /* islands (connected components over dynamic-dynamic contacts) for the per-island early-out */
+    for (int b = 0; b < N; ++b) { w->parent[b] = b; }
+    for (int i = 0; i < w->ncon; ++i) if (w->con[i].a >= 0) uf_union(w->parent, w->con[i].a, w->con[i].b);
+    for (int b = 0; b < N; ++b) { w->parent[b] = uf_find(w->parent, b); w->active[b] = 1; }
+    /* SolvePositionConstraints, b2ContactSolver.cpp; per island: break when minSeparation >= -3 slop */
+    for (int it = 0; it < cfg->pos_iters; ++it) {
+        int any = 0;
+        memset(w->next_active, 0, (size_t)N);
+        for (int i = 0; i < w->ncon; ++i) {
+            contact_t *c = &w->con[i];
+            int isl = w->parent[c->b];
+            if (!w->active[isl]) continue;
+            float nx, ny, sep;
+            if (c->a < 0) {
+                float bx, by; float dist = wall_dist(d, -1 - c->a, w->px[c->b], w->py[c->b], &bx, &by);
+                /* manifold normal is fixed at detection time (stored in c->nx, c->ny) */
+                nx = c->nx; ny = c->ny;
+                float along = (nx == bx && ny == by) ? dist : -dist;
+                sep = along - c->ra - c->rb;
+            } else {
+                float dx = w->px[c->b] - w->px[c->a], dy = w->py[c->b] - w->py[c->a];
+                float len = sqrtf(dx * dx + dy * dy);
+                nx = dx; ny = dy;
+                if (!(len < B2_EPSILON)) { float inv = 1.0f / len; nx = dx * inv; ny = dy * inv; }   /* b2Vec2::Normalize */
+                sep = (dx * nx + dy * ny) - c->ra - c->rb;
+            }
+            if (sep < -3.0f * B2_LINEAR_SLOP) { w->next_active[isl] = 1; any = 1; }
+            float C = clampf(B2_BAUMGARTE * (sep + B2_LINEAR_SLOP), -B2_MAX_LINEAR_CORRECTION, 0.0f);
+            float K = c->ima + c->imb;
+            float imp = K > 0.0f ? -C / K : 0.0f;
+            float Px = imp * nx, Py = imp * ny;
+            if (c->a >= 0) { w->px[c->a] -= c->ima * Px; w->py[c->a] -= c->ima * Py; }
+            w->px[c->b] += c->imb * Px; w->py[c->b] += c->imb * Py;
+        }
+        memcpy(w->active, w->next_active, (size_t)N);
+        if (!any) break;
+    }
+}
+
+/* one substep of the kilobots_env.py:168-190 loop for env e */
+static void substep_env(const kbo_config *cfg, const derived_t *d, kbo_state *st, const float *light_action,
+                        int flags, int e, work_t *w) {
+    const int N = w->N;
+    const size_t o = (size_t)e * N;
+    const float h = d->h;
+    /* light.step, kilobots_env.py:171-172 */
+    if (light_action && cfg->light_type == KBO_LIGHT_CIRCULAR && !(flags & KBO_STEP_NO_DRIVE)) {
+        /* SinglePositionLight.step, light.py:59-75 (relative actions) */
+        float ax = fminf(fmaxf(light_action[2 * e + 0], cfg->light_act_lo[0]), cfg->light_act_hi[0]);
+        float ay = fminf(fmaxf(light_action[2 * e + 1], cfg->light_act_lo[1]), cfg->light_act_hi[1]);
+        float lx = st->light_x[e] + ax * h, ly = st->light_y[e] + ay * h;
+        st->light_x[e] = fminf(fmaxf(lx, cfg->light_lo[0]), cfg->light_hi[0]);
+        st->light_y[e] = fminf(fmaxf(ly, cfg->light_lo[1]), cfg->light_hi[1]);
+    }
+    for (int b = 0; b < N; ++b) {
+        float th = st->theta[o + b];
+        float bvx = 0.0f, bvy = 0.0f, bw = 0.0f;
+        w->px[b] = st->x[o + b]; w->py[b] = st->y[o + b];
+        if (!(flags & KBO_STEP_NO_DRIVE)) {
+            float lval = 0.0f, lgx = 0.0f, lgy = 0.0f;
+            if (cfg->light_type == KBO_LIGHT_CIRCULAR) {
+                /* kilobots_env.py:174-180; sensor position kilobot.py:54-55 / :188-189 */
+                float sx = w->px[b], sy = w->py[b];
+                if (cfg->drive_mode != KBO_DRIVE_SIMPLE_PHOTOTAXIS) {
+                    float s, c; kbo_sincosf(th, &s, &c);
+                    float lx0 = 0.0f, ly0 = -d->r_bot;
+                    sx = (c * lx0 - s * ly0) + w->px[b];
+                    sy = (s * lx0 + c * ly0) + w->py[b];
+                }
+                light_circular(sx / WORLD_SCALE, sy / WORLD_SCALE, st->light_x[e], st->light_y[e],
+                               cfg->light_radius, &lval, &lgx, &lgy);
+                if (st->light_value) { st->light_value[o + b] = lval; st->light_gx[o + b] = lgx; st->light_gy[o + b] = lgy; }
+            }
+            switch (cfg->drive_mode) {
+            case KBO_DRIVE_ACCEL: {
+                /* kilobot.py:294-300 */
+                float v = st->v[o + b] + st->acc_v[o + b] * h, ww = st->w[o + b] + st->acc_w[o + b] * h;
+                const float mw = 0.5f * 3.14159265358979323846f;
+                v = fminf(fmaxf(v, 0.0f), 0.01f); ww = fminf(fmaxf(ww, -mw), mw);
+                st->v[o + b] = v; st->w[o + b] = ww;
+            } /* fallthrough */
+            case KBO_DRIVE_VELOCITY: {
+                /* kilobot.py:253-258 */
+                float s, c; kbo_sincosf(th, &s, &c);
+                float sp = st->v[o + b] * WORLD_SCALE;
+                bvx = c * sp; bvy = s * sp; bw = st->w[o + b];
+            } break;
+            case KBO_DRIVE_PHOTOTAXIS: {
+                /* kilobot.py:318-333 */
+                int upd = st->pt_update[o + b];
+                if (upd % 6 == 0) {
+                    float meas = lval;
+                    if (meas > st->pt_threshold[o + b] || st->pt_nochange[o + b] >= 15) {
+                        st->pt_threshold[o + b] = meas + 0.01f;
+                        if (st->pt_dir[o + b] == 0) { st->pt_dir[o + b] = 1; st->motor_l[o + b] = 0; st->motor_r[o + b] = 255; }
+                        else { st->pt_dir[o + b] = 0; st->motor_l[o + b] = 255; st->motor_r[o + b] = 0; }
+                        st->pt_nochange[o + b] = 0;
+                    } else st->pt_nochange[o + b] += 1;
+                }
+                st->pt_update[o + b] = upd + 1;
+            } /* fallthrough */
+            case KBO_DRIVE_MOTORS:
+                motor_law(st->motor_l[o + b], st->motor_r[o + b], th, h, &bvx, &bvy, &bw);
+                break;
+            case KBO_DRIVE_SIMPLE_PHOTOTAXIS: {
+                /* kilobot.py:191-203 */
+                float n = sqrtf(lgx * lgx + lgy * lgy);
+                float mx = lgx, my = lgy;
+                if (n > 0.01f) { mx = lgx / n * 0.01f; my = lgy / n * 0.01f; }
+                bvx = mx * WORLD_SCALE; bvy = my * WORLD_SCALE; bw = 0.0f;
+            } break;
+            default: break;
+            }
+        }
+        w->vx[b] = bvx; w->vy[b] = bvy; w->bw[b] = bw;
+        if (st->cmd_vx) { st->cmd_vx[o + b] = bvx; st->cmd_vy[o + b] = bvy; st->cmd_w[o + b] = bw; }
+    }
+    world_step_env(cfg, d, st, e, w);
+    for (int b = 0; b < N; ++b) { st->x[o + b] = w->px[b]; st->y[o + b] = w->py[b]; }
+    if (st->status) st->status[e] |= w->status;
+}
+
+static int work_alloc(work_t *w, const kbo_config *cfg, const derived_t *d) {
+    memset(w, 0, sizeof(*w));
+    int N = cfg->num_bots, M = cfg->num_objects, T = N + M;
+    w->N = N; w->M = M; w->S = cfg->ws_slots;
+    w->px = (float *)malloc(sizeof(float) * T * 5);
+    w->py = w->px + T; w->vx = w->py + T; w->vy = w->vx + T; w->bw = w->vy + T;
+    w->cell = (int *)malloc(sizeof(int) * T * 3); w->cx = w->cell + T; w->cy = w->cx + T;
+    w->cell_start = (int *)malloc(sizeof(int) * (d->gw * d->gh + 1));
+    w->cell_items = (int *)malloc(sizeof(int) * T);
+    /* contact capacity per env (must equal the HIP kernel's, kb_contact_capacity) */
+    long cap = (long)N * (N - 1) / 2 + 4L * N;
+    if (cap > 2304) cap = 2304;
+    if (cap < 4L * N + 64) cap = 4L * N + 64;
+    w->cap = (int)cap;
+    w->con = (contact_t *)malloc(sizeof(contact_t) * w->cap);
+    w->parent = (int *)malloc(sizeof(int) * T);
+    w->active = (unsigned char *)malloc(2 * (size_t)T); w->next_active = w->active + T;
+    return (w->px && w->cell && w->cell_start && w->cell_items && w->con && w->parent && w->active) ? 0 : -1;
+}
+static void work_free(work_t *w) {
+    free(w->px); free(w->cell); free(w->cell_start); free(w->cell_items); free(w->con); free(w->parent); free(w->active);
+}
+
+int kbo_step(const kbo_config *cfg, kbo_state *st, const float *light_action, int n_substeps, int flags,
+             int num_threads) {
+    if (!cfg || !st || cfg->num_bots < 1 || cfg->num_envs < 1 || cfg->num_objects != 0) return -1;
+    derived_t d; derive(cfg, &d);
+    int nt = num_threads > 1 ? num_threads : 1;
+    int err = 0;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nt)
+#endif
+    {
+        work_t w;
+        int ok = work_alloc(&w, cfg, &d) == 0;
+        if (!ok) {
+#ifdef _OPENMP
+#pragma omp atomic write
+#endif
+            err = -2;
+        }
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+        for (int e = 0; e < cfg->num_envs; ++e) {
+            if (!ok) continue;
+            w.status = 0;
+            for (int s = 0; s < n_substeps; ++s) substep_env(cfg, &d, st, light_action, flags, e, &w);
+        }
+        work_free(&w);
+    }
+    (void)nt;
+    return err;
+}
+
+int kbo_set_actions(const kbo_config *cfg, kbo_state *st, const float *actions) {
+    const size_t T = (size_t)cfg->num_envs * cfg->num_bots;
+    const float mw = 0.5f * 3.14159265358979323846f;
+    for (size_t i = 0; i < T; ++i) {
+        float a0 = actions ? actions[2 * i] : 0.0f, a1 = actions ? actions[2 * i + 1] : 0.0f;
+        if (cfg->drive_mode == KBO_DRIVE_VELOCITY) {
+            /* kilobot.py:216-218, 235-241 */
+            st->v[i] = fmaxf(fminf(a0, 0.01f), 0.0f);
+            st->w[i] = fmaxf(fminf(a1, mw), -mw);
+        } else if (cfg->drive_mode == KBO_DRIVE_ACCEL) {
+            /* kilobot.py:269, 283-289 */
+            const float aw = 0.2f * 3.14159265358979323846f;
+            st->acc_v[i] = fmaxf(fminf(a0, 0.005f), -0.005f);
+            st->acc_w[i] = fmaxf(fminf(a1, aw), -aw);
+        } else return -1;
+    }
+    return 0;
+}
+
+int kbo_count_contacts(const kbo_config *cfg, const kbo_state *st, int env, int *n_botbot, int *n_wall) {
+    derived_t d; derive(cfg, &d);
+    work_t w;
+    if (work_alloc(&w, cfg, &d) != 0) return -2;
+    const size_t o = (size_t)env * cfg->num_bots;
+    for (int b = 0; b < cfg->num_bots; ++b) { w.px[b] = st->x[o + b]; w.py[b] = st->y[o + b]; }
+    detect_env(cfg, &d, st, env, &w);
+    int nb = 0, nw = 0;
+    for (int i = 0; i < w.ncon; ++i) { if (w.con[i].a < 0) nw++; else nb++; }
+    if (n_botbot) *n_botbot = nb;
+    if (n_wall) *n_wall = nw;
+    int r = w.status;
+    work_free(&w);
+    return r;
+}
