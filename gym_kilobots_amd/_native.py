@@ -1,0 +1,135 @@
+"""ctypes binding of libkilobots_hip.so (include/kilobots_hip.h).
+
+The library is the product: there is no CPU fallback.  If it is missing this module raises
+ImportError-like RuntimeError at load() time with the build command.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libkilobots_hip.so')
+
+KB_OK, KB_EINVAL, KB_ENOTBOUND, KB_EHIP, KB_ELDS = 0, -1, -2, -3, -4
+DRIVE_VELOCITY, DRIVE_ACCEL, DRIVE_MOTORS, DRIVE_SIMPLE_PHOTOTAXIS, DRIVE_PHOTOTAXIS = range(5)
+LIGHT_NONE, LIGHT_CIRCULAR = 0, 1
+STEP_NO_DRIVE = 1
+MAX_OBJECTS = 8
+MAX_BOTS = 1024
+WORLD_SCALE = 25.0    # reference gym_kilobots/lib/body.py:7
+
+
+class KbConfig(C.Structure):
+    _fields_ = [
+        ('num_envs', C.c_int32), ('num_bots', C.c_int32), ('num_objects', C.c_int32),
+        ('world_width', C.c_float), ('world_height', C.c_float),
+        ('dt', C.c_float), ('vel_iters', C.c_int32), ('pos_iters', C.c_int32),
+        ('drive_mode', C.c_int32), ('light_type', C.c_int32),
+        ('bot_radius', C.c_float), ('bot_density', C.c_float),
+        ('bot_linear_damping', C.c_float), ('bot_angular_damping', C.c_float),
+        ('light_radius', C.c_float),
+        ('light_lo', C.c_float * 2), ('light_hi', C.c_float * 2),
+        ('light_act_lo', C.c_float * 2), ('light_act_hi', C.c_float * 2),
+        ('light_max_velocity', C.c_float),
+        ('ws_slots', C.c_int32),
+        ('obj_radius', C.c_float * MAX_OBJECTS),
+        ('obj_density', C.c_float), ('obj_friction', C.c_float),
+        ('obj_linear_damping', C.c_float), ('obj_angular_damping', C.c_float),
+        ('toi_walls', C.c_int32),
+    ]
+
+
+_P = C.c_void_p
+
+BUFFER_FIELDS = ['x', 'y', 'theta', 'v', 'w', 'acc_v', 'acc_w', 'motor_l', 'motor_r',
+                 'pt_threshold', 'pt_update', 'pt_nochange', 'pt_dir',
+                 'light_x', 'light_y', 'light_vx', 'light_vy',
+                 'ox', 'oy', 'otheta', 'ovx', 'ovy', 'ow',
+                 'ws_key', 'ws_acc', 'ws_cnt',
+                 'light_value', 'light_gx', 'light_gy', 'cmd_vx', 'cmd_vy', 'cmd_w', 'status']
+
+
+class KbBuffers(C.Structure):
+    _fields_ = [(n, _P) for n in BUFFER_FIELDS]
+
+
+EXPORTS = ['kb_create', 'kb_destroy', 'kb_bind', 'kb_set_actions', 'kb_step', 'kb_get_poses',
+           'kb_lds_bytes', 'kb_contact_capacity', 'kb_block_threads', 'kb_set_block_threads',
+           'kb_last_error', 'kb_version']
+
+_lib = None
+
+
+class KilobotsHipError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the HIP library; fails loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise KilobotsHipError(
+            'libkilobots_hip.so is missing (%s). Build it with `python -m gym_kilobots_amd.build` '
+            '(needs hipcc; cross-compiles for gfx950 without a GPU). There is no CPU fallback.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.kb_create.argtypes = [C.POINTER(KbConfig), C.POINTER(_P)]
+    lib.kb_create.restype = C.c_int
+    lib.kb_destroy.argtypes = [_P]
+    lib.kb_destroy.restype = None
+    lib.kb_bind.argtypes = [_P, C.POINTER(KbBuffers)]
+    lib.kb_bind.restype = C.c_int
+    lib.kb_set_actions.argtypes = [_P, _P, _P]
+    lib.kb_set_actions.restype = C.c_int
+    lib.kb_step.argtypes = [_P, _P, _P, C.c_int, C.c_int, _P]
+    lib.kb_step.restype = C.c_int
+    lib.kb_get_poses.argtypes = [_P, _P, _P]
+    lib.kb_get_poses.restype = C.c_int
+    for name in ('kb_lds_bytes', 'kb_contact_capacity', 'kb_block_threads'):
+        getattr(lib, name).argtypes = [_P]
+        getattr(lib, name).restype = C.c_int
+    lib.kb_set_block_threads.argtypes = [_P, C.c_int]
+    lib.kb_set_block_threads.restype = C.c_int
+    lib.kb_last_error.argtypes = []
+    lib.kb_last_error.restype = C.c_char_p
+    lib.kb_version.argtypes = []
+    lib.kb_version.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != KB_OK:
+        msg = load().kb_last_error().decode('utf-8', 'replace')
+        raise KilobotsHipError('%s failed (%d): %s' % (what, rc, msg))
+
+
+def default_config(num_envs, num_bots, drive_mode=DRIVE_VELOCITY, light_type=LIGHT_NONE, **kw):
+    """Reference defaults: kilobots_env.py:19,25-28; kilobot.py:9,25-30,214; body.py:11-16; light.py:49-54,152."""
+    inf = float('inf')
+    c = KbConfig()
+    c.num_envs, c.num_bots, c.num_objects = num_envs, num_bots, 0
+    c.world_width, c.world_height = 2.0, 1.5
+    c.dt, c.vel_iters, c.pos_iters = 0.1, 10, 10
+    c.drive_mode, c.light_type = drive_mode, light_type
+    c.bot_radius = 0.0165
+    c.bot_density = 2.0 if drive_mode in (DRIVE_VELOCITY, DRIVE_ACCEL) else 1.0
+    c.bot_linear_damping = c.bot_angular_damping = 0.8
+    c.light_radius = 0.2
+    c.light_lo[0] = c.light_lo[1] = -inf
+    c.light_hi[0] = c.light_hi[1] = inf
+    c.light_act_lo[0] = c.light_act_lo[1] = -0.01
+    c.light_act_hi[0] = c.light_act_hi[1] = 0.01
+    c.light_max_velocity = inf
+    c.ws_slots = 8
+    c.obj_density, c.obj_friction = 2.0, 0.01
+    c.obj_linear_damping = c.obj_angular_damping = 0.8
+    c.toi_walls = 0
+    for k, v in kw.items():
+        cur = getattr(c, k)
+        if hasattr(cur, '__len__'):
+            for i, vi in enumerate(v):
+                cur[i] = vi
+        else:
+            setattr(c, k, v)
+    return c

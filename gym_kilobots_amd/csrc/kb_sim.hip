@@ -1,0 +1,830 @@
+// kb_sim.hip -- batched Kilobot world step for MI355X (gfx950 / CDNA4) + its C ABI.
+//
+// One workgroup owns one env for the whole launch: the env's SoA state is loaded once from HBM
+// into LDS, `n_substeps` iterations of the reference substep loop
+// (gym_kilobots/envs/kilobots_env.py:168-190) run entirely out of LDS, and the poses are written
+// back once.  Per substep:
+//   drive law (kilobot.py:86-127,191-203,253-258,294-300,318-333) + light (light.py:59-75,176-189)
+//   -> uniform-grid broadphase in LDS (count / scan / scatter, 3x3 half stencil)
+//   -> circle-circle / circle-wall narrowphase (Box2D b2CollideCircles, b2CollideEdgeAndCircle)
+//   -> warm start + 10 sequential-impulse velocity iterations (b2ContactSolver)
+//   -> symplectic Euler (b2Island::Solve) -> <=10 position iterations with per-island early out.
+// Gauss-Seidel order: contacts are bucketed into rounds (class, rank); two contacts of one round
+// never share a body, so a round runs in parallel and the result equals the sequential sweep in
+// the canonical (class, group, A, B) order that DESIGN.md defines.  No MFMA: this is LDS/HBM work.
+//
+// Arithmetic: fp32, compiled with -ffp-contract=off; every expression is written in the same
+// operation order as the specification in DESIGN.md so that results do not depend on how many
+// substeps are fused into a launch or on how envs are sharded over GPUs.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "kilobots_hip.h"
+
+namespace {
+
+// ---- Box2D 2.3.1 constants (b2Settings.h) ---------------------------------------------------
+constexpr float B2_PI = 3.14159265359f;
+constexpr float B2_LINEAR_SLOP = 0.005f;
+constexpr float B2_POLYGON_RADIUS = 2.0f * B2_LINEAR_SLOP;
+constexpr float B2_BAUMGARTE = 0.2f;
+constexpr float B2_MAX_LINEAR_CORRECTION = 0.2f;
+constexpr float B2_MAX_TRANSLATION = 2.0f;
+constexpr float B2_MAX_TRANSLATION_SQ = B2_MAX_TRANSLATION * B2_MAX_TRANSLATION;
+constexpr float B2_MAX_ROTATION = 0.5f * B2_PI;
+constexpr float B2_MAX_ROTATION_SQ = B2_MAX_ROTATION * B2_MAX_ROTATION;
+constexpr float B2_EPSILON = 1.19209290e-07f;
+constexpr float WORLD_SCALE = 25.0f;  // body.py:7
+
+constexpr float CELL_SIZE = 0.875f;   // world units, >= 2 * bot radius
+constexpr int MAX_CELLS = 8192;
+
+constexpr unsigned KEY_WALL = 0x10000u;
+constexpr int WALL_CODE = 0xFFF0;     // ca[] value of wall w is WALL_CODE + w
+
+// contact classes in canonical order; +1 on E/N/NE/NW for odd base-cell parity
+constexpr int CLS_SAME = 0, CLS_E = 1, CLS_N = 3, CLS_NE = 5, CLS_NW = 7, CLS_WALL = 9, NUM_CLS = 10;
+constexpr int RMAX = 64;              // ranks per class
+constexpr int NKEYS = NUM_CLS * RMAX;
+
+enum { M_NCON = 0, M_NROUNDS = 1, M_ANY0 = 2, M_ANY1 = 3, M_STATUS = 4, M_COUNT = 8 };
+
+struct Layout {  // byte offsets into dynamic LDS
+    int px, py, vx, vy, th, bw;
+    int cellEnd, dirCnt, parent, roundStart, roundFill, roundFlag, misc, wsum;
+    int cacc, cnx, cny;
+    int ca, cb, ckey, order, cellItems, cellOf, label, roundList;
+    int cslot, wsCnt, wsCntNew, active;
+    int total;
+};
+
+struct Params {
+    kb_buffers buf;
+    const float *actions;
+    const float *light_action;
+    int N, E, S, gw, gh, ncell, cap, n_substeps, flags, drive_mode, light_type, vel_iters, pos_iters;
+    float xmin, ymin, xmax, ymax, inv_cell, r_bot, im_bot, kl_bot, ka_bot, h;
+    float light_radius, light_lo[2], light_hi[2], act_lo[2], act_hi[2];
+    Layout L;
+};
+
+Layout make_layout(int N, int ncell, int cap) {
+    Layout L;
+    int o = 0;
+    auto take = [&](int bytes) { int r = o; o += (bytes + 15) & ~15; return r; };
+    L.px = take(4 * N); L.py = take(4 * N); L.vx = take(4 * N); L.vy = take(4 * N);
+    L.th = take(4 * N); L.bw = take(4 * N);
+    L.cellEnd = take(4 * ncell); L.dirCnt = take(4 * N); L.parent = take(4 * N);
+    L.roundStart = take(4 * (NKEYS + 1)); L.roundFill = take(4 * NKEYS); L.roundFlag = take(4 * NKEYS);
+    L.misc = take(4 * M_COUNT); L.wsum = take(4 * 16);
+    L.cacc = take(4 * cap); L.cnx = take(4 * cap); L.cny = take(4 * cap);
+    L.ca = take(2 * cap); L.cb = take(2 * cap); L.ckey = take(2 * cap); L.order = take(2 * cap);
+    L.cellItems = take(2 * N); L.cellOf = take(2 * N); L.label = take(2 * N); L.roundList = take(2 * NKEYS);
+    L.cslot = take(cap); L.wsCnt = take(N); L.wsCntNew = take(N); L.active = take(2 * N);
+    L.total = o;
+    return L;
+}
+
+// ---- device math ----------------------------------------------------------------------------
+// sin/cos: Cephes single-precision algorithm (argument reduction by pi/4 in three parts, degree-3
+// minimax polynomials in x^2).  Own implementation so that results are identical wherever the
+// same specification is evaluated in IEEE fp32.
+__device__ __forceinline__ void kb_sincosf(float xx, float &sn, float &cs) {
+    const float DP1 = 0.78515625f, DP2 = 2.4187564849853515625e-4f, DP3 = 3.77489497744594108e-8f;
+    const float FOPI = 1.27323954473516f;
+    float x = fabsf(xx);
+    int j = (int)(FOPI * x);
+    float y = (float)j;
+    if (j & 1) { j += 1; y += 1.0f; }
+    j &= 7;
+    float ssign = xx < 0.0f ? -1.0f : 1.0f, csign = 1.0f;
+    if (j > 3) { ssign = -ssign; csign = -csign; j -= 4; }
+    if (j > 1) csign = -csign;
+    x = ((x - y * DP1) - y * DP2) - y * DP3;
+    float z = x * x;
+    float pc = ((2.443315711809948E-005f * z - 1.388731625493765E-003f) * z + 4.166664568298827E-002f) * z * z
+               - 0.5f * z + 1.0f;
+    float ps = ((-1.9515295891E-4f * z + 8.3321608736E-3f) * z - 1.6666654611E-1f) * z * x + x;
+    if (j == 1 || j == 2) { sn = ssign * pc; cs = csign * ps; }
+    else { sn = ssign * ps; cs = csign * pc; }
+}
+
+// CircularGradientLight.value_and_gradients, light.py:176-189 (zero gradient instead of NaN at distance 0)
+__device__ __forceinline__ void kb_light_circular(float sx, float sy, float lx, float ly, float R,
+                                                  float &val, float &gx, float &gy) {
+    float dx = -1.0f * (sx - lx), dy = -1.0f * (sy - ly);
+    float n = sqrtf(dx * dx + dy * dy);
+    float v = 1.0f - n / R;
+    v = fmaxf(fminf(v, 1.0f), 0.0f);
+    val = v * 255.0f;
+    if (n > 0.0f) { dx = dx / n; dy = dy / n; }
+    else { dx = 0.0f; dy = 0.0f; }
+    if (n > R) { dx *= 0.0f; dy *= 0.0f; }
+    gx = dx; gy = dy;
+}
+
+// Kilobot.step motor law, kilobot.py:86-127; body velocity in world units
+__device__ __forceinline__ void kb_motor_law(int ml, int mr, float th, float h, float &vx, float &vy, float &w) {
+    const float max_lin = 0.01f, max_ang = 0.5f * 3.14159265358979323846f;
+    float s, c;
+    kb_sincosf(th, s, c);
+    if (ml && mr) {  // kilobot.py:97-101 (intended meaning; the reference raises TypeError at :127)
+        float lin = (float)(mr + ml) / 510.0f * max_lin;
+        vx = (s * lin) * WORLD_SCALE; vy = (c * lin) * WORLD_SCALE;
+        w = (float)(mr - ml) / 510.0f * max_ang;
+    } else if (mr || ml) {  // kilobot.py:103-121: pivot about the opposite leg
+        float av, lx, ly = -0.009f;
+        if (mr) { av = (float)mr / 255.0f * max_ang; lx = -0.013f; }
+        else { av = -(float)ml / 255.0f * max_ang; lx = 0.013f; }
+        float ds, dc;
+        kb_sincosf(av * h, ds, dc);
+        float tx = lx - (dc * lx - ds * ly), ty = ly - (ds * lx + dc * ly);
+        tx *= WORLD_SCALE; ty *= WORLD_SCALE;
+        float wx = c * tx - s * ty, wy = s * tx + c * ty;  // b2Body::GetWorldVector
+        wx = wx / WORLD_SCALE / h; wy = wy / WORLD_SCALE / h;
+        vx = wx * WORLD_SCALE; vy = wy * WORLD_SCALE; w = av;
+    } else {
+        vx = 0.0f; vy = 0.0f; w = 0.0f;
+    }
+}
+
+__device__ __forceinline__ float kb_clampf(float a, float lo, float hi) { return fmaxf(lo, fminf(a, hi)); }
+
+// in-place exclusive scan of a[0..n) by the whole workgroup (all threads must call)
+__device__ void block_excl_scan(unsigned *a, int n, unsigned *wsum) {
+    const int nt = blockDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int chunk = (n + nt - 1) / nt;
+    const int s = tid * chunk, e = min(n, s + chunk);
+    unsigned sum = 0;
+    for (int i = s; i < e; ++i) sum += a[i];
+    unsigned incl = sum;
+    for (int d = 1; d < 64; d <<= 1) {
+        unsigned t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    unsigned base = 0;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    unsigned run = base + incl - sum;
+    for (int i = s; i < e; ++i) { unsigned v = a[i]; a[i] = run; run += v; }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void wall_geom(const Params &p, int wl, float x, float y, float &dist, float &nx, float &ny) {
+    switch (wl) {
+    case 0: nx = 1.0f; ny = 0.0f; dist = x - p.xmin; break;
+    case 1: nx = 0.0f; ny = 1.0f; dist = y - p.ymin; break;
+    case 2: nx = -1.0f; ny = 0.0f; dist = p.xmax - x; break;
+    default: nx = 0.0f; ny = -1.0f; dist = p.ymax - y; break;
+    }
+}
+
+__global__ void __launch_bounds__(1024) kb_step_kernel(const Params p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int e = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int N = p.N, S = p.S;
+    const size_t o = (size_t)e * N;
+    const float h = p.h;
+
+    float *px = (float *)(smem + p.L.px), *py = (float *)(smem + p.L.py);
+    float *vx = (float *)(smem + p.L.vx), *vy = (float *)(smem + p.L.vy);
+    float *th = (float *)(smem + p.L.th), *bw = (float *)(smem + p.L.bw);
+    unsigned *cellEnd = (unsigned *)(smem + p.L.cellEnd), *dirCnt = (unsigned *)(smem + p.L.dirCnt);
+    unsigned *parent = (unsigned *)(smem + p.L.parent);
+    unsigned *roundStart = (unsigned *)(smem + p.L.roundStart), *roundFill = (unsigned *)(smem + p.L.roundFill);
+    unsigned *roundFlag = (unsigned *)(smem + p.L.roundFlag);
+    unsigned *misc = (unsigned *)(smem + p.L.misc), *wsum = (unsigned *)(smem + p.L.wsum);
+    float *cacc = (float *)(smem + p.L.cacc), *cnx = (float *)(smem + p.L.cnx), *cny = (float *)(smem + p.L.cny);
+    unsigned short *ca = (unsigned short *)(smem + p.L.ca), *cb = (unsigned short *)(smem + p.L.cb);
+    unsigned short *ckey = (unsigned short *)(smem + p.L.ckey), *order = (unsigned short *)(smem + p.L.order);
+    unsigned short *cellItems = (unsigned short *)(smem + p.L.cellItems), *cellOf = (unsigned short *)(smem + p.L.cellOf);
+    unsigned short *label = (unsigned short *)(smem + p.L.label), *roundList = (unsigned short *)(smem + p.L.roundList);
+    unsigned char *cslot = smem + p.L.cslot, *wsCnt = smem + p.L.wsCnt, *wsCntNew = smem + p.L.wsCntNew;
+    unsigned char *active = smem + p.L.active;
+
+    const kb_buffers &g = p.buf;
+
+    // ---- load state; optional fused set_action (kilobot.py:235-241, 283-289) ----
+    for (int b = tid; b < N; b += nt) {
+        px[b] = g.x[o + b]; py[b] = g.y[o + b]; th[b] = g.theta[o + b];
+        if (p.actions) {
+            const float2 a = reinterpret_cast<const float2 *>(p.actions)[o + b];
+            const float mw = 0.5f * 3.14159265358979323846f;
+            if (p.drive_mode == KB_DRIVE_VELOCITY) {
+                g.v[o + b] = fmaxf(fminf(a.x, 0.01f), 0.0f);
+                g.w[o + b] = fmaxf(fminf(a.y, mw), -mw);
+            } else if (p.drive_mode == KB_DRIVE_ACCEL) {
+                const float aw = 0.2f * 3.14159265358979323846f;
+                g.acc_v[o + b] = fmaxf(fminf(a.x, 0.005f), -0.005f);
+                g.acc_w[o + b] = fmaxf(fminf(a.y, aw), -aw);
+            }
+        }
+    }
+    if (tid == 0) misc[M_STATUS] = 0;
+    float lx = 0.0f, ly = 0.0f;
+    if (p.light_type == KB_LIGHT_CIRCULAR) { lx = g.light_x[e]; ly = g.light_y[e]; }
+    const bool drive = !(p.flags & KB_STEP_NO_DRIVE);
+    const float rr = p.r_bot + p.r_bot, rr2 = rr * rr;
+    const float rw = B2_POLYGON_RADIUS + p.r_bot, rw2 = rw * rw;
+    __syncthreads();
+
+    for (int sub = 0; sub < p.n_substeps; ++sub) {
+        // ---- light.step: SinglePositionLight.step, light.py:59-75 (uniform per env) ----
+        if (p.light_action && p.light_type == KB_LIGHT_CIRCULAR && drive) {
+            float ax = fminf(fmaxf(p.light_action[2 * e + 0], p.act_lo[0]), p.act_hi[0]);
+            float ay = fminf(fmaxf(p.light_action[2 * e + 1], p.act_lo[1]), p.act_hi[1]);
+            float nlx = lx + ax * h, nly = ly + ay * h;
+            lx = fminf(fmaxf(nlx, p.light_lo[0]), p.light_hi[0]);
+            ly = fminf(fmaxf(nly, p.light_lo[1]), p.light_hi[1]);
+        }
+        // ---- sensing + drive law + damping; reset per-substep scratch ----
+        for (int b = tid; b < N; b += nt) {
+            float bvx = 0.0f, bvy = 0.0f, bww = 0.0f;
+            if (drive) {
+                const float t = th[b];
+                float lval = 0.0f, lgx = 0.0f, lgy = 0.0f;
+                if (p.light_type == KB_LIGHT_CIRCULAR) {
+                    float sx = px[b], sy = py[b];
+                    if (p.drive_mode != KB_DRIVE_SIMPLE_PHOTOTAXIS) {  // kilobot.py:54-55: world point of (0, -r)
+                        float s, c;
+                        kb_sincosf(t, s, c);
+                        const float lx0 = 0.0f, ly0 = -p.r_bot;
+                        sx = (c * lx0 - s * ly0) + px[b];
+                        sy = (s * lx0 + c * ly0) + py[b];
+                    }
+                    kb_light_circular(sx / WORLD_SCALE, sy / WORLD_SCALE, lx, ly, p.light_radius, lval, lgx, lgy);
+                    if (g.light_value) { g.light_value[o + b] = lval; g.light_gx[o + b] = lgx; g.light_gy[o + b] = lgy; }
+                }
+                switch (p.drive_mode) {
+                case KB_DRIVE_ACCEL: {  // kilobot.py:294-300
+                    float v = g.v[o + b] + g.acc_v[o + b] * h, ww = g.w[o + b] + g.acc_w[o + b] * h;
+                    const float mw = 0.5f * 3.14159265358979323846f;
+                    v = fminf(fmaxf(v, 0.0f), 0.01f); ww = fminf(fmaxf(ww, -mw), mw);
+                    g.v[o + b] = v; g.w[o + b] = ww;
+                    float s, c;
+                    kb_sincosf(t, s, c);
+                    float sp = v * WORLD_SCALE;
+                    bvx = c * sp; bvy = s * sp; bww = ww;
+                } break;
+                case KB_DRIVE_VELOCITY: {  // kilobot.py:253-258
+                    float s, c;
+                    kb_sincosf(t, s, c);
+                    float sp = g.v[o + b] * WORLD_SCALE;
+                    bvx = c * sp; bvy = s * sp; bww = g.w[o + b];
+                } break;
+                case KB_DRIVE_PHOTOTAXIS: {  // kilobot.py:318-333
+                    int upd = g.pt_update[o + b];
+                    if (upd % 6 == 0) {
+                        float meas = lval;
+                        if (meas > g.pt_threshold[o + b] || g.pt_nochange[o + b] >= 15) {
+                            g.pt_threshold[o + b] = meas + 0.01f;
+                            if (g.pt_dir[o + b] == 0) { g.pt_dir[o + b] = 1; g.motor_l[o + b] = 0; g.motor_r[o + b] = 255; }
+                            else { g.pt_dir[o + b] = 0; g.motor_l[o + b] = 255; g.motor_r[o + b] = 0; }
+                            g.pt_nochange[o + b] = 0;
+                        } else g.pt_nochange[o + b] += 1;
+                    }
+                    g.pt_update[o + b] = upd + 1;
+                    kb_motor_law(g.motor_l[o + b], g.motor_r[o + b], t, h, bvx, bvy, bww);
+                } break;
+                case KB_DRIVE_MOTORS:
+                    kb_motor_law(g.motor_l[o + b], g.motor_r[o + b], t, h, bvx, bvy, bww);
+                    break;
+                case KB_DRIVE_SIMPLE_PHOTOTAXIS: {  // kilobot.py:191-203
+                    float n = sqrtf(lgx * lgx + lgy * lgy);
+                    float mx = lgx, my = lgy;
+                    if (n > 0.01f) { mx = lgx / n * 0.01f; my = lgy / n * 0.01f; }
+                    bvx = mx * WORLD_SCALE; bvy = my * WORLD_SCALE; bww = 0.0f;
+                } break;
+                default: break;
+                }
+            }
+            if (g.cmd_vx) { g.cmd_vx[o + b] = bvx; g.cmd_vy[o + b] = bvy; g.cmd_w[o + b] = bww; }
+            // b2Island::Solve: v *= 1/(1 + h c)  (SimplePhototaxisKilobot sets linearDamping = 0, kilobot.py:203)
+            const float kl = (p.drive_mode == KB_DRIVE_SIMPLE_PHOTOTAXIS) ? 1.0f / (1.0f + h * 0.0f) : p.kl_bot;
+            vx[b] = bvx * kl; vy[b] = bvy * kl; bw[b] = bww * p.ka_bot;
+            wsCnt[b] = g.ws_cnt[o + b];
+            parent[b] = b;
+        }
+        for (int c = tid; c < p.ncell; c += nt) cellEnd[c] = 0;
+        for (int k = tid; k < NKEYS; k += nt) { roundStart[k] = 0; roundFill[k] = 0; roundFlag[k] = 0; }
+        if (tid == 0) { roundStart[NKEYS] = 0; misc[M_NCON] = 0; misc[M_NROUNDS] = 0; misc[M_ANY0] = 0; misc[M_ANY1] = 0; }
+        __syncthreads();
+
+        // ---- broadphase: uniform grid, count -> scan -> scatter -> in-cell sort by id ----
+        for (int b = tid; b < N; b += nt) {
+            int cx = (int)floorf((px[b] - p.xmin) * p.inv_cell);
+            int cy = (int)floorf((py[b] - p.ymin) * p.inv_cell);
+            cx = cx < 0 ? 0 : (cx >= p.gw ? p.gw - 1 : cx);
+            cy = cy < 0 ? 0 : (cy >= p.gh ? p.gh - 1 : cy);
+            const int cell = cy * p.gw + cx;
+            cellOf[b] = (unsigned short)cell;
+            atomicAdd(&cellEnd[cell], 1u);
+        }
+        __syncthreads();
+        block_excl_scan(cellEnd, p.ncell, wsum);
+        for (int b = tid; b < N; b += nt) {
+            const unsigned pos = atomicAdd(&cellEnd[cellOf[b]], 1u);  // afterwards cellEnd[c] = end of cell c
+            cellItems[pos] = (unsigned short)b;
+        }
+        __syncthreads();
+        for (int b = tid; b < N; b += nt) {
+            const int cell = cellOf[b];
+            const int s = cell ? (int)cellEnd[cell - 1] : 0, en = (int)cellEnd[cell];
+            int idx = 0;
+            for (int it = s; it < en; ++it) idx += (cellItems[it] < b) ? 1 : 0;
+            label[b] = (unsigned short)(s + idx);
+        }
+        __syncthreads();
+        for (int b = tid; b < N; b += nt) cellItems[label[b]] = (unsigned short)b;
+        __syncthreads();
+
+        // ---- narrowphase pass 1: per bot, number of contacts it owns per direction (for ranks) ----
+        for (int a = tid; a < N; a += nt) {
+            const int cell = cellOf[a];
+            const int cx = cell % p.gw, cy = cell / p.gw;
+            const float ax = px[a], ay = py[a];
+            unsigned cnt = 0;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const int ddx = (k == 1 || k == 3) ? 1 : (k == 4 ? -1 : 0), ddy = (k >= 2) ? 1 : 0;
+                const int ox = cx + ddx, oy = cy + ddy;
+                if (ox < 0 || ox >= p.gw || oy >= p.gh) continue;
+                const int oc = oy * p.gw + ox;
+                const int s = oc ? (int)cellEnd[oc - 1] : 0, en = (int)cellEnd[oc];
+                unsigned ck = 0;
+                for (int it = s; it < en; ++it) {
+                    const int b = cellItems[it];
+                    if (k == 0 && b <= a) continue;
+                    const float dx = px[b] - ax, dy = py[b] - ay;
+                    const float dd = dx * dx + dy * dy;
+                    if (dd > rr2) continue;  // b2CollideCircles
+                    ck++;
+                }
+                if (ck > 63u) { ck = 63u; atomicOr(&misc[M_STATUS], 4u); }
+                cnt |= ck << (6 * k);
+            }
+            dirCnt[a] = cnt;
+        }
+        __syncthreads();
+
+        // ---- narrowphase pass 2: emit contacts with (class, rank) round keys + warm-start impulses ----
+        for (int a = tid; a < N; a += nt) {
+            const int cell = cellOf[a];
+            const int cx = cell % p.gw, cy = cell / p.gw;
+            const float ax = px[a], ay = py[a];
+            const int own_s = cell ? (int)cellEnd[cell - 1] : 0;
+            const unsigned mycnt = dirCnt[a];
+            int nslot = 0;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                if (((mycnt >> (6 * k)) & 63u) == 0u) continue;
+                const int ddx = (k == 1 || k == 3) ? 1 : (k == 4 ? -1 : 0), ddy = (k >= 2) ? 1 : 0;
+                const int oc = (cy + ddy) * p.gw + (cx + ddx);
+                int cls;
+                if (k == 0) cls = CLS_SAME;
+                else if (k == 1) cls = CLS_E + (cx & 1);
+                else if (k == 2) cls = CLS_N + (cy & 1);
+                else if (k == 3) cls = CLS_NE + (cx & 1);
+                else cls = CLS_NW + (cx & 1);
+                // rank base: contacts of this (cell, direction) group owned by lower-id bots of the cell
+                int rank = 0;
+                for (int it = own_s;; ++it) {
+                    const int a2 = cellItems[it];
+                    if (a2 >= a) break;
+                    rank += (int)((dirCnt[a2] >> (6 * k)) & 63u);
+                }
+                const int s = oc ? (int)cellEnd[oc - 1] : 0, en = (int)cellEnd[oc];
+                for (int it = s; it < en; ++it) {
+                    const int b = cellItems[it];
+                    if (k == 0 && b <= a) continue;
+                    const float dx = px[b] - ax, dy = py[b] - ay;
+                    const float dd = dx * dx + dy * dy;
+                    if (dd > rr2) continue;
+                    // warm start: impulse of the same pair in the previous substep (b2Contact::Update id match)
+                    float acc = 0.0f;
+                    bool found = false;
+                    for (int sl = 0; sl < (int)wsCnt[a] && sl < S; ++sl) {
+                        const size_t idx = ((size_t)e * S + sl) * N + a;
+                        if (g.ws_key[idx] == (unsigned)b) { acc = g.ws_acc[idx]; found = true; break; }
+                    }
+                    if (!found) {
+                        for (int sl = 0; sl < (int)wsCnt[b] && sl < S; ++sl) {
+                            const size_t idx = ((size_t)e * S + sl) * N + b;
+                            if (g.ws_key[idx] == (unsigned)a) { acc = g.ws_acc[idx]; break; }
+                        }
+                    }
+                    const int slot = nslot < S ? nslot : 255;
+                    if (slot == 255) atomicOr(&misc[M_STATUS], 2u);
+                    nslot++;
+                    int r = rank++;
+                    if (r >= RMAX) { r = RMAX - 1; atomicOr(&misc[M_STATUS], 4u); }
+                    const unsigned c = atomicAdd(&misc[M_NCON], 1u);
+                    if (c >= (unsigned)p.cap) { atomicOr(&misc[M_STATUS], 1u); continue; }
+                    // b2WorldManifold::Initialize (circles)
+                    float nx = 1.0f, ny = 0.0f;
+                    if (dd > B2_EPSILON * B2_EPSILON) {
+                        const float len = sqrtf(dd);
+                        const float inv = 1.0f / len;
+                        nx = dx * inv; ny = dy * inv;
+                    }
+                    const int key = cls * RMAX + r;
+                    ca[c] = (unsigned short)a; cb[c] = (unsigned short)b; ckey[c] = (unsigned short)key;
+                    cacc[c] = acc; cnx[c] = nx; cny[c] = ny; cslot[c] = (unsigned char)slot;
+                    atomicAdd(&roundStart[key], 1u);
+                }
+            }
+            // walls: b2CollideEdgeAndCircle (region AB) against the chain loop of kilobots_env.py:48-51
+            int wrank = 0;
+#pragma unroll
+            for (int wl = 0; wl < 4; ++wl) {
+                float dist, nx, ny;
+                wall_geom(p, wl, ax, ay, dist, nx, ny);
+                if (dist * dist > rw2) continue;
+                float acc = 0.0f;
+                for (int sl = 0; sl < (int)wsCnt[a] && sl < S; ++sl) {
+                    const size_t idx = ((size_t)e * S + sl) * N + a;
+                    if (g.ws_key[idx] == KEY_WALL + (unsigned)wl) { acc = g.ws_acc[idx]; break; }
+                }
+                const int slot = nslot < S ? nslot : 255;
+                if (slot == 255) atomicOr(&misc[M_STATUS], 2u);
+                nslot++;
+                const int r = wrank++;
+                const unsigned c = atomicAdd(&misc[M_NCON], 1u);
+                if (c >= (unsigned)p.cap) { atomicOr(&misc[M_STATUS], 1u); continue; }
+                if (dist < 0.0f) { nx = -nx; ny = -ny; }  // normal flips towards the circle centre
+                const int key = CLS_WALL * RMAX + r;
+                ca[c] = (unsigned short)(WALL_CODE + wl); cb[c] = (unsigned short)a; ckey[c] = (unsigned short)key;
+                cacc[c] = acc; cnx[c] = nx; cny[c] = ny; cslot[c] = (unsigned char)slot;
+                atomicAdd(&roundStart[key], 1u);
+            }
+            wsCntNew[a] = (unsigned char)(nslot < S ? nslot : S);
+        }
+        __syncthreads();
+        const int ncon = min((int)misc[M_NCON], p.cap);
+
+        // ---- rounds: counting sort of contacts by key, list of non-empty rounds ----
+        for (int k = tid; k < NKEYS; k += nt) roundFlag[k] = roundStart[k] ? 1u : 0u;
+        __syncthreads();
+        block_excl_scan(roundStart, NKEYS + 1, wsum);
+        block_excl_scan(roundFlag, NKEYS, wsum);
+        for (int k = tid; k < NKEYS; k += nt) {
+            if (roundStart[k + 1] > roundStart[k]) roundList[roundFlag[k]] = (unsigned short)k;
+        }
+        if (tid == 0) {
+            int last = NKEYS - 1;
+            misc[M_NROUNDS] = roundFlag[last] + ((roundStart[NKEYS] > roundStart[last]) ? 1u : 0u);
+        }
+        for (int c = tid; c < ncon; c += nt) {
+            const int key = ckey[c];
+            const unsigned pos = roundStart[key] + atomicAdd(&roundFill[key], 1u);
+            order[pos] = (unsigned short)c;
+        }
+        // islands: lock-free union-find over dynamic-dynamic contacts (larger root hooks under smaller)
+        for (int c = tid; c < ncon; c += nt) {
+            if (ca[c] >= WALL_CODE) continue;
+            unsigned ra = ca[c], rb = cb[c];
+            for (;;) {
+                while (true) { unsigned q = ((volatile unsigned *)parent)[ra]; if (q == ra) break; ra = q; }
+                while (true) { unsigned q = ((volatile unsigned *)parent)[rb]; if (q == rb) break; rb = q; }
+                if (ra == rb) break;
+                if (ra < rb) { unsigned t = ra; ra = rb; rb = t; }
+                if (atomicCAS(&parent[ra], ra, rb) == ra) break;
+            }
+        }
+        __syncthreads();
+        const int nrounds = (int)misc[M_NROUNDS];
+        for (int b = tid; b < N; b += nt) {
+            unsigned r = b;
+            while (true) { unsigned q = parent[r]; if (q == r) break; r = q; }
+            label[b] = (unsigned short)r;
+            active[b] = 1; active[N + b] = 0;
+        }
+        // (the next barrier is the one closing the first warm-start round)
+
+        // ---- b2ContactSolver::WarmStart, in round order ----
+        for (int ri = 0; ri < nrounds; ++ri) {
+            const int key = roundList[ri];
+            const int s = (int)roundStart[key], en = (int)roundStart[key + 1];
+            for (int i = s + tid; i < en; i += nt) {
+                const int c = order[i];
+                const int a = ca[c], b = cb[c];
+                const float Px = cacc[c] * cnx[c], Py = cacc[c] * cny[c];
+                if (a < WALL_CODE) { vx[a] -= p.im_bot * Px; vy[a] -= p.im_bot * Py; }
+                vx[b] += p.im_bot * Px; vy[b] += p.im_bot * Py;
+            }
+            __syncthreads();
+        }
+        // ---- SolveVelocityConstraints: friction 0, restitution 0, one manifold point ----
+        for (int it = 0; it < p.vel_iters; ++it) {
+            for (int ri = 0; ri < nrounds; ++ri) {
+                const int key = roundList[ri];
+                const int s = (int)roundStart[key], en = (int)roundStart[key + 1];
+                for (int i = s + tid; i < en; i += nt) {
+                    const int c = order[i];
+                    const int a = ca[c], b = cb[c];
+                    const float nx = cnx[c], ny = cny[c];
+                    float vax = 0.0f, vay = 0.0f, ima = 0.0f;
+                    if (a < WALL_CODE) { vax = vx[a]; vay = vy[a]; ima = p.im_bot; }
+                    const float vbx = vx[b], vby = vy[b];
+                    const float dvx = vbx - vax, dvy = vby - vay;
+                    const float vn = dvx * nx + dvy * ny;
+                    const float k = ima + p.im_bot;
+                    const float nm = k > 0.0f ? 1.0f / k : 0.0f;
+                    float lambda = -(nm * vn);
+                    const float accOld = cacc[c];
+                    const float newimp = fmaxf(accOld + lambda, 0.0f);
+                    lambda = newimp - accOld;
+                    cacc[c] = newimp;
+                    const float Px = lambda * nx, Py = lambda * ny;
+                    if (a < WALL_CODE) { vx[a] = vax - ima * Px; vy[a] = vay - ima * Py; }
+                    vx[b] = vbx + p.im_bot * Px; vy[b] = vby + p.im_bot * Py;
+                }
+                __syncthreads();
+            }
+        }
+        // ---- StoreImpulses -> warm-start cache of the next substep ----
+        for (int c = tid; c < ncon; c += nt) {
+            const int sl = cslot[c];
+            if (sl == 255) continue;
+            const int a = ca[c], b = cb[c];
+            const int owner = a < WALL_CODE ? a : b;
+            const unsigned key = a < WALL_CODE ? (unsigned)b : KEY_WALL + (unsigned)(a - WALL_CODE);
+            const size_t idx = ((size_t)e * S + sl) * N + owner;
+            g.ws_key[idx] = key; g.ws_acc[idx] = cacc[c];
+        }
+        // ---- integrate positions (b2Island::Solve) ----
+        for (int b = tid; b < N; b += nt) {
+            g.ws_cnt[o + b] = wsCntNew[b];
+            float vxx = vx[b], vyy = vy[b], ww = bw[b];
+            const float tx = h * vxx, ty = h * vyy;
+            if (tx * tx + ty * ty > B2_MAX_TRANSLATION_SQ) {
+                const float ratio = B2_MAX_TRANSLATION / sqrtf(tx * tx + ty * ty);
+                vxx *= ratio; vyy *= ratio;
+            }
+            const float rot = h * ww;
+            if (rot * rot > B2_MAX_ROTATION_SQ) {
+                const float ratio = B2_MAX_ROTATION / fabsf(rot);
+                ww *= ratio;
+            }
+            px[b] += h * vxx; py[b] += h * vyy;
+            th[b] += h * ww;
+        }
+        __syncthreads();
+        // ---- SolvePositionConstraints; an island stops once its minSeparation >= -3 slop ----
+        for (int it = 0; it < p.pos_iters; ++it) {
+            unsigned char *act = active + (it & 1) * N, *nxt = active + ((it + 1) & 1) * N;
+            for (int ri = 0; ri < nrounds; ++ri) {
+                const int key = roundList[ri];
+                const int s = (int)roundStart[key], en = (int)roundStart[key + 1];
+                for (int i = s + tid; i < en; i += nt) {
+                    const int c = order[i];
+                    const int a = ca[c], b = cb[c];
+                    const int isl = label[b];
+                    if (!act[isl]) continue;
+                    float nx, ny, sep, ima = 0.0f;
+                    const float bx = px[b], by = py[b];
+                    float axx = 0.0f, ayy = 0.0f;
+                    if (a >= WALL_CODE) {
+                        float dist, wx, wy;
+                        wall_geom(p, a - WALL_CODE, bx, by, dist, wx, wy);
+                        nx = cnx[c]; ny = cny[c];  // manifold normal fixed at detection
+                        const float along = (nx == wx && ny == wy) ? dist : -dist;
+                        sep = along - B2_POLYGON_RADIUS - p.r_bot;
+                    } else {
+                        axx = px[a]; ayy = py[a]; ima = p.im_bot;
+                        const float dx = bx - axx, dy = by - ayy;
+                        const float len = sqrtf(dx * dx + dy * dy);
+                        nx = dx; ny = dy;
+                        if (!(len < B2_EPSILON)) { const float inv = 1.0f / len; nx = dx * inv; ny = dy * inv; }
+                        sep = (dx * nx + dy * ny) - p.r_bot - p.r_bot;
+                    }
+                    if (sep < -3.0f * B2_LINEAR_SLOP) { nxt[isl] = 1; misc[M_ANY0 + ((it + 1) & 1)] = 1u; }
+                    const float C = kb_clampf(B2_BAUMGARTE * (sep + B2_LINEAR_SLOP), -B2_MAX_LINEAR_CORRECTION, 0.0f);
+                    const float K = ima + p.im_bot;
+                    const float imp = K > 0.0f ? -C / K : 0.0f;
+                    const float Px = imp * nx, Py = imp * ny;
+                    if (a < WALL_CODE) { px[a] = axx - ima * Px; py[a] = ayy - ima * Py; }
+                    px[b] = bx + p.im_bot * Px; py[b] = by + p.im_bot * Py;
+                }
+                __syncthreads();
+            }
+            const bool any = misc[M_ANY0 + ((it + 1) & 1)] != 0u;
+            __syncthreads();
+            if (!any) break;
+            // prepare the flags the next iteration writes
+            for (int b = tid; b < N; b += nt) act[b] = 0;
+            if (tid == 0) misc[M_ANY0 + (it & 1)] = 0u;
+            __syncthreads();
+        }
+        __syncthreads();
+    }
+
+    // ---- write back ----
+    for (int b = tid; b < N; b += nt) { g.x[o + b] = px[b]; g.y[o + b] = py[b]; g.theta[o + b] = th[b]; }
+    if (tid == 0) {
+        if (p.light_type == KB_LIGHT_CIRCULAR && p.light_action && drive) { g.light_x[e] = lx; g.light_y[e] = ly; }
+        if (misc[M_STATUS]) atomicOr(&g.status[e], (int)misc[M_STATUS]);
+    }
+}
+
+// set_action alone (kilobot.py:235-241, 283-289)
+__global__ void kb_set_actions_kernel(const Params p) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t T = (size_t)p.E * p.N;
+    if (i >= T) return;
+    float a0 = 0.0f, a1 = 0.0f;
+    if (p.actions) { const float2 a = reinterpret_cast<const float2 *>(p.actions)[i]; a0 = a.x; a1 = a.y; }
+    if (p.drive_mode == KB_DRIVE_VELOCITY) {
+        const float mw = 0.5f * 3.14159265358979323846f;
+        p.buf.v[i] = fmaxf(fminf(a0, 0.01f), 0.0f);
+        p.buf.w[i] = fmaxf(fminf(a1, mw), -mw);
+    } else {
+        const float aw = 0.2f * 3.14159265358979323846f;
+        p.buf.acc_v[i] = fmaxf(fminf(a0, 0.005f), -0.005f);
+        p.buf.acc_w[i] = fmaxf(fminf(a1, aw), -aw);
+    }
+}
+
+// Body.get_pose for every kilobot (body.py:63-65): metres, radians
+__global__ void kb_get_poses_kernel(const float *x, const float *y, const float *th, float *out, size_t T) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T) return;
+    out[3 * i + 0] = x[i] / WORLD_SCALE;
+    out[3 * i + 1] = y[i] / WORLD_SCALE;
+    out[3 * i + 2] = th[i];
+}
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, const char *detail = "") {
+    snprintf(g_err, sizeof(g_err), fmt, detail);
+    return code;
+}
+
+}  // namespace
+
+struct kb_sim {
+    kb_config cfg;
+    Params p;
+    bool bound;
+    int threads;
+};
+
+extern "C" {
+
+const char *kb_last_error(void) { return g_err; }
+const char *kb_version(void) { return "kilobots_hip 0.1 (gfx950)"; }
+
+int kb_create(const kb_config *cfg, kb_sim **out) {
+    if (!cfg || !out) return fail(KB_EINVAL, "kb_create: NULL argument");
+    if (cfg->num_envs < 1 || cfg->num_bots < 1 || cfg->num_bots > KB_MAX_BOTS)
+        return fail(KB_EINVAL, "kb_create: num_envs >= 1 and 1 <= num_bots <= 1024 required");
+    if (cfg->num_objects != 0) return fail(KB_EINVAL, "kb_create: objects are not supported by this version");
+    if (cfg->drive_mode < 0 || cfg->drive_mode > KB_DRIVE_PHOTOTAXIS) return fail(KB_EINVAL, "kb_create: bad drive_mode");
+    if (cfg->light_type != KB_LIGHT_NONE && cfg->light_type != KB_LIGHT_CIRCULAR)
+        return fail(KB_EINVAL, "kb_create: unsupported light_type");
+    if ((cfg->drive_mode == KB_DRIVE_SIMPLE_PHOTOTAXIS || cfg->drive_mode == KB_DRIVE_PHOTOTAXIS) &&
+        cfg->light_type == KB_LIGHT_NONE)
+        return fail(KB_EINVAL, "kb_create: phototaxis drive modes need a light");
+    if (cfg->ws_slots < 1 || cfg->ws_slots > 64) return fail(KB_EINVAL, "kb_create: 1 <= ws_slots <= 64 required");
+    if (!(cfg->dt > 0.0f) || cfg->vel_iters < 0 || cfg->pos_iters < 0 || !(cfg->world_width > 0.0f) ||
+        !(cfg->world_height > 0.0f) || !(cfg->bot_radius > 0.0f) || !(cfg->bot_density > 0.0f))
+        return fail(KB_EINVAL, "kb_create: non-positive dt / size / radius / density");
+    kb_sim *s = new (std::nothrow) kb_sim();
+    if (!s) return fail(KB_EINVAL, "kb_create: out of host memory");
+    s->cfg = *cfg;
+    s->bound = false;
+    Params &p = s->p;
+    memset(&p, 0, sizeof(p));
+    p.N = cfg->num_bots; p.E = cfg->num_envs; p.S = cfg->ws_slots;
+    p.drive_mode = cfg->drive_mode; p.light_type = cfg->light_type;
+    p.vel_iters = cfg->vel_iters; p.pos_iters = cfg->pos_iters;
+    const float W = cfg->world_width * WORLD_SCALE, H = cfg->world_height * WORLD_SCALE;
+    p.xmin = -0.5f * W; p.xmax = 0.5f * W; p.ymin = -0.5f * H; p.ymax = 0.5f * H;
+    float cell = CELL_SIZE;
+    const float dmin = 2.0f * cfg->bot_radius * WORLD_SCALE;
+    while (cell < dmin) cell *= 2.0f;
+    for (;;) {
+        p.inv_cell = 1.0f / cell;
+        p.gw = (int)ceilf(W * p.inv_cell); if (p.gw < 1) p.gw = 1;
+        p.gh = (int)ceilf(H * p.inv_cell); if (p.gh < 1) p.gh = 1;
+        if ((long)p.gw * p.gh <= MAX_CELLS) break;
+        cell *= 2.0f;
+    }
+    p.ncell = p.gw * p.gh;
+    p.h = cfg->dt;
+    p.r_bot = cfg->bot_radius * WORLD_SCALE;
+    const float m = cfg->bot_density * B2_PI * p.r_bot * p.r_bot;  // b2CircleShape::ComputeMass
+    p.im_bot = m > 0.0f ? 1.0f / m : 0.0f;
+    p.kl_bot = 1.0f / (1.0f + p.h * cfg->bot_linear_damping);
+    p.ka_bot = 1.0f / (1.0f + p.h * cfg->bot_angular_damping);
+    p.light_radius = cfg->light_radius;
+    for (int i = 0; i < 2; ++i) {
+        p.light_lo[i] = cfg->light_lo[i]; p.light_hi[i] = cfg->light_hi[i];
+        p.act_lo[i] = cfg->light_act_lo[i]; p.act_hi[i] = cfg->light_act_hi[i];
+    }
+    long cap = (long)p.N * (p.N - 1) / 2 + 4L * p.N;
+    if (cap > 2304) cap = 2304;
+    if (cap < 4L * p.N + 64) cap = 4L * p.N + 64;
+    p.cap = (int)cap;
+    p.L = make_layout(p.N, p.ncell, p.cap);
+    if (p.L.total > 160 * 1024) {
+        delete s;
+        return fail(KB_ELDS, "kb_create: configuration needs more than 160 KiB of LDS per env");
+    }
+    s->threads = p.N <= 64 ? 64 : (p.N <= 128 ? 128 : 256);
+    *out = s;
+    return KB_OK;
+}
+
+void kb_destroy(kb_sim *sim) { delete sim; }
+
+int kb_bind(kb_sim *sim, const kb_buffers *b) {
+    if (!sim || !b) return fail(KB_EINVAL, "kb_bind: NULL argument");
+    if (!b->x || !b->y || !b->theta || !b->ws_key || !b->ws_acc || !b->ws_cnt || !b->status)
+        return fail(KB_ENOTBOUND, "kb_bind: x, y, theta, ws_key, ws_acc, ws_cnt and status are required");
+    const int m = sim->cfg.drive_mode;
+    if ((m == KB_DRIVE_VELOCITY || m == KB_DRIVE_ACCEL) && (!b->v || !b->w))
+        return fail(KB_ENOTBOUND, "kb_bind: v and w are required in the velocity / acceleration modes");
+    if (m == KB_DRIVE_ACCEL && (!b->acc_v || !b->acc_w)) return fail(KB_ENOTBOUND, "kb_bind: acc_v, acc_w required");
+    if ((m == KB_DRIVE_MOTORS || m == KB_DRIVE_PHOTOTAXIS) && (!b->motor_l || !b->motor_r))
+        return fail(KB_ENOTBOUND, "kb_bind: motor_l, motor_r required");
+    if (m == KB_DRIVE_PHOTOTAXIS && (!b->pt_threshold || !b->pt_update || !b->pt_nochange || !b->pt_dir))
+        return fail(KB_ENOTBOUND, "kb_bind: pt_* buffers required in the phototaxis mode");
+    if (sim->cfg.light_type != KB_LIGHT_NONE && (!b->light_x || !b->light_y))
+        return fail(KB_ENOTBOUND, "kb_bind: light_x, light_y required when a light is configured");
+    if ((b->light_value != nullptr) != (b->light_gx != nullptr) || (b->light_value != nullptr) != (b->light_gy != nullptr))
+        return fail(KB_EINVAL, "kb_bind: light_value, light_gx, light_gy must be given together");
+    if ((b->cmd_vx != nullptr) != (b->cmd_vy != nullptr) || (b->cmd_vx != nullptr) != (b->cmd_w != nullptr))
+        return fail(KB_EINVAL, "kb_bind: cmd_vx, cmd_vy, cmd_w must be given together");
+    sim->p.buf = *b;
+    sim->bound = true;
+    return KB_OK;
+}
+
+int kb_set_actions(kb_sim *sim, const float *d_actions, void *stream) {
+    if (!sim) return fail(KB_EINVAL, "kb_set_actions: NULL handle");
+    if (!sim->bound) return fail(KB_ENOTBOUND, "kb_set_actions: kb_bind() first");
+    if (sim->cfg.drive_mode != KB_DRIVE_VELOCITY && sim->cfg.drive_mode != KB_DRIVE_ACCEL)
+        return fail(KB_EINVAL, "kb_set_actions: only the velocity / acceleration drive modes take actions");
+    Params p = sim->p;
+    p.actions = d_actions;
+    const size_t T = (size_t)p.E * p.N;
+    hipLaunchKernelGGL(kb_set_actions_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return fail(KB_EHIP, "kb_set_actions: %s", hipGetErrorString(err));
+    return KB_OK;
+}
+
+int kb_step(kb_sim *sim, const float *d_actions, const float *d_light_action, int n_substeps, int flags, void *stream) {
+    if (!sim) return fail(KB_EINVAL, "kb_step: NULL handle");
+    if (!sim->bound) return fail(KB_ENOTBOUND, "kb_step: kb_bind() first");
+    if (n_substeps < 0) return fail(KB_EINVAL, "kb_step: n_substeps < 0");
+    if (d_actions && sim->cfg.drive_mode != KB_DRIVE_VELOCITY && sim->cfg.drive_mode != KB_DRIVE_ACCEL)
+        return fail(KB_EINVAL, "kb_step: only the velocity / acceleration drive modes take actions");
+    if (n_substeps == 0 && !d_actions) return KB_OK;
+    Params p = sim->p;
+    p.actions = d_actions;
+    p.light_action = d_light_action;
+    p.n_substeps = n_substeps;
+    p.flags = flags;
+    static thread_local int attr_set_for = -1;
+    if (p.L.total > 64 * 1024 && attr_set_for != p.L.total) {
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(kb_step_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, p.L.total);
+        if (e2 != hipSuccess) return fail(KB_EHIP, "kb_step: hipFuncSetAttribute: %s", hipGetErrorString(e2));
+        attr_set_for = p.L.total;
+    }
+    hipLaunchKernelGGL(kb_step_kernel, dim3((unsigned)p.E), dim3((unsigned)sim->threads), (size_t)p.L.total,
+                       (hipStream_t)stream, p);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return fail(KB_EHIP, "kb_step: %s", hipGetErrorString(err));
+    return KB_OK;
+}
+
+int kb_get_poses(kb_sim *sim, float *d_out, void *stream) {
+    if (!sim || !d_out) return fail(KB_EINVAL, "kb_get_poses: NULL argument");
+    if (!sim->bound) return fail(KB_ENOTBOUND, "kb_get_poses: kb_bind() first");
+    const size_t T = (size_t)sim->p.E * sim->p.N;
+    hipLaunchKernelGGL(kb_get_poses_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       sim->p.buf.x, sim->p.buf.y, sim->p.buf.theta, d_out, T);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return fail(KB_EHIP, "kb_get_poses: %s", hipGetErrorString(err));
+    return KB_OK;
+}
+
+int kb_lds_bytes(const kb_sim *sim) { return sim ? sim->p.L.total : KB_EINVAL; }
+int kb_contact_capacity(const kb_sim *sim) { return sim ? sim->p.cap : KB_EINVAL; }
+int kb_block_threads(const kb_sim *sim) { return sim ? sim->threads : KB_EINVAL; }
+int kb_set_block_threads(kb_sim *sim, int threads) {
+    if (!sim || threads < 64 || threads > 1024 || (threads & 63)) return fail(KB_EINVAL, "kb_set_block_threads: multiple of 64 in [64, 1024]");
+    sim->threads = threads;
+    return KB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,145 @@
+"""KilobotSim: device buffers (torch-ROCm tensors) + the HIP world step behind the C ABI.
+
+This is the host side of the hot path only.  torch is used for device memory and streams; all
+simulation arithmetic happens inside libkilobots_hip.so (gym_kilobots_amd/csrc/kb_sim.hip).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _native as nat
+from ._native import (DRIVE_VELOCITY, DRIVE_ACCEL, DRIVE_MOTORS, DRIVE_SIMPLE_PHOTOTAXIS,  # noqa: F401
+                      DRIVE_PHOTOTAXIS, LIGHT_NONE, LIGHT_CIRCULAR, STEP_NO_DRIVE, WORLD_SCALE)
+
+
+class KilobotSim:
+    """num_envs independent worlds of num_bots kilobots, resident on one GPU.
+
+    State tensors are [num_envs, num_bots] float32 in Box2D world units (metres x 25), exactly
+    what the reference's b2Body objects hold; `poses()` returns metres like Body.get_pose
+    (reference gym_kilobots/lib/body.py:63-65).
+    """
+
+    def __init__(self, num_envs, num_bots, drive_mode=DRIVE_VELOCITY, light_type=LIGHT_NONE,
+                 device=None, debug_outputs=False, **cfg_overrides):
+        self._lib = nat.load()                      # raises if the HIP library is not built
+        if not torch.cuda.is_available():
+            raise nat.KilobotsHipError('KilobotSim needs a ROCm GPU (torch.cuda.is_available() is False); '
+                                       'there is no CPU fallback')
+        self.device = torch.device(device if device is not None else 'cuda:%d' % torch.cuda.current_device())
+        self.cfg = nat.default_config(num_envs, num_bots, drive_mode, light_type, **cfg_overrides)
+        self.num_envs, self.num_bots = num_envs, num_bots
+        self.drive_mode, self.light_type = drive_mode, light_type
+        self._h = C.c_void_p()
+        nat.check(self._lib.kb_create(C.byref(self.cfg), C.byref(self._h)), 'kb_create')
+        E, N, S = num_envs, num_bots, self.cfg.ws_slots
+        dev = self.device
+        f = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        self.x, self.y, self.theta = f(E, N), f(E, N), f(E, N)
+        self.v = self.w = self.acc_v = self.acc_w = None
+        self.motor_l = self.motor_r = None
+        self.pt_threshold = self.pt_update = self.pt_nochange = self.pt_dir = None
+        self.light_x = self.light_y = None
+        if drive_mode in (DRIVE_VELOCITY, DRIVE_ACCEL):
+            self.v, self.w = f(E, N), f(E, N)
+        if drive_mode == DRIVE_ACCEL:
+            self.acc_v, self.acc_w = f(E, N), f(E, N)
+        if drive_mode in (DRIVE_MOTORS, DRIVE_PHOTOTAXIS):
+            # Kilobot._setup -> turn_left (kilobot.py:78-81, 315-316)
+            self.motor_l = torch.full((E, N), 255, dtype=torch.uint8, device=dev)
+            self.motor_r = torch.zeros(E, N, dtype=torch.uint8, device=dev)
+        if drive_mode == DRIVE_PHOTOTAXIS:
+            self.pt_threshold = torch.full((E, N), float('-inf'), dtype=torch.float32, device=dev)
+            self.pt_update = torch.zeros(E, N, dtype=torch.int32, device=dev)
+            self.pt_nochange = torch.zeros(E, N, dtype=torch.int32, device=dev)
+            self.pt_dir = torch.zeros(E, N, dtype=torch.uint8, device=dev)
+        if light_type != LIGHT_NONE:
+            self.light_x, self.light_y = f(E), f(E)
+        self.ws_key = torch.zeros(E, S, N, dtype=torch.int32, device=dev)
+        self.ws_acc = f(E, S, N)
+        self.ws_cnt = torch.zeros(E, N, dtype=torch.uint8, device=dev)
+        self.status = torch.zeros(E, dtype=torch.int32, device=dev)
+        self.light_value = self.light_gx = self.light_gy = None
+        self.cmd_vx = self.cmd_vy = self.cmd_w = None
+        if debug_outputs:
+            self.light_value, self.light_gx, self.light_gy = f(E, N), f(E, N), f(E, N)
+            self.cmd_vx, self.cmd_vy, self.cmd_w = f(E, N), f(E, N), f(E, N)
+        self._bind()
+
+    # ------------------------------------------------------------------ plumbing
+    def _bind(self):
+        b = nat.KbBuffers()
+        for name in nat.BUFFER_FIELDS:
+            t = getattr(self, name, None)
+            setattr(b, name, None if t is None else t.data_ptr())
+        nat.check(self._lib.kb_bind(self._h, C.byref(b)), 'kb_bind')
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h:
+            self._lib.kb_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def lds_bytes(self):
+        return self._lib.kb_lds_bytes(self._h)
+
+    @property
+    def contact_capacity(self):
+        return self._lib.kb_contact_capacity(self._h)
+
+    @property
+    def block_threads(self):
+        return self._lib.kb_block_threads(self._h)
+
+    @block_threads.setter
+    def block_threads(self, n):
+        nat.check(self._lib.kb_set_block_threads(self._h, int(n)), 'kb_set_block_threads')
+
+    # ------------------------------------------------------------------ state
+    def set_poses_m(self, xy_m, theta):
+        """Body poses in metres / radians; stored as fp32 world units like body.py:32-34 does."""
+        xy = np.asarray(xy_m, np.float64) * WORLD_SCALE
+        self.x.copy_(torch.from_numpy(np.ascontiguousarray(xy[..., 0].astype(np.float32))).reshape(self.x.shape))
+        self.y.copy_(torch.from_numpy(np.ascontiguousarray(xy[..., 1].astype(np.float32))).reshape(self.y.shape))
+        self.theta.copy_(torch.from_numpy(np.ascontiguousarray(np.asarray(theta, np.float32))).reshape(self.theta.shape))
+        self.forget_contacts()
+
+    def forget_contacts(self):
+        """Drop all warm-start impulses (bodies were re-created / teleported)."""
+        self.ws_cnt.zero_()
+
+    def poses(self):
+        """[num_envs, num_bots, 3] float32 (x [m], y [m], theta): get_state()['kilobots'] of every env."""
+        out = torch.empty(self.num_envs, self.num_bots, 3, dtype=torch.float32, device=self.device)
+        nat.check(self._lib.kb_get_poses(self._h, C.c_void_p(out.data_ptr()), self._stream()), 'kb_get_poses')
+        return out
+
+    # ------------------------------------------------------------------ stepping
+    @staticmethod
+    def _ptr(t, shape, name):
+        if t is None:
+            return None
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == tuple(shape)):
+            raise ValueError('%s must be a contiguous float32 cuda tensor of shape %s' % (name, tuple(shape)))
+        return C.c_void_p(t.data_ptr())
+
+    def set_actions(self, actions):
+        """set_action of every kilobot (clamped); actions [E, N, 2] cuda float32 or None (= zeros)."""
+        p = self._ptr(actions, (self.num_envs, self.num_bots, 2), 'actions')
+        nat.check(self._lib.kb_set_actions(self._h, p, self._stream()), 'kb_set_actions')
+
+    def step(self, n_substeps=1, actions=None, light_action=None, flags=0):
+        """n_substeps iterations of the reference substep loop in one kernel launch (asynchronous)."""
+        pa = self._ptr(actions, (self.num_envs, self.num_bots, 2), 'actions')
+        pl = self._ptr(light_action, (self.num_envs, 2), 'light_action')
+        nat.check(self._lib.kb_step(self._h, pa, pl, int(n_substeps), int(flags), self._stream()), 'kb_step')

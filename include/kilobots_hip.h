@@ -1,0 +1,148 @@
+/*
+ * kilobots_hip.h -- C ABI of libkilobots_hip.so: the MI355X (gfx950) batched Kilobot world step.
+ *
+ * This is the drop-in boundary for the one hot path this library replaces: the substep loop of
+ * gym-kilobots' `KilobotsEnv.step` (reference gym_kilobots/envs/kilobots_env.py:161-215), i.e.
+ * light step -> light sensing -> per-kilobot drive law -> Box2D `world.Step(0.1, 10, 10)` ->
+ * pose read-back, executed for num_envs x num_bots agents per launch.
+ *
+ * The reference has no FFI of its own (it is Python calling the SWIG module `Box2D`); every
+ * entry point below cites the reference Python interface it replaces.  The Python binding
+ * (ctypes) is gym_kilobots_amd/_native.py; INTEGRATION.md shows the stub a maintainer of the
+ * reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative KB_E* code otherwise;
+ *     kb_last_error() returns a thread-local message for the last failure;
+ *   - nothing throws across the ABI;
+ *   - all `d_*` pointers are DEVICE pointers owned by the caller (e.g. torch tensors); the
+ *     library allocates no device memory.  Buffers bound with kb_bind() must stay alive until
+ *     kb_destroy() or the next kb_bind();
+ *   - all work is enqueued asynchronously on the `hipStream_t` passed as `void *stream`
+ *     (NULL = the null stream); no call synchronises the device;
+ *   - a handle is not thread-safe; distinct handles are independent;
+ *   - arrays are SoA, shape [num_envs][num_bots], env-major, float32 unless noted;
+ *   - body poses are Box2D world units = metres x 25 (reference gym_kilobots/lib/body.py:7),
+ *     exactly what the reference's b2Body holds; kb_get_poses() converts to metres like
+ *     Body.get_pose (body.py:63-65).
+ */
+#ifndef KILOBOTS_HIP_H
+#define KILOBOTS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KB_OK 0
+#define KB_EINVAL (-1)      /* bad argument / unsupported configuration */
+#define KB_ENOTBOUND (-2)   /* kb_bind() has not been called or a required buffer is NULL */
+#define KB_EHIP (-3)        /* a HIP runtime call failed */
+#define KB_ELDS (-4)        /* configuration does not fit the 160 KiB LDS of a CU */
+
+/* drive laws: which reference Kilobot subclass every bot of the handle is */
+enum kb_drive_mode {
+    KB_DRIVE_VELOCITY = 0,          /* SimpleVelocityControlKilobot      kilobot.py:213-263 */
+    KB_DRIVE_ACCEL = 1,             /* SimpleAccelerationControlKilobot  kilobot.py:266-300 */
+    KB_DRIVE_MOTORS = 2,            /* Kilobot.step motor law            kilobot.py:86-127  */
+    KB_DRIVE_SIMPLE_PHOTOTAXIS = 3, /* SimplePhototaxisKilobot           kilobot.py:171-210 */
+    KB_DRIVE_PHOTOTAXIS = 4         /* PhototaxisKilobot                 kilobot.py:303-333 */
+};
+
+enum kb_light_type {
+    KB_LIGHT_NONE = 0,
+    KB_LIGHT_CIRCULAR = 1           /* CircularGradientLight             light.py:151-195   */
+};
+
+/* kb_step flags */
+#define KB_STEP_NO_DRIVE 1          /* world.Step only, kilobot body velocities = 0:
+                                       KilobotsEnv._step_world, kilobots_env.py:217-219 */
+
+#define KB_MAX_OBJECTS 8
+#define KB_MAX_BOTS 1024
+
+/* Scene constants.  Defaults of the reference are given in brackets. */
+typedef struct kb_config {
+    int32_t num_envs, num_bots, num_objects;    /* objects: must be 0 in this version */
+    float world_width, world_height;            /* metres [2.0, 1.5]   kilobots_env.py:19 */
+    float dt;                                   /* [0.1]               kilobots_env.py:25,32 */
+    int32_t vel_iters, pos_iters;               /* [10, 10]            kilobots_env.py:26-27 */
+    int32_t drive_mode, light_type;
+    float bot_radius;                           /* metres [0.0165]     kilobot.py:9 */
+    float bot_density;                          /* [1.0; 2.0 for the velocity/accel bots] kilobot.py:25,214 */
+    float bot_linear_damping, bot_angular_damping; /* [0.8, 0.8]       kilobot.py:29-30 */
+    float light_radius;                         /* metres [0.2]        light.py:152 */
+    float light_lo[2], light_hi[2];             /* light position bounds, light.py:44-46 */
+    float light_act_lo[2], light_act_hi[2];     /* [-0.01, 0.01]       light.py:49-54 */
+    float light_max_velocity;                   /* reserved (MomentumLight) */
+    int32_t ws_slots;                           /* warm-start slots per bot [8] */
+    float obj_radius[KB_MAX_OBJECTS];           /* reserved (objects) */
+    float obj_density, obj_friction;
+    float obj_linear_damping, obj_angular_damping;
+    int32_t toi_walls;                          /* reserved */
+} kb_config;
+
+/* Device buffers of one handle.  NULL is allowed for buffers the configuration never touches
+ * (noted per field).  Replaces the per-object state of the reference: b2Body position/angle
+ * (body.py:51-72), Kilobot._velocity / _acceleration / _motor_* (kilobot.py:37-38,225-229,277),
+ * PhototaxisKilobot counters (kilobot.py:307-313), light position (light.py:40-42). */
+typedef struct kb_buffers {
+    float *x, *y, *theta;               /* required */
+    float *v, *w;                       /* VELOCITY / ACCEL modes: commanded (v [m/s], omega [rad/s]) */
+    float *acc_v, *acc_w;               /* ACCEL mode */
+    uint8_t *motor_l, *motor_r;         /* MOTORS / PHOTOTAXIS modes */
+    float *pt_threshold;                /* PHOTOTAXIS mode */
+    int32_t *pt_update, *pt_nochange;   /* PHOTOTAXIS mode */
+    uint8_t *pt_dir;                    /* PHOTOTAXIS mode: 0 = 'left', 1 = 'right' */
+    float *light_x, *light_y;           /* [num_envs], metres; required when light_type != NONE */
+    float *light_vx, *light_vy;         /* reserved */
+    float *ox, *oy, *otheta, *ovx, *ovy, *ow; /* reserved (objects) */
+    uint32_t *ws_key;                   /* required: [num_envs][ws_slots][num_bots] */
+    float *ws_acc;                      /* required: [num_envs][ws_slots][num_bots] */
+    uint8_t *ws_cnt;                    /* required: [num_envs][num_bots]; zero it to forget all contacts */
+    float *light_value, *light_gx, *light_gy; /* optional outputs: last sensed light (kilobots_env.py:176-180) */
+    float *cmd_vx, *cmd_vy, *cmd_w;     /* optional outputs: body velocity written by the drive law */
+    int32_t *status;                    /* required: [num_envs]; bit0 contact capacity overflow,
+                                           bit1 warm-start slot overflow, bit2 rank/cell overflow */
+} kb_buffers;
+
+typedef struct kb_sim kb_sim;
+
+/* Replaces KilobotsEnv.__init__ world construction (kilobots_env.py:45-51: b2World + chain-loop
+ * walls) and Body/Circle/Kilobot fixture constants (body.py:32-38,187-192; kilobot.py:9-30). */
+int kb_create(const kb_config *cfg, kb_sim **out);
+void kb_destroy(kb_sim *sim);
+
+/* Attach caller-owned device buffers (copied by value). */
+int kb_bind(kb_sim *sim, const kb_buffers *buf);
+
+/* SimpleVelocityControlKilobot.set_action / SimpleAccelerationControlKilobot.set_action
+ * (kilobot.py:235-241, 283-289), as called per bot by DirectControlKilobotsEnv.step
+ * (direct_control_kilobots_env.py:18-27).  d_actions: [num_envs][num_bots][2] or NULL (= None). */
+int kb_set_actions(kb_sim *sim, const float *d_actions, void *stream);
+
+/* n_substeps iterations of the KilobotsEnv.step loop body (kilobots_env.py:168-190) in ONE launch.
+ * d_actions (optional): kilobot actions applied first, as kb_set_actions.
+ * d_light_action (optional): [num_envs][2] light action, applied every substep (kilobots_env.py:171-172);
+ * NULL = action None. */
+int kb_step(kb_sim *sim, const float *d_actions, const float *d_light_action, int n_substeps, int flags,
+            void *stream);
+
+/* KilobotsEnv.get_state()['kilobots'] (kilobots_env.py:115-118 -> body.py:63-72):
+ * d_out [num_envs][num_bots][3] = (x [m], y [m], theta). */
+int kb_get_poses(kb_sim *sim, float *d_out, void *stream);
+
+/* Introspection */
+int kb_lds_bytes(const kb_sim *sim);            /* dynamic LDS per workgroup (one env per workgroup) */
+int kb_contact_capacity(const kb_sim *sim);     /* contacts per env */
+int kb_block_threads(const kb_sim *sim);
+int kb_set_block_threads(kb_sim *sim, int threads);  /* multiple of 64, <= 1024 */
+const char *kb_last_error(void);
+const char *kb_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,334 @@
+"""GPU parity: the HIP world step (through the C ABI) against the CPU oracle on the same seeded
+inputs, plus size-independent properties at full benchmark size.
+
+The step is specified operation-by-operation in fp32 and both sides are compiled with
+-ffp-contract=off, so the bar here is BIT-EXACT poses, commands and warm-start impulses; the
+float32 tolerance the north star allows (1e-6 m absolute on positions) is asserted only where the
+comparison is against float64 golden data from the reference."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from tests import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def make_pair(E, N, mode=O.DRIVE_VELOCITY, light=O.LIGHT_NONE, xy=None, th=None, **kw):
+    from gym_kilobots_amd.sim import KilobotSim
+    osim = O.OracleSim(O.default_config(E, N, mode, light, **kw))
+    gsim = KilobotSim(E, N, mode, light, debug_outputs=True, **kw)
+    if xy is not None:
+        osim.set_poses_m(xy, th)
+        gsim.set_poses_m(xy, th)
+    return osim, gsim
+
+
+def cpu(t):
+    return t.detach().cpu().numpy()
+
+
+def assert_same(osim, gsim, what='', fields=('x', 'y', 'theta')):
+    torch.cuda.synchronize()
+    for f in fields:
+        a, b = getattr(osim, f), cpu(getattr(gsim, f))
+        if not np.array_equal(a, b.reshape(a.shape)):
+            d = np.abs(a.astype(np.float64) - b.reshape(a.shape).astype(np.float64))
+            raise AssertionError('%s: field %s differs: max |d| = %.3e at %s (%d of %d elements)'
+                                 % (what, f, d.max(), np.unravel_index(d.argmax(), d.shape), (d > 0).sum(), d.size))
+
+
+def assert_ws_same(osim, gsim, what=''):
+    torch.cuda.synchronize()
+    cnt_o, cnt_g = osim.ws_cnt, cpu(gsim.ws_cnt)
+    assert np.array_equal(cnt_o, cnt_g), what + ': ws_cnt differs'
+    key_g, acc_g = cpu(gsim.ws_key).view(np.uint32), cpu(gsim.ws_acc)
+    S = osim.cfg.ws_slots
+    used = np.arange(S)[None, :, None] < cnt_o[:, None, :]
+    assert np.array_equal(osim.ws_key[used], key_g[used]), what + ': ws_key differs'
+    assert np.array_equal(osim.ws_acc[used], acc_g[used]), what + ': ws_acc differs'
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('mode', [O.DRIVE_VELOCITY, O.DRIVE_ACCEL, O.DRIVE_MOTORS])
+def test_contact_free_drive_modes(mode):
+    E, N = 3, 64
+    xy, th = scenes.lattice_spawn(E, N, seed=1, pitch=0.08)
+    osim, gsim = make_pair(E, N, mode, xy=xy, th=th)
+    rng = np.random.RandomState(5)
+    if mode == O.DRIVE_MOTORS:
+        ml = rng.randint(0, 256, size=(E, N)).astype(np.uint8)
+        mr = rng.randint(0, 256, size=(E, N)).astype(np.uint8)
+        ml[0, :8] = 0
+        mr[0, 8:16] = 0
+        ml[0, 16:20] = 0
+        mr[0, 16:20] = 0
+        osim.motor_l[...] = ml
+        osim.motor_r[...] = mr
+        gsim.motor_l.copy_(dev(ml))
+        gsim.motor_r.copy_(dev(mr))
+    for k in range(4):
+        if mode != O.DRIVE_MOTORS:
+            scale = 1.0 if mode == O.DRIVE_VELOCITY else 2.0
+            a = (scenes.random_actions(E, N, seed=10 + k) * scale - (0 if mode == O.DRIVE_VELOCITY else 0.004)).astype(np.float32)
+            osim.set_actions(a)
+            gsim.set_actions(dev(a))
+        osim.step(5)
+        gsim.step(5)
+        fields = ('x', 'y', 'theta', 'cmd_vx', 'cmd_vy', 'cmd_w') + (('v', 'w') if mode != O.DRIVE_MOTORS else ())
+        assert_same(osim, gsim, 'mode %d step %d' % (mode, k), fields)
+    assert osim.count_contacts(0) == (0, 0)
+    assert int(cpu(gsim.status).max()) == 0
+
+
+def test_golden_vectors_through_the_c_abi(golden):
+    """Reference-generated vectors (tools/gen_golden.py) checked on the HIP path itself."""
+    from gym_kilobots_amd.sim import KilobotSim
+    cases = golden['a3_velocity']['cases']
+    n = len(cases)
+    g = KilobotSim(1, n, O.DRIVE_VELOCITY, debug_outputs=True)
+    xy = np.stack([np.linspace(-0.8, 0.8, n), np.zeros(n)], -1)[None]
+    g.set_poses_m(xy, np.array([[c['theta'] for c in cases]]))
+    g.step(1, actions=dev(np.array([[c['action'] for c in cases]], np.float32)))
+    torch.cuda.synchronize()
+    got = np.stack([cpu(g.cmd_vx)[0], cpu(g.cmd_vy)[0], cpu(g.cmd_w)[0]], -1)
+    np.testing.assert_allclose(got, [c['vel'] for c in cases], rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(np.stack([cpu(g.v)[0], cpu(g.w)[0]], -1), [c['clamped'] for c in cases], rtol=1e-6, atol=1e-9)
+    cases = golden['a2_motor']['cases']
+    n = len(cases)
+    g = KilobotSim(1, n, O.DRIVE_MOTORS, debug_outputs=True)
+    xy = np.stack([np.linspace(-0.9, 0.9, n), np.zeros(n)], -1)[None]
+    g.set_poses_m(xy, np.array([[c['theta'] for c in cases]]))
+    g.motor_l.copy_(dev(np.array([[c['left'] for c in cases]], np.uint8)))
+    g.motor_r.copy_(dev(np.array([[c['right'] for c in cases]], np.uint8)))
+    g.step(1)
+    torch.cuda.synchronize()
+    got = np.stack([cpu(g.cmd_vx)[0], cpu(g.cmd_vy)[0], cpu(g.cmd_w)[0]], -1)
+    np.testing.assert_allclose(got, [c['vel'] for c in cases], rtol=2e-5, atol=2e-7)
+
+
+def run_velocity_scene(E, N, xy, th, steps, substeps=10, seed=100, check_every=1, **kw):
+    osim, gsim = make_pair(E, N, O.DRIVE_VELOCITY, xy=xy, th=th, **kw)
+    for k in range(steps):
+        a = scenes.random_actions(E, N, seed=seed + k)
+        osim.set_actions(a)
+        osim.step(substeps)
+        gsim.step(substeps, actions=dev(a))
+        if (k + 1) % check_every == 0 or k == steps - 1:
+            assert_same(osim, gsim, 'env.step %d' % k, ('x', 'y', 'theta', 'v', 'w'))
+            assert_ws_same(osim, gsim, 'env.step %d' % k)
+    return osim, gsim
+
+
+def test_cfg1_one_env_16_bots_gaussian_spawn():
+    """BASELINE config 1: 1 env x 16 kilobots, random motor commands, 100 env.steps."""
+    xy, th = scenes.gaussian_spawn(1, 16, sigma=0.1, seed=0, random_theta=False)
+    osim, gsim = run_velocity_scene(1, 16, xy, th, steps=100, check_every=10)
+    assert int(cpu(gsim.status).max()) == 0
+
+
+def test_cfg2_slice_64_envs_64_bots():
+    """BASELINE config 2 (256 x 64) on a 64-env slice: envs are independent, see the shard test."""
+    xy, th = scenes.gaussian_spawn(64, 64, sigma=0.15, seed=2)
+    osim, gsim = run_velocity_scene(64, 64, xy, th, steps=12, check_every=3)
+    nb = sum(osim.count_contacts(e)[0] for e in range(64))
+    assert nb > 0, 'scene is supposed to be in contact'
+    assert int(cpu(gsim.status).max()) == 0 and int(osim.status.max()) == 0
+
+
+def test_dense_cluster_256_bots():
+    xy, th = scenes.gaussian_spawn(6, 256, sigma=0.2, seed=3)
+    osim, gsim = run_velocity_scene(6, 256, xy, th, steps=4)
+    assert sum(osim.count_contacts(e)[0] for e in range(6)) > 200
+
+
+def test_1024_bots_lattice_then_crowding():
+    """1024 bots packed on a lattice slightly tighter than 2r (every neighbour pair in contact from the
+    start) and driven towards the arena centre: one big island, ~2000 contacts per env."""
+    E, N = 2, 1024
+    xy, th = scenes.lattice_spawn(E, N, seed=4, pitch=0.0325, jitter=0.0004)
+    th = np.arctan2(-xy[..., 1], -xy[..., 0])       # face the arena centre
+    osim, gsim = make_pair(E, N, O.DRIVE_VELOCITY, xy=xy, th=th)
+    a = np.zeros((E, N, 2), np.float32)
+    a[..., 0] = 0.01
+    for k in range(3):
+        osim.set_actions(a)
+        osim.step(10)
+        gsim.step(10, actions=dev(a))
+        assert_same(osim, gsim, 'crowd step %d' % k)
+        assert_ws_same(osim, gsim, 'crowd step %d' % k)
+    assert osim.count_contacts(0)[0] > 1500
+    assert int(cpu(gsim.status).max()) == 0
+
+
+def test_walls_and_corners():
+    E, N = 1, 32
+    rng = np.random.RandomState(7)
+    xy = np.zeros((E, N, 2))
+    th = np.zeros((E, N))
+    # 8 bots per wall, heading into it, plus corner huggers
+    for i in range(8):
+        xy[0, i] = (-0.97, -0.6 + 0.15 * i); th[0, i] = np.pi + rng.uniform(-0.5, 0.5)
+        xy[0, 8 + i] = (0.97, -0.6 + 0.15 * i); th[0, 8 + i] = rng.uniform(-0.5, 0.5)
+        xy[0, 16 + i] = (-0.8 + 0.2 * i, -0.72); th[0, 16 + i] = -np.pi / 2 + rng.uniform(-0.5, 0.5)
+        xy[0, 24 + i] = (-0.8 + 0.2 * i, 0.72); th[0, 24 + i] = np.pi / 2 + rng.uniform(-0.5, 0.5)
+    xy[0, 0] = (-0.975, -0.725); th[0, 0] = -3 * np.pi / 4
+    xy[0, 15] = (0.975, 0.725); th[0, 15] = np.pi / 4
+    osim, gsim = make_pair(E, N, O.DRIVE_VELOCITY, xy=xy, th=th)
+    a = np.zeros((E, N, 2), np.float32)
+    a[..., 0] = 0.01
+    for k in range(6):
+        osim.set_actions(a)
+        osim.step(10)
+        gsim.step(10, actions=dev(a))
+        assert_same(osim, gsim, 'wall step %d' % k)
+        assert_ws_same(osim, gsim, 'wall step %d' % k)
+    assert osim.count_contacts(0)[1] >= 30
+    # nobody left the arena: centre stays >= r + polygonRadius - 3 slop inside (world units / 25)
+    p = osim.poses_m()[0]
+    lim = 0.0165 + (0.01 - 0.015) / 25 - 1e-6
+    assert (np.abs(p[:, 0]) <= 1.0 - lim).all() and (np.abs(p[:, 1]) <= 0.75 - lim).all()
+
+
+@pytest.mark.parametrize('mode', [O.DRIVE_SIMPLE_PHOTOTAXIS, O.DRIVE_PHOTOTAXIS])
+def test_light_driven_modes(mode):
+    E, N = 8, 48
+    xy, th = scenes.gaussian_spawn(E, N, sigma=0.12, seed=9)
+    bounds = dict(light_lo=(-1.1, -0.825), light_hi=(1.1, 0.825), light_radius=0.4)
+    osim, gsim = make_pair(E, N, mode, O.LIGHT_CIRCULAR, xy=xy, th=th, **bounds)
+    rng = np.random.RandomState(11)
+    l0 = rng.uniform(-0.3, 0.3, size=(E, 2)).astype(np.float32)
+    osim.light_x[...] = l0[:, 0]
+    osim.light_y[...] = l0[:, 1]
+    gsim.light_x.copy_(dev(l0[:, 0]))
+    gsim.light_y.copy_(dev(l0[:, 1]))
+    fields = ('x', 'y', 'theta', 'light_x', 'light_y', 'light_value', 'light_gx', 'light_gy', 'cmd_vx', 'cmd_vy', 'cmd_w')
+    if mode == O.DRIVE_PHOTOTAXIS:
+        fields += ('motor_l', 'motor_r', 'pt_threshold', 'pt_update', 'pt_nochange', 'pt_dir')
+    for k in range(8):
+        la = rng.uniform(-0.02, 0.02, size=(E, 2)).astype(np.float32)
+        if k == 3:
+            osim.step(10)
+            gsim.step(10)               # action None: light not stepped (kilobots_env.py:171)
+        else:
+            osim.step(10, light_action=la)
+            gsim.step(10, light_action=dev(la))
+        assert_same(osim, gsim, 'light mode %d step %d' % (mode, k), fields)
+    assert int(cpu(gsim.status).max()) == 0
+
+
+def test_reset_step_resolves_overlaps_without_drive():
+    """KilobotsEnv.reset: one world.Step with zero velocities pushes overlapping bodies apart
+    (kilobots_env.py:156-157); heavy initial overlap like kilobots_test_envs.py:53-82."""
+    E, N = 4, 15
+    xy, th = scenes.gaussian_spawn(E, N, sigma=0.02, seed=13, random_theta=False)
+    xy[:, 5] = xy[:, 0]                    # exactly coincident pair (kilobots_test_envs.py:53,63)
+    osim, gsim = make_pair(E, N, O.DRIVE_VELOCITY, xy=xy, th=th, ws_slots=16)
+    d0 = np.linalg.norm(xy[:, :, None] - xy[:, None, :], axis=-1)
+    for k in range(5):
+        osim.step(1, flags=O.STEP_NO_DRIVE)
+        gsim.step(1, flags=O.STEP_NO_DRIVE)
+        assert_same(osim, gsim, 'resolve %d' % k)
+        assert_ws_same(osim, gsim, 'resolve %d' % k)
+    p = osim.poses_m()[..., :2]
+    d1 = np.linalg.norm(p[:, :, None] - p[:, None, :], axis=-1)
+    iu = np.triu_indices(N, 1)
+    assert d1[:, iu[0], iu[1]].mean() > d0[:, iu[0], iu[1]].mean()
+
+
+# ---- size-independent properties on the HIP path --------------------------------------------------
+def test_fused_launch_equals_single_substep_launches():
+    """kb_step(10) == 10 x kb_step(1), bit for bit (state incl. warm-start cache is complete)."""
+    from gym_kilobots_amd.sim import KilobotSim
+    E, N = 256, 64
+    xy, th = scenes.gaussian_spawn(E, N, sigma=0.15, seed=21)
+    a = dev(scenes.random_actions(E, N, seed=22))
+    g1 = KilobotSim(E, N)
+    g2 = KilobotSim(E, N)
+    for g in (g1, g2):
+        g.set_poses_m(xy, th)
+        g.set_actions(a)
+    for k in range(3):
+        g1.step(10)
+        for _ in range(10):
+            g2.step(1)
+    torch.cuda.synchronize()
+    for f in ('x', 'y', 'theta', 'ws_cnt'):
+        assert torch.equal(getattr(g1, f), getattr(g2, f)), f
+
+
+def test_env_shard_equals_rows_of_unsharded_run():
+    """Multi-GPU contract: shard k of the env axis == rows of the unsharded run."""
+    from gym_kilobots_amd.sim import KilobotSim
+    E, N = 64, 64
+    xy, th = scenes.gaussian_spawn(E, N, sigma=0.15, seed=31)
+    a = scenes.random_actions(E, N, seed=32)
+    full = KilobotSim(E, N)
+    full.set_poses_m(xy, th)
+    sl = slice(16, 32)
+    part = KilobotSim(16, N)
+    part.set_poses_m(xy[sl], th[sl])
+    for k in range(3):
+        full.step(10, actions=dev(a))
+        part.step(10, actions=dev(a[sl]))
+    torch.cuda.synchronize()
+    for f in ('x', 'y', 'theta'):
+        assert torch.equal(getattr(full, f)[sl], getattr(part, f)), f
+
+
+def test_block_size_does_not_change_results():
+    from gym_kilobots_amd.sim import KilobotSim
+    E, N = 8, 256
+    xy, th = scenes.gaussian_spawn(E, N, sigma=0.2, seed=41)
+    a = dev(scenes.random_actions(E, N, seed=42))
+    outs = []
+    for threads in (64, 256, 1024):
+        g = KilobotSim(E, N)
+        g.block_threads = threads
+        g.set_poses_m(xy, th)
+        g.step(10, actions=a)
+        g.step(10)
+        torch.cuda.synchronize()
+        outs.append((g.x.clone(), g.y.clone(), g.theta.clone()))
+    for o in outs[1:]:
+        for t0, t1 in zip(outs[0], o):
+            assert torch.equal(t0, t1)
+
+
+def test_cfg3_full_size_invariants_and_slice_parity():
+    """BASELINE config 3 (4096 envs x 1024 bots): invariants on the whole batch, oracle parity on a slice."""
+    from gym_kilobots_amd.sim import KilobotSim
+    E, N = 4096, 1024
+    xy1, th1 = scenes.lattice_spawn(8, N, seed=51)
+    reps = E // 8
+    xy, th = np.tile(xy1, (reps, 1, 1)), np.tile(th1, (reps, 1))
+    a1 = scenes.random_actions(8, N, seed=52)
+    g = KilobotSim(E, N)
+    g.set_poses_m(xy, th)
+    a = dev(np.tile(a1, (reps, 1, 1)))
+    for k in range(2):
+        g.step(10, actions=a)
+    torch.cuda.synchronize()
+    assert int(g.status.max().item()) == 0
+    x, y, t = cpu(g.x), cpu(g.y), cpu(g.theta)
+    assert np.isfinite(x).all() and np.isfinite(y).all() and np.isfinite(t).all()
+    # replicas of the same 8 envs must be identical (no cross-env state, no nondeterminism)
+    assert np.array_equal(x.reshape(reps, 8, N), np.broadcast_to(x[:8], (reps, 8, N)))
+    assert np.array_equal(y.reshape(reps, 8, N), np.broadcast_to(y[:8], (reps, 8, N)))
+    # and equal to the oracle on those 8 envs
+    osim = O.OracleSim(O.default_config(8, N))
+    osim.set_poses_m(xy1, th1)
+    osim.set_actions(a1)
+    osim.step(20, threads=8)
+    assert np.array_equal(osim.x, x[:8]) and np.array_equal(osim.y, y[:8]) and np.array_equal(osim.theta, t[:8])
+    # non-penetration: no pair closer than 2r - 3 slop - 1 substep of approach (2 * 0.0625 world units)
+    px, py = x[:8].astype(np.float64), y[:8].astype(np.float64)
+    for e in range(8):
+        d = np.hypot(px[e][:, None] - px[e][None, :], py[e][:, None] - py[e][None, :])
+        d[np.diag_indices(N)] = 10.0
+        assert d.min() > 0.825 - 0.015 - 0.13
