@@ -1,0 +1,314 @@
+"""KilobotsEnv: the reference's gym.Env surface (gym_kilobots/envs/kilobots_env.py) on top of the
+batched HIP world step.
+
+Subclasses configure a scene exactly as with the reference: `_configure_environment` creates
+kilobots / a light through the same constructors, passing `self.world`:
+
+    class MyEnv(KilobotsEnv):
+        def _configure_environment(self):
+            self._light = CircularGradientLight(position=np.zeros(2))
+            for p in positions:
+                self._add_kilobot(PhototaxisKilobot(self.world, position=p, light=self._light))
+
+`reset()` then uploads the scene to the GPU and `step(action)` runs the 10-substep loop of
+kilobots_env.py:168-190 as ONE kernel launch.  `num_envs > 1` replicates the configured scene into
+independent worlds (see BatchedKilobotsEnv for the tensor-level API)."""
+import abc
+
+import numpy as np
+import torch
+
+from .. import _native as nat
+from ..lib.body import World, Body, _world_scale  # noqa: F401
+from ..lib.kilobot import Kilobot
+from ..lib.light import Light, CircularGradientLight
+
+
+class UnknownObjectException(Exception):
+    pass
+
+
+class UnknownLightTypeException(Exception):
+    pass
+
+
+def _default_sim_factory(*args, **kwargs):
+    from ..sim import KilobotSim
+    return KilobotSim(*args, **kwargs)
+
+
+class KilobotsEnv(object):
+    metadata = {'render.modes': ['human']}
+
+    world_size = world_width, world_height = 2., 1.5
+    screen_size = screen_width, screen_height = 1200, 900
+
+    _observe_objects = False
+    _observe_light = True
+
+    __sim_steps_per_second = 10
+    __sim_velocity_iterations = 10
+    __sim_position_iterations = 10
+    __steps_per_action = 10
+
+    def __new__(cls, **kwargs):
+        cls.sim_steps_per_second = cls.__sim_steps_per_second
+        cls.sim_step = 1. / cls.__sim_steps_per_second
+        cls.world_x_range = -cls.world_width / 2, cls.world_width / 2
+        cls.world_y_range = -cls.world_height / 2, cls.world_height / 2
+        cls.world_bounds = (np.array([-cls.world_width / 2, -cls.world_height / 2]),
+                            np.array([cls.world_width / 2, cls.world_height / 2]))
+        return super(KilobotsEnv, cls).__new__(cls)
+
+    def __init__(self, num_envs=1, device=None, sim_factory=None, **kwargs):
+        self.__sim_steps = 0
+        self.__reset_counter = 0
+        self.__seed = 0
+        self.num_envs = int(num_envs)
+        self._device = device
+        self._sim_factory = sim_factory or _default_sim_factory
+        self._sim = None
+        self._sim_signature = None
+
+        # the "world": records bodies created by _configure_environment (kilobots_env.py:45-51)
+        self.world = World()
+        self._real_time = False
+        self._kilobots = []
+        self._objects = []
+        self._light = None
+        self._screen = None
+        self.render_mode = 'human'
+        self.video_path = None
+
+        # like the reference constructor: configure once, then drop the kilobots again
+        # (kilobots_env.py:67-68) -- an env has no kilobots until the first reset()
+        self._configure_environment()
+        self._kilobots = []
+        self.world.clear()
+
+    # ------------------------------------------------------------------ reference properties
+    @property
+    def _sim_steps(self):
+        return self.__sim_steps
+
+    @property
+    def kilobots(self):
+        return tuple(self._kilobots)
+
+    @property
+    def num_kilobots(self):
+        return len(self._kilobots)
+
+    @property
+    def objects(self):
+        return tuple(self._objects)
+
+    @property
+    def action_space(self):
+        if self._light:
+            return self._light.action_space
+
+    @property
+    def observation_space(self):
+        return NotImplemented
+
+    @property
+    def state_space(self):
+        return NotImplemented
+
+    @property
+    def _steps_per_action(self):
+        return self.__steps_per_action
+
+    @property
+    def sim(self):
+        """The device-side simulator (gym_kilobots_amd.sim.KilobotSim); None before the first reset()."""
+        return self._sim
+
+    def _add_kilobot(self, kilobot):
+        self._kilobots.append(kilobot)
+
+    def _add_object(self, body):
+        self._objects.append(body)
+
+    @abc.abstractmethod
+    def _configure_environment(self):
+        raise NotImplementedError
+
+    # ------------------------------------------------------------------ state
+    def get_state(self):
+        if self._sim is None:
+            return {'kilobots': np.array([k.get_state() for k in self._kilobots]),
+                    'objects': np.array([o.get_state() for o in self._objects]),
+                    'light': self._light.get_state() if self._light else None}
+        poses = self._sim.poses()            # one kernel + one copy instead of 3N SWIG reads
+        kb = poses[0].double().cpu().numpy() if self.num_envs == 1 else poses.double().cpu().numpy()
+        if self._sim.drive_mode == nat.DRIVE_ACCEL:
+            vw = torch.stack([self._sim.v, self._sim.w], -1).double().cpu().numpy()
+            kb = np.concatenate([kb, vw[0] if self.num_envs == 1 else vw], -1)
+        light = None
+        if self._light is not None:
+            l = torch.stack([self._sim.light_x, self._sim.light_y], -1).double().cpu().numpy()
+            light = l[0] if self.num_envs == 1 else l
+        return {'kilobots': kb, 'objects': np.array([o.get_state() for o in self._objects]), 'light': light}
+
+    def get_observation(self):
+        return self.get_state()
+
+    @abc.abstractmethod
+    def get_reward(self, state, action, new_state):
+        raise NotImplementedError
+
+    def has_finished(self, state, action):
+        return False
+
+    def get_info(self, state, action):
+        return ""
+
+    def destroy(self):
+        del self._objects[:]
+        del self._kilobots[:]
+        self._light = None
+        self.world.clear()
+        self.world.backend = None
+        self._screen = None
+
+    def close(self):
+        self.destroy()
+        if self._sim is not None:
+            self._sim.close()
+            self._sim = None
+            self._sim_signature = None
+
+    def seed(self, seed=None):
+        if seed is not None:
+            self.__seed = seed
+        return [self.__seed]
+
+    # ------------------------------------------------------------------ scene upload
+    def _upload_scene(self):
+        kbs = self._kilobots
+        if len(kbs) == 0:
+            raise ValueError('the configured scene has no kilobots')
+        if len(self._objects) != 0:
+            raise UnknownObjectException('pushable objects are not supported by this version of the HIP step')
+        kinds = {type(k).drive_mode for k in kbs}
+        if len(kinds) != 1:
+            raise ValueError('all kilobots of an env must share one drive law (got %s)' % sorted(kinds))
+        for k in kbs:
+            if not isinstance(k, Kilobot):
+                raise TypeError('kilobots must derive from gym_kilobots_amd.lib.Kilobot')
+        mode = kinds.pop()
+        light_type = nat.LIGHT_NONE
+        overrides = dict(world_width=self.world_width, world_height=self.world_height, dt=self.sim_step,
+                         vel_iters=self.__sim_velocity_iterations, pos_iters=self.__sim_position_iterations,
+                         bot_density=float(type(kbs[0])._density), bot_radius=float(type(kbs[0])._radius),
+                         bot_linear_damping=float(type(kbs[0])._linear_damping),
+                         bot_angular_damping=float(type(kbs[0])._angular_damping))
+        if self._light is not None:
+            if not isinstance(self._light, CircularGradientLight):
+                raise UnknownLightTypeException('only CircularGradientLight runs on the device in this version')
+            light_type = nat.LIGHT_CIRCULAR
+            overrides.update(light_radius=float(self._light._radius),
+                             light_lo=[float(v) for v in self._light._bounds[0]],
+                             light_hi=[float(v) for v in self._light._bounds[1]],
+                             light_act_lo=[float(v) for v in self._light._action_bounds[0]],
+                             light_act_hi=[float(v) for v in self._light._action_bounds[1]])
+        N = len(kbs)
+        sig = (self.num_envs, N, mode, light_type, tuple(sorted((k, str(v)) for k, v in overrides.items())))
+        if self._sim is None or sig != self._sim_signature:
+            if self._sim is not None:
+                self._sim.close()
+            kw = dict(overrides)
+            if self._device is not None:
+                kw['device'] = self._device
+            self._sim = self._sim_factory(self.num_envs, N, mode, light_type, debug_outputs=True, **kw)
+            self._sim_signature = sig
+        sim = self._sim
+        poses = np.array([k._init_pose for k in kbs], dtype=np.float64)
+        xy = np.broadcast_to(poses[None, :, :2], (self.num_envs, N, 2))
+        th = np.broadcast_to(poses[None, :, 2], (self.num_envs, N))
+        sim.set_poses_m(xy, th)
+        sim.status.zero_()
+        if mode in (nat.DRIVE_VELOCITY, nat.DRIVE_ACCEL):
+            v0 = np.array([k._velocity for k in kbs], dtype=np.float32)
+            sim.v.copy_(torch.from_numpy(np.broadcast_to(v0[None, :, 0], (self.num_envs, N)).copy()))
+            sim.w.copy_(torch.from_numpy(np.broadcast_to(v0[None, :, 1], (self.num_envs, N)).copy()))
+        if mode == nat.DRIVE_ACCEL:
+            sim.acc_v.zero_()
+            sim.acc_w.zero_()
+        if mode in (nat.DRIVE_MOTORS, nat.DRIVE_PHOTOTAXIS):
+            ml = np.array([k._motor_left for k in kbs], dtype=np.uint8)
+            mr = np.array([k._motor_right for k in kbs], dtype=np.uint8)
+            sim.motor_l.copy_(torch.from_numpy(np.broadcast_to(ml[None], (self.num_envs, N)).copy()))
+            sim.motor_r.copy_(torch.from_numpy(np.broadcast_to(mr[None], (self.num_envs, N)).copy()))
+        if mode == nat.DRIVE_PHOTOTAXIS:
+            sim.pt_threshold.fill_(float('-inf'))
+            sim.pt_update.zero_()
+            sim.pt_nochange.zero_()
+            sim.pt_dir.zero_()
+        if self._light is not None:
+            p = self._light._position
+            sim.light_x.fill_(float(p[0]))
+            sim.light_y.fill_(float(p[1]))
+            self._light._world = self.world
+        self.world.backend = sim
+        self.world.env_index = 0
+
+    def reset(self):
+        self.__reset_counter += 1
+        self.destroy()
+        self._configure_environment()
+        self.__sim_steps = 0
+        self._upload_scene()
+        # step to resolve (kilobots_env.py:156-157): one world.Step with the bodies at rest
+        self._step_world()
+        return self.get_observation()
+
+    def _light_action_tensor(self, action):
+        a = torch.as_tensor(np.asarray(action, dtype=np.float32).reshape(-1, 2) if not torch.is_tensor(action) else action,
+                            dtype=torch.float32, device=self._sim.x.device)
+        if a.dim() == 1:
+            a = a.reshape(1, 2)
+        if a.shape[0] == 1 and self.num_envs > 1:
+            a = a.expand(self.num_envs, 2)
+        return a.contiguous()
+
+    def step(self, action):
+        if self._sim is None:
+            raise RuntimeError('call reset() before step()')
+        state = self.get_state()
+        la = None
+        if action is not None and self._light:
+            la = self._light_action_tensor(action)
+        # the whole `for i in range(steps_per_action)` loop (kilobots_env.py:168-190) is one launch
+        self._sim.step(self.__steps_per_action, light_action=la)
+        self.__sim_steps += self.__steps_per_action
+        next_state = self.get_state()
+        observation = self.get_observation()
+        reward = self.get_reward(state, action, next_state)
+        done = self.has_finished(next_state, action)
+        info = self.get_info(next_state, action)
+        return observation, reward, done, info
+
+    def _step_world(self):
+        self._sim.step(1, flags=nat.STEP_NO_DRIVE)
+
+    def render(self, mode=None):
+        raise NotImplementedError('rendering (pygame viewer) is outside the accelerated hot path; '
+                                  'see SURVEY.md section 2, component 8')
+
+    def get_objects(self):
+        return self._objects
+
+    def get_kilobots(self):
+        return self._kilobots
+
+    def get_light(self):
+        return self._light
+
+    def _draw_on_table(self, screen):
+        pass
+
+    def _draw_on_top(self, screen):
+        pass

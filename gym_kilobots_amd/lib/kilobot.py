@@ -1,0 +1,208 @@
+"""Kilobot views (reference gym_kilobots/lib/kilobot.py).  Each class fixes the drive law the HIP
+kernel applies to every kilobot of the env (KB_DRIVE_*); the per-kilobot methods read and write
+the batched device state."""
+import numpy as np
+
+from .. import _native as nat
+from ..spaces import Box
+from .body import Circle, _world_scale  # noqa: F401
+
+
+class Kilobot(Circle):
+    _radius = 0.0165
+
+    _leg_front = np.array([.0, _radius])
+    _leg_left = np.array([-0.013, -.009])
+    _leg_right = np.array([+0.013, -.009])
+    _light_sensor = np.array([.0, -_radius + .001])
+    _led = np.array([.011, .01])
+
+    _max_linear_velocity = 0.01  # meters / s
+    _max_angular_velocity = 0.5 * np.pi  # radians / s
+
+    _density = 1.0
+    _friction = 0.0
+    _restitution = 0.0
+
+    _linear_damping = .8
+    _angular_damping = .8
+
+    drive_mode = nat.DRIVE_MOTORS
+
+    def __init__(self, world, position=None, orientation=None, light=None):
+        super().__init__(world=world, position=position, orientation=orientation, radius=self._radius)
+        self._motor_left = 0
+        self._motor_right = 0
+        self._body_color = (150, 150, 150)
+        self._highlight_color = (255, 255, 255)
+        self._turn_direction = None
+        self._setup()
+
+    def _arrays(self):
+        return ('x', 'y', 'theta')
+
+    def light_sensor_pos(self):
+        return self.get_world_point((0.0, -self._radius))
+
+    def get_ambientlight(self):
+        be = self._world.backend
+        if be is None or getattr(be, 'light_value', None) is None:
+            return 0
+        v = self._get('light_value')
+        return v if v else 0
+
+    def set_motors(self, left, right):
+        self._motor_left = left
+        self._motor_right = right
+        if self._live() and self._world.backend.motor_l is not None:
+            self._set('motor_l', int(left))
+            self._set('motor_r', int(right))
+
+    def get_motors(self):
+        if self._live() and self._world.backend.motor_l is not None:
+            return int(self._get('motor_l')), int(self._get('motor_r'))
+        return self._motor_left, self._motor_right
+
+    def switch_directions(self):
+        if self._turn_direction == 'left':
+            self.turn_right()
+        else:
+            self.turn_left()
+
+    def turn_right(self):
+        self._turn_direction = 'right'
+        self.set_motors(0, 255)
+        self.set_color((255, 0, 0))
+
+    def turn_left(self):
+        self._turn_direction = 'left'
+        self.set_motors(255, 0)
+        self.set_color((0, 255, 0))
+
+    def set_color(self, color):
+        self._highlight_color = color
+
+    def step(self, time_step):
+        raise NotImplementedError('kilobots are stepped in bulk by the env (one HIP launch per substep batch)')
+
+    @classmethod
+    def get_radius(cls):
+        return cls._radius
+
+    def _setup(self):
+        raise NotImplementedError('Kilobot subclass needs to implement _setup')
+
+    def _loop(self):
+        raise NotImplementedError('Kilobot subclass needs to implement _loop')
+
+
+class MotorKilobot(Kilobot):
+    """Base motor law with user-set motor values (reference Kilobot.step, kilobot.py:86-127; the
+    reference base class is abstract, this concrete subclass exposes the law itself)."""
+    drive_mode = nat.DRIVE_MOTORS
+
+    def _setup(self):
+        pass
+
+    def _loop(self):
+        pass
+
+
+class SimplePhototaxisKilobot(Kilobot):
+    drive_mode = nat.DRIVE_SIMPLE_PHOTOTAXIS
+
+    def _setup(self):
+        self.turn_left()
+
+    def _loop(self):
+        pass
+
+    def light_sensor_pos(self):
+        return self.get_position()
+
+
+class SimpleVelocityControlKilobot(Kilobot):
+    _density = 2.0
+    drive_mode = nat.DRIVE_VELOCITY
+
+    action_space = Box(np.array([.0, -Kilobot._max_angular_velocity]),
+                       np.array([Kilobot._max_linear_velocity, Kilobot._max_angular_velocity]),
+                       dtype=np.float64)
+    state_space = Box(np.array([-np.inf, -np.inf, -np.inf]), np.array([np.inf, np.inf, np.inf]), dtype=np.float64)
+
+    def __init__(self, world, *, velocity=None, **kwargs):
+        super().__init__(world=world, light=None, **kwargs)
+        if velocity is not None:
+            self._velocity = np.asarray(velocity, dtype=np.float64)
+        else:
+            self._velocity = np.random.rand(2) * np.array([self._max_linear_velocity, 2 * self._max_angular_velocity])
+            self._velocity[1] -= self._max_angular_velocity
+
+    def set_action(self, action):
+        if action is not None:
+            action = np.minimum(action, self.action_space.high)
+            action = np.maximum(action, self.action_space.low)
+            self._velocity = action
+        else:
+            self._velocity = np.array([.0, .0])
+        if self._live():
+            self._set('v', self._velocity[0])
+            self._set('w', self._velocity[1])
+
+    def get_action(self):
+        if self._live():
+            return np.array([self._get('v'), self._get('w')])
+        return self._velocity
+
+    def _setup(self):
+        pass
+
+    def _loop(self):
+        pass
+
+    def set_color(self, color):
+        self._body_color = color
+
+
+class SimpleAccelerationControlKilobot(SimpleVelocityControlKilobot):
+    _density = 2.0
+    drive_mode = nat.DRIVE_ACCEL
+
+    action_space = Box(np.array([-.005, -.2 * np.pi]), np.array([.005, .2 * np.pi]), dtype=np.float64)
+    state_space = Box(np.array([-np.inf, -np.inf, -np.inf, .0, -Kilobot._max_angular_velocity]),
+                      np.array([np.inf, np.inf, np.inf, Kilobot._max_linear_velocity, Kilobot._max_angular_velocity]),
+                      dtype=np.float64)
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._acceleration = np.array([.0, .0])
+
+    def get_state(self):
+        pose = super().get_state()
+        if self._live():
+            return pose + (self._get('v'), self._get('w'))
+        return pose + tuple(self._velocity)
+
+    def set_action(self, action):
+        if action is not None:
+            action = np.minimum(action, self.action_space.high)
+            action = np.maximum(action, self.action_space.low)
+            self._acceleration = action
+        else:
+            self._acceleration = np.array([.0, .0])
+        if self._live():
+            self._set('acc_v', self._acceleration[0])
+            self._set('acc_w', self._acceleration[1])
+
+    def get_action(self):
+        return self._acceleration
+
+
+class PhototaxisKilobot(Kilobot):
+    drive_mode = nat.DRIVE_PHOTOTAXIS
+
+    def _setup(self):
+        self.turn_left()
+
+    def _loop(self):
+        pass

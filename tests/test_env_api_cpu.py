@@ -1,0 +1,174 @@
+"""Host-side drop-in surface (upper side): env classes, body / kilobot / light views,
+spaces.  Runs on CPU with the oracle-backed stand-in simulator from tests/oracle_backend.py; the GPU
+twin of these checks is tests/test_env_api_gpu.py."""
+import numpy as np
+import pytest
+import torch
+
+from gym_kilobots_amd.envs import KilobotsEnv, DirectControlKilobotsEnv, BatchedKilobotsEnv, UnknownLightTypeException
+from gym_kilobots_amd.lib import (SimpleVelocityControlKilobot, SimpleAccelerationControlKilobot, PhototaxisKilobot,
+                                  SimplePhototaxisKilobot, CircularGradientLight, Body, Circle, Light)
+from gym_kilobots_amd import dist as kdist
+from tests.oracle_backend import OracleBackend
+
+
+class VelEnv(DirectControlKilobotsEnv):
+    def _configure_environment(self):
+        for i in range(6):
+            self._add_kilobot(SimpleVelocityControlKilobot(self.world, position=(-0.25 + 0.1 * i, 0.05 * i),
+                                                           orientation=0.3 * i, velocity=[0.005, 0.1]))
+
+    def get_reward(self, state, action, new_state):
+        return float(np.linalg.norm(new_state['kilobots'][:, :2] - state['kilobots'][:, :2]))
+
+
+class PhotoEnv(KilobotsEnv):
+    def _configure_environment(self):
+        self._light = CircularGradientLight(position=np.array([0.1, 0.0]), radius=0.3,
+                                            bounds=(np.array([-1.1, -0.825]), np.array([1.1, 0.825])))
+        for i in range(5):
+            self._add_kilobot(PhototaxisKilobot(self.world, position=(0.04 * i, 0.0), light=self._light))
+
+    def get_reward(self, state, action, new_state):
+        return 1.
+
+
+def test_constructor_leaves_env_empty_until_reset_like_the_reference():
+    env = VelEnv(sim_factory=OracleBackend)
+    assert env.num_kilobots == 0 and env.kilobots == ()          # kilobots_env.py:67-68
+    assert env.sim_step == 0.1 and env.world_bounds[1].tolist() == [1.0, 0.75]
+    assert env.world_x_range == (-1.0, 1.0) and env.seed(5) == [5]
+    obs = env.reset()
+    assert env.num_kilobots == 6
+    assert set(obs.keys()) == {'kilobots', 'objects', 'light'} and obs['kilobots'].shape == (6, 3)
+    with pytest.raises(NotImplementedError):
+        env.render()
+    assert env.observation_space is NotImplemented
+
+
+def test_direct_control_step_matches_the_kat_and_old_gym_signature():
+    env = VelEnv(sim_factory=OracleBackend)
+    env.reset()
+    assert env.action_space.shape == (6, 2)
+    np.testing.assert_allclose(env.action_space.high[0], [0.01, np.pi / 2])
+    a = np.tile([0.008, 0.3], (6, 1))
+    p0 = env.get_state()['kilobots']
+    obs, reward, done, info = env.step(a)
+    assert done is False and info == "" and reward > 0
+    # contact-free closed form: theta advances by 10 * 0.1 * 0.3 / 1.08
+    np.testing.assert_allclose(obs['kilobots'][:, 2] - p0[:, 2], 10 * 0.1 * 0.3 / 1.08, rtol=1e-5)
+    # actions are clamped like kilobot.py:235-241; None -> zeros
+    env.step(np.tile([0.5, -9.0], (6, 1)))
+    np.testing.assert_allclose(env.kilobots[0].get_action(), [0.01, -np.pi / 2], rtol=1e-6)
+    p1 = env.get_state()['kilobots']
+    env.step(None)
+    np.testing.assert_allclose(env.get_state()['kilobots'], p1, atol=1e-9)
+
+
+def test_body_and_kilobot_views():
+    env = VelEnv(sim_factory=OracleBackend)
+    env.reset()
+    kb = env.kilobots[2]
+    x, y, th = kb.get_pose()
+    np.testing.assert_allclose([x, y, th], [-0.05, 0.1, 0.6], atol=1e-6)
+    assert kb.get_state() == kb.get_pose() and kb.get_radius() == 0.0165 and kb.width == 0.033
+    np.testing.assert_allclose(kb.get_world_point((0.0, -0.0165)), kb.light_sensor_pos())
+    np.testing.assert_allclose(kb.get_local_point(kb.get_world_point((0.01, 0.02))), (0.01, 0.02), atol=1e-7)
+    assert abs(kb.get_local_orientation(1.0) - (1.0 - th)) < 1e-7
+    kb.set_pose((0.3, -0.2, 1.0))
+    np.testing.assert_allclose(kb.get_pose(), (0.3, -0.2, 1.0), atol=1e-6)
+    np.testing.assert_allclose(env.get_state()['kilobots'][2], (0.3, -0.2, 1.0), atol=1e-6)
+    a, b = env.kilobots[0], env.kilobots[1]
+    assert a.collides_with(b) is None
+    b.set_position(np.array(a.get_position()) + (0.03, 0.0))
+    assert a.collides_with(b) is True
+    with pytest.raises(NotImplementedError):
+        Body(env.world)
+    assert isinstance(kb, Circle)
+
+
+def test_light_env_phototaxis_and_light_actions():
+    env = PhotoEnv(sim_factory=OracleBackend)
+    env.reset()
+    assert env.action_space.shape == (2,) and env.action_space.high.tolist() == [0.01, 0.01]
+    obs, r, d, i = env.step(np.array([0.01, -0.05]))
+    # light moved by clamp(action, +-0.01) * 0.1 per substep, 10 substeps (light.py:59-75)
+    np.testing.assert_allclose(obs['light'], [0.1 + 0.01, 0.0 - 0.01], atol=1e-6)
+    np.testing.assert_allclose(env.get_light().get_state(), obs['light'])
+    assert r == 1. and i == ""
+    l0 = obs['light'].copy()
+    obs, *_ = env.step(None)                          # action None: light not stepped
+    np.testing.assert_allclose(obs['light'], l0)
+    assert env.kilobots[0].get_motors() in ((255, 0), (0, 255))
+    assert env.kilobots[0].get_ambientlight() > 0
+    v, g = env.get_light().value_and_gradients(np.array([[0.0, 0.0], [2.0, 2.0]]))
+    assert v[1] == 0 and np.allclose(g[1], 0)
+
+
+def test_acceleration_env_state_has_five_columns():
+    class AccEnv(DirectControlKilobotsEnv):
+        def _configure_environment(self):
+            for i in range(3):
+                self._add_kilobot(SimpleAccelerationControlKilobot(self.world, position=(0.1 * i, 0.0), velocity=[0.0, 0.0]))
+
+        def get_reward(self, *a):
+            return 0.
+
+    env = AccEnv(sim_factory=OracleBackend)
+    env.reset()
+    obs, *_ = env.step(np.tile([0.005, 0.1], (3, 1)))
+    assert obs['kilobots'].shape == (3, 5)                      # kilobot.py:279-281
+    np.testing.assert_allclose(obs['kilobots'][:, 3], 0.005, rtol=1e-5)
+    assert len(env.kilobots[0].get_state()) == 5
+
+
+def test_unsupported_scenes_fail_loudly():
+    class MixedEnv(KilobotsEnv):
+        def _configure_environment(self):
+            self._light = CircularGradientLight()
+            self._add_kilobot(PhototaxisKilobot(self.world, position=(0, 0)))
+            self._add_kilobot(SimplePhototaxisKilobot(self.world, position=(0.1, 0)))
+
+        def get_reward(self, *a):
+            return 0.
+
+    with pytest.raises(ValueError):
+        MixedEnv(sim_factory=OracleBackend).reset()
+
+    class OddLightEnv(KilobotsEnv):
+        def _configure_environment(self):
+            self._light = Light()
+            self._add_kilobot(PhototaxisKilobot(self.world, position=(0, 0)))
+
+        def get_reward(self, *a):
+            return 0.
+
+    with pytest.raises(UnknownLightTypeException):
+        OddLightEnv(sim_factory=OracleBackend).reset()
+
+
+def test_batched_env_and_replicated_scene():
+    env = BatchedKilobotsEnv(5, 16, sim_factory=OracleBackend, seed=3,
+                             reward_fn=lambda prev, a, obs: -(obs[..., :2] ** 2).sum(-1).mean(-1))
+    obs = env.reset()
+    assert obs.shape == (5, 16, 3)
+    a = torch.zeros(5, 16, 2)
+    a[..., 0] = 0.01
+    obs2, r, done, info = env.step(a)
+    assert r.shape == (5,) and not done.any() and obs2.shape == (5, 16, 3)
+    assert torch.allclose(env.episode_returns, r)
+    assert env.gather_episode_returns().shape == (5,)
+    multi = VelEnv(num_envs=3, sim_factory=OracleBackend)
+    o = multi.reset()
+    assert o['kilobots'].shape == (3, 6, 3) and np.array_equal(o['kilobots'][0], o['kilobots'][2])
+
+
+def test_env_shard_partition():
+    for total, world in ((32768, 8), (10, 4), (7, 7), (5, 8)):
+        parts = [kdist.env_shard(total, r, world) for r in range(world)]
+        assert parts[0][0] == 0 and parts[-1][1] == total
+        assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+        sizes = [hi - lo for lo, hi in parts]
+        assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        kdist.env_shard(8, 8, 8)
