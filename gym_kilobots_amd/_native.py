@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libkilobots_hip.so')
+LIB_PATH = os.environ.get('KB_HIP_LIB', os.path.join(HERE, 'libkilobots_hip.so'))
 
 KB_OK, KB_EINVAL, KB_ENOTBOUND, KB_EHIP, KB_ELDS = 0, -1, -2, -3, -4
 DRIVE_VELOCITY, DRIVE_ACCEL, DRIVE_MOTORS, DRIVE_SIMPLE_PHOTOTAXIS, DRIVE_PHOTOTAXIS = range(5)

@@ -36,5 +36,17 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_profile(verbose=False):
+    """Diagnostic build with in-kernel cycle stamps per phase (tools/phase_profile.py); never shipped
+    as the product library: it writes its stamps behind the status buffer."""
+    hipcc = os.environ.get('HIPCC', 'hipcc')
+    out = os.path.join(HERE, 'libkilobots_hip_prof.so')
+    cmd = [hipcc] + FLAGS + ['-DKB_PROFILE', '-I', INC, '-o', out] + SRC
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == '__main__':
     print(build(force='--force' in sys.argv, verbose=True))

@@ -1,21 +1,28 @@
 // kb_sim.hip -- batched Kilobot world step for MI355X (gfx950 / CDNA4) + its C ABI.
 //
-// One workgroup owns one env for the whole launch: the env's SoA state is loaded once from HBM
-// into LDS, `n_substeps` iterations of the reference substep loop
-// (gym_kilobots/envs/kilobots_env.py:168-190) run entirely out of LDS, and the poses are written
-// back once.  Per substep:
+// One workgroup owns one env for the whole launch: positions are loaded once from HBM into LDS,
+// `n_substeps` iterations of the reference substep loop
+// (gym_kilobots/envs/kilobots_env.py:168-190) run out of LDS / registers, poses are written back once.
+// Per substep:
 //   drive law (kilobot.py:86-127,191-203,253-258,294-300,318-333) + light (light.py:59-75,176-189)
-//   -> uniform-grid broadphase in LDS (count / scan / scatter, 3x3 half stencil)
-//   -> circle-circle / circle-wall narrowphase (Box2D b2CollideCircles, b2CollideEdgeAndCircle)
-//   -> warm start + 10 sequential-impulse velocity iterations (b2ContactSolver)
-//   -> symplectic Euler (b2Island::Solve) -> <=10 position iterations with per-island early out.
-// Gauss-Seidel order: contacts are bucketed into rounds (class, rank); two contacts of one round
-// never share a body, so a round runs in parallel and the result equals the sequential sweep in
-// the canonical (class, group, A, B) order that DESIGN.md defines.  No MFMA: this is LDS/HBM work.
+//   -> broadphase: uniform grid of per-cell linked lists in LDS (one atomic exchange per bot)
+//   -> narrowphase: circle-circle / circle-wall (Box2D b2CollideCircles, b2CollideEdgeAndCircle),
+//      5-cell half stencil, warm-start impulses matched from the previous substep
+//   -> islands: lock-free union-find in LDS
+//   -> solver (b2ContactSolver semantics): warm start + 10 sequential-impulse velocity sweeps,
+//      symplectic Euler, <= 10 position sweeps with Box2D's per-island early out.
+// Gauss-Seidel order.  Every contact gets a key (class, rank): class from the relative grid position
+// of the two bodies and the parity of the base cell, rank from its position inside its cell-pair
+// group.  Two contacts with the same key never share a body, so all contacts of one key can be
+// solved concurrently and the result equals the sequential sweep in (class, group, A, B) order that
+// DESIGN.md specifies.  Islands are independent, so each island is bound to ONE wavefront
+// (root id mod #waves): a wave walks its own contacts key by key with no workgroup barrier at all
+// (LDS operations of one wave execute in order).  Only when one island is very large does the whole
+// workgroup cooperate on the sweep with s_barrier between keys.
+// No MFMA anywhere: this is LDS/latency- and HBM-bound integer/float work.
 //
-// Arithmetic: fp32, compiled with -ffp-contract=off; every expression is written in the same
-// operation order as the specification in DESIGN.md so that results do not depend on how many
-// substeps are fused into a launch or on how envs are sharded over GPUs.
+// Arithmetic: fp32, compiled with -ffp-contract=off; every expression is written in the operation
+// order of the specification so results do not depend on launch fusion, workgroup size or sharding.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -45,20 +52,26 @@ constexpr int MAX_CELLS = 8192;
 
 constexpr unsigned KEY_WALL = 0x10000u;
 constexpr int WALL_CODE = 0xFFF0;     // ca[] value of wall w is WALL_CODE + w
+constexpr unsigned EMPTY32 = 0xFFFFFFFFu;
+constexpr unsigned short EMPTY16 = 0xFFFFu;
 
 // contact classes in canonical order; +1 on E/N/NE/NW for odd base-cell parity
 constexpr int CLS_SAME = 0, CLS_E = 1, CLS_N = 3, CLS_NE = 5, CLS_NW = 7, CLS_WALL = 9, NUM_CLS = 10;
-constexpr int RMAX = 64;              // ranks per class
-constexpr int NKEYS = NUM_CLS * RMAX;
+constexpr int RK = 4;                 // rank buckets per class; the last one holds every rank >= RK-1
+constexpr int MAX_WAVES = 4;       // workgroups are at most 256 threads
+constexpr int BK_PER_WAVE = NUM_CLS * RK;
+constexpr int MAX_BUCKETS = MAX_WAVES * BK_PER_WAVE;
+constexpr int BPT = 4;                // bots per thread (max): N <= BPT * blockDim.x
+constexpr int GIANT_ISLAND = 256;     // contacts; larger islands are swept by the whole workgroup
 
-enum { M_NCON = 0, M_NROUNDS = 1, M_ANY0 = 2, M_ANY1 = 3, M_STATUS = 4, M_COUNT = 8 };
+enum { M_NCON = 0, M_TOTAL = 1, M_ANY = 2, M_STATUS = 3, M_MAXISL = 4, M_COUNT = 8 };
 
 struct Layout {  // byte offsets into dynamic LDS
-    int px, py, vx, vy, th, bw;
-    int cellEnd, dirCnt, parent, roundStart, roundFill, roundFlag, misc, wsum;
-    int cacc, cnx, cny;
-    int ca, cb, ckey, order, cellItems, cellOf, label, roundList;
-    int cslot, wsCnt, wsCntNew, active;
+    int px, py, vx, vy;
+    int head, dirCnt, parent, bkStart, bkFill, bkMaxRank, misc, wsum;
+    int cacc;
+    int ca, cb, cbk, order, next, cellOf, bkList;
+    int ccls, crank, cslot, wsCnt, wsCntNew, active, nList;
     int total;
 };
 
@@ -77,14 +90,15 @@ Layout make_layout(int N, int ncell, int cap) {
     int o = 0;
     auto take = [&](int bytes) { int r = o; o += (bytes + 15) & ~15; return r; };
     L.px = take(4 * N); L.py = take(4 * N); L.vx = take(4 * N); L.vy = take(4 * N);
-    L.th = take(4 * N); L.bw = take(4 * N);
-    L.cellEnd = take(4 * ncell); L.dirCnt = take(4 * N); L.parent = take(4 * N);
-    L.roundStart = take(4 * (NKEYS + 1)); L.roundFill = take(4 * NKEYS); L.roundFlag = take(4 * NKEYS);
+    L.head = take(4 * ncell); L.dirCnt = take(4 * N); L.parent = take(4 * N);
+    L.bkStart = take(4 * (MAX_BUCKETS + 1)); L.bkFill = take(4 * MAX_BUCKETS);
+    L.bkMaxRank = take(4 * MAX_WAVES * NUM_CLS);
     L.misc = take(4 * M_COUNT); L.wsum = take(4 * 16);
-    L.cacc = take(4 * cap); L.cnx = take(4 * cap); L.cny = take(4 * cap);
-    L.ca = take(2 * cap); L.cb = take(2 * cap); L.ckey = take(2 * cap); L.order = take(2 * cap);
-    L.cellItems = take(2 * N); L.cellOf = take(2 * N); L.label = take(2 * N); L.roundList = take(2 * NKEYS);
-    L.cslot = take(cap); L.wsCnt = take(N); L.wsCntNew = take(N); L.active = take(2 * N);
+    L.cacc = take(4 * cap);
+    L.ca = take(2 * cap); L.cb = take(2 * cap); L.cbk = take(2 * cap); L.order = take(2 * cap);
+    L.next = take(2 * N); L.cellOf = take(2 * N); L.bkList = take(2 * MAX_BUCKETS);
+    L.ccls = take(cap); L.crank = take(cap); L.cslot = take(cap);
+    L.wsCnt = take(N); L.wsCntNew = take(N); L.active = take(2 * N); L.nList = take(MAX_WAVES);
     L.total = o;
     return L;
 }
@@ -154,25 +168,12 @@ __device__ __forceinline__ void kb_motor_law(int ml, int mr, float th, float h, 
 
 __device__ __forceinline__ float kb_clampf(float a, float lo, float hi) { return fmaxf(lo, fminf(a, hi)); }
 
-// in-place exclusive scan of a[0..n) by the whole workgroup (all threads must call)
-__device__ void block_excl_scan(unsigned *a, int n, unsigned *wsum) {
-    const int nt = blockDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int chunk = (n + nt - 1) / nt;
-    const int s = tid * chunk, e = min(n, s + chunk);
-    unsigned sum = 0;
-    for (int i = s; i < e; ++i) sum += a[i];
-    unsigned incl = sum;
-    for (int d = 1; d < 64; d <<= 1) {
-        unsigned t = __shfl_up(incl, d);
-        if (lane >= d) incl += t;
-    }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    unsigned base = 0;
-    for (int w = 0; w < wave; ++w) base += wsum[w];
-    unsigned run = base + incl - sum;
-    for (int i = s; i < e; ++i) { unsigned v = a[i]; a[i] = run; run += v; }
-    __syncthreads();
+// LDS operations of one wave execute in program order; this only stops the compiler from moving
+// LDS accesses across the point where other lanes' results are consumed.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 __device__ __forceinline__ void wall_geom(const Params &p, int wl, float x, float y, float &dist, float &nx, float &ny) {
@@ -184,47 +185,70 @@ __device__ __forceinline__ void wall_geom(const Params &p, int wl, float x, floa
     }
 }
 
-__global__ void __launch_bounds__(1024) kb_step_kernel(const Params p) {
+#ifdef KB_PROFILE
+// diagnostic build: wave 0 / lane 0 accumulates shader cycles per phase into g.status[E + 8*e + phase]
+#define KB_STAMP(ph) do { if (tid == 0) { long long t_ = clock64(); prof_acc[ph] += t_ - prof_t; prof_t = t_; } } while (0)
+#else
+#define KB_STAMP(ph) do { } while (0)
+#endif
+
+__device__ __forceinline__ int dir_dx(int k) { return (k == 1 || k == 3) ? 1 : (k == 4 ? -1 : 0); }
+__device__ __forceinline__ int dir_dy(int k) { return (k >= 2) ? 1 : 0; }
+
+__global__ void __launch_bounds__(256, 2) kb_step_kernel(const Params p) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int e = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
     const int N = p.N, S = p.S;
     const size_t o = (size_t)e * N;
     const float h = p.h;
 
     float *px = (float *)(smem + p.L.px), *py = (float *)(smem + p.L.py);
     float *vx = (float *)(smem + p.L.vx), *vy = (float *)(smem + p.L.vy);
-    float *th = (float *)(smem + p.L.th), *bw = (float *)(smem + p.L.bw);
-    unsigned *cellEnd = (unsigned *)(smem + p.L.cellEnd), *dirCnt = (unsigned *)(smem + p.L.dirCnt);
+    unsigned *head = (unsigned *)(smem + p.L.head), *dirCnt = (unsigned *)(smem + p.L.dirCnt);
+    unsigned *islCnt = dirCnt;  // alias: dirCnt is dead once the contacts are emitted
     unsigned *parent = (unsigned *)(smem + p.L.parent);
-    unsigned *roundStart = (unsigned *)(smem + p.L.roundStart), *roundFill = (unsigned *)(smem + p.L.roundFill);
-    unsigned *roundFlag = (unsigned *)(smem + p.L.roundFlag);
-    unsigned *misc = (unsigned *)(smem + p.L.misc), *wsum = (unsigned *)(smem + p.L.wsum);
-    float *cacc = (float *)(smem + p.L.cacc), *cnx = (float *)(smem + p.L.cnx), *cny = (float *)(smem + p.L.cny);
+    unsigned *bkStart = (unsigned *)(smem + p.L.bkStart), *bkFill = (unsigned *)(smem + p.L.bkFill);
+    unsigned *bkMaxRank = (unsigned *)(smem + p.L.bkMaxRank);
+    unsigned *misc = (unsigned *)(smem + p.L.misc);
+    float *cacc = (float *)(smem + p.L.cacc);
     unsigned short *ca = (unsigned short *)(smem + p.L.ca), *cb = (unsigned short *)(smem + p.L.cb);
-    unsigned short *ckey = (unsigned short *)(smem + p.L.ckey), *order = (unsigned short *)(smem + p.L.order);
-    unsigned short *cellItems = (unsigned short *)(smem + p.L.cellItems), *cellOf = (unsigned short *)(smem + p.L.cellOf);
-    unsigned short *label = (unsigned short *)(smem + p.L.label), *roundList = (unsigned short *)(smem + p.L.roundList);
-    unsigned char *cslot = smem + p.L.cslot, *wsCnt = smem + p.L.wsCnt, *wsCntNew = smem + p.L.wsCntNew;
-    unsigned char *active = smem + p.L.active;
+    unsigned short *cbk = (unsigned short *)(smem + p.L.cbk), *order = (unsigned short *)(smem + p.L.order);
+    unsigned short *nextb = (unsigned short *)(smem + p.L.next), *cellOf = (unsigned short *)(smem + p.L.cellOf);
+    unsigned short *bkList = (unsigned short *)(smem + p.L.bkList);
+    unsigned char *ccls = smem + p.L.ccls, *crank = smem + p.L.crank, *cslot = smem + p.L.cslot;
+    unsigned char *wsCnt = smem + p.L.wsCnt, *wsCntNew = smem + p.L.wsCntNew;
+    unsigned char *active = smem + p.L.active, *nList = smem + p.L.nList;
 
     const kb_buffers &g = p.buf;
+#ifdef KB_PROFILE
+    long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long prof_t = clock64();
+#endif
 
     // ---- load state; optional fused set_action (kilobot.py:235-241, 283-289) ----
-    for (int b = tid; b < N; b += nt) {
-        px[b] = g.x[o + b]; py[b] = g.y[o + b]; th[b] = g.theta[o + b];
-        if (p.actions) {
-            const float2 a = reinterpret_cast<const float2 *>(p.actions)[o + b];
-            const float mw = 0.5f * 3.14159265358979323846f;
-            if (p.drive_mode == KB_DRIVE_VELOCITY) {
-                g.v[o + b] = fmaxf(fminf(a.x, 0.01f), 0.0f);
-                g.w[o + b] = fmaxf(fminf(a.y, mw), -mw);
-            } else if (p.drive_mode == KB_DRIVE_ACCEL) {
-                const float aw = 0.2f * 3.14159265358979323846f;
-                g.acc_v[o + b] = fmaxf(fminf(a.x, 0.005f), -0.005f);
-                g.acc_w[o + b] = fmaxf(fminf(a.y, aw), -aw);
+    float th[BPT], bw[BPT];
+#pragma unroll
+    for (int q = 0; q < BPT; ++q) {
+        const int b = tid + q * nt;
+        th[q] = 0.0f; bw[q] = 0.0f;
+        if (b < N) {
+            px[b] = g.x[o + b]; py[b] = g.y[o + b]; th[q] = g.theta[o + b];
+            if (p.actions) {
+                const float2 a = reinterpret_cast<const float2 *>(p.actions)[o + b];
+                const float mw = 0.5f * 3.14159265358979323846f;
+                if (p.drive_mode == KB_DRIVE_VELOCITY) {
+                    g.v[o + b] = fmaxf(fminf(a.x, 0.01f), 0.0f);
+                    g.w[o + b] = fmaxf(fminf(a.y, mw), -mw);
+                } else if (p.drive_mode == KB_DRIVE_ACCEL) {
+                    const float aw = 0.2f * 3.14159265358979323846f;
+                    g.acc_v[o + b] = fmaxf(fminf(a.x, 0.005f), -0.005f);
+                    g.acc_w[o + b] = fmaxf(fminf(a.y, aw), -aw);
+                }
             }
         }
     }
+    for (int c = tid; c < p.ncell; c += nt) head[c] = EMPTY32;
     if (tid == 0) misc[M_STATUS] = 0;
     float lx = 0.0f, ly = 0.0f;
     if (p.light_type == KB_LIGHT_CIRCULAR) { lx = g.light_x[e]; ly = g.light_y[e]; }
@@ -242,20 +266,24 @@ __global__ void __launch_bounds__(1024) kb_step_kernel(const Params p) {
             lx = fminf(fmaxf(nlx, p.light_lo[0]), p.light_hi[0]);
             ly = fminf(fmaxf(nly, p.light_lo[1]), p.light_hi[1]);
         }
-        // ---- sensing + drive law + damping; reset per-substep scratch ----
-        for (int b = tid; b < N; b += nt) {
+        // ---- sensing + drive law + damping; grid insertion; reset per-substep scratch ----
+#pragma unroll
+        for (int q = 0; q < BPT; ++q) {
+            const int b = tid + q * nt;
+            if (b >= N) continue;
             float bvx = 0.0f, bvy = 0.0f, bww = 0.0f;
+            const float bx = px[b], by = py[b];
             if (drive) {
-                const float t = th[b];
+                const float t = th[q];
                 float lval = 0.0f, lgx = 0.0f, lgy = 0.0f;
                 if (p.light_type == KB_LIGHT_CIRCULAR) {
-                    float sx = px[b], sy = py[b];
+                    float sx = bx, sy = by;
                     if (p.drive_mode != KB_DRIVE_SIMPLE_PHOTOTAXIS) {  // kilobot.py:54-55: world point of (0, -r)
                         float s, c;
                         kb_sincosf(t, s, c);
                         const float lx0 = 0.0f, ly0 = -p.r_bot;
-                        sx = (c * lx0 - s * ly0) + px[b];
-                        sy = (s * lx0 + c * ly0) + py[b];
+                        sx = (c * lx0 - s * ly0) + bx;
+                        sy = (s * lx0 + c * ly0) + by;
                     }
                     kb_light_circular(sx / WORLD_SCALE, sy / WORLD_SCALE, lx, ly, p.light_radius, lval, lgx, lgy);
                     if (g.light_value) { g.light_value[o + b] = lval; g.light_gx[o + b] = lgx; g.light_gy[o + b] = lgy; }
@@ -306,44 +334,26 @@ __global__ void __launch_bounds__(1024) kb_step_kernel(const Params p) {
             if (g.cmd_vx) { g.cmd_vx[o + b] = bvx; g.cmd_vy[o + b] = bvy; g.cmd_w[o + b] = bww; }
             // b2Island::Solve: v *= 1/(1 + h c)  (SimplePhototaxisKilobot sets linearDamping = 0, kilobot.py:203)
             const float kl = (p.drive_mode == KB_DRIVE_SIMPLE_PHOTOTAXIS) ? 1.0f / (1.0f + h * 0.0f) : p.kl_bot;
-            vx[b] = bvx * kl; vy[b] = bvy * kl; bw[b] = bww * p.ka_bot;
+            vx[b] = bvx * kl; vy[b] = bvy * kl; bw[q] = bww * p.ka_bot;
             wsCnt[b] = g.ws_cnt[o + b];
             parent[b] = b;
-        }
-        for (int c = tid; c < p.ncell; c += nt) cellEnd[c] = 0;
-        for (int k = tid; k < NKEYS; k += nt) { roundStart[k] = 0; roundFill[k] = 0; roundFlag[k] = 0; }
-        if (tid == 0) { roundStart[NKEYS] = 0; misc[M_NCON] = 0; misc[M_NROUNDS] = 0; misc[M_ANY0] = 0; misc[M_ANY1] = 0; }
-        __syncthreads();
-
-        // ---- broadphase: uniform grid, count -> scan -> scatter -> in-cell sort by id ----
-        for (int b = tid; b < N; b += nt) {
-            int cx = (int)floorf((px[b] - p.xmin) * p.inv_cell);
-            int cy = (int)floorf((py[b] - p.ymin) * p.inv_cell);
+            // broadphase: push the bot on its cell's list
+            int cx = (int)floorf((bx - p.xmin) * p.inv_cell);
+            int cy = (int)floorf((by - p.ymin) * p.inv_cell);
             cx = cx < 0 ? 0 : (cx >= p.gw ? p.gw - 1 : cx);
             cy = cy < 0 ? 0 : (cy >= p.gh ? p.gh - 1 : cy);
             const int cell = cy * p.gw + cx;
             cellOf[b] = (unsigned short)cell;
-            atomicAdd(&cellEnd[cell], 1u);
+            nextb[b] = (unsigned short)atomicExch(&head[cell], (unsigned)b);
         }
+        for (int k = tid; k < nw * BK_PER_WAVE; k += nt) { bkStart[k] = 0; bkFill[k] = 0; }
+        for (int k = tid; k < nw * NUM_CLS; k += nt) bkMaxRank[k] = 0;
+        if (tid == 0) { bkStart[nw * BK_PER_WAVE] = 0; misc[M_NCON] = 0; misc[M_TOTAL] = 0; misc[M_ANY] = 0; misc[M_MAXISL] = 0; }
         __syncthreads();
-        block_excl_scan(cellEnd, p.ncell, wsum);
-        for (int b = tid; b < N; b += nt) {
-            const unsigned pos = atomicAdd(&cellEnd[cellOf[b]], 1u);  // afterwards cellEnd[c] = end of cell c
-            cellItems[pos] = (unsigned short)b;
-        }
-        __syncthreads();
-        for (int b = tid; b < N; b += nt) {
-            const int cell = cellOf[b];
-            const int s = cell ? (int)cellEnd[cell - 1] : 0, en = (int)cellEnd[cell];
-            int idx = 0;
-            for (int it = s; it < en; ++it) idx += (cellItems[it] < b) ? 1 : 0;
-            label[b] = (unsigned short)(s + idx);
-        }
-        __syncthreads();
-        for (int b = tid; b < N; b += nt) cellItems[label[b]] = (unsigned short)b;
-        __syncthreads();
+        KB_STAMP(0);
 
-        // ---- narrowphase pass 1: per bot, number of contacts it owns per direction (for ranks) ----
+        // ---- narrowphase pass 1: per bot, number of contacts it owns per direction ----
+#pragma unroll 1
         for (int a = tid; a < N; a += nt) {
             const int cell = cellOf[a];
             const int cx = cell % p.gw, cy = cell / p.gw;
@@ -351,15 +361,11 @@ __global__ void __launch_bounds__(1024) kb_step_kernel(const Params p) {
             unsigned cnt = 0;
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
-                const int ddx = (k == 1 || k == 3) ? 1 : (k == 4 ? -1 : 0), ddy = (k >= 2) ? 1 : 0;
-                const int ox = cx + ddx, oy = cy + ddy;
+                const int ox = cx + dir_dx(k), oy = cy + dir_dy(k);
                 if (ox < 0 || ox >= p.gw || oy >= p.gh) continue;
-                const int oc = oy * p.gw + ox;
-                const int s = oc ? (int)cellEnd[oc - 1] : 0, en = (int)cellEnd[oc];
                 unsigned ck = 0;
-                for (int it = s; it < en; ++it) {
-                    const int b = cellItems[it];
-                    if (k == 0 && b <= a) continue;
+                for (unsigned b = head[oy * p.gw + ox]; b != EMPTY32; b = (nextb[b] == EMPTY16 ? EMPTY32 : nextb[b])) {
+                    if (k == 0 && (int)b <= a) continue;
                     const float dx = px[b] - ax, dy = py[b] - ay;
                     const float dd = dx * dx + dy * dy;
                     if (dd > rr2) continue;  // b2CollideCircles
@@ -371,20 +377,21 @@ __global__ void __launch_bounds__(1024) kb_step_kernel(const Params p) {
             dirCnt[a] = cnt;
         }
         __syncthreads();
+        KB_STAMP(1);
 
-        // ---- narrowphase pass 2: emit contacts with (class, rank) round keys + warm-start impulses ----
+        // ---- narrowphase pass 2: emit contacts (class, rank), warm-start impulses, hook islands ----
+#pragma unroll 1
         for (int a = tid; a < N; a += nt) {
             const int cell = cellOf[a];
             const int cx = cell % p.gw, cy = cell / p.gw;
             const float ax = px[a], ay = py[a];
-            const int own_s = cell ? (int)cellEnd[cell - 1] : 0;
             const unsigned mycnt = dirCnt[a];
             int nslot = 0;
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
-                if (((mycnt >> (6 * k)) & 63u) == 0u) continue;
-                const int ddx = (k == 1 || k == 3) ? 1 : (k == 4 ? -1 : 0), ddy = (k >= 2) ? 1 : 0;
-                const int oc = (cy + ddy) * p.gw + (cx + ddx);
+                const int nk = (int)((mycnt >> (6 * k)) & 63u);
+                if (nk == 0) continue;
+                const int oc = (cy + dir_dy(k)) * p.gw + (cx + dir_dx(k));
                 int cls;
                 if (k == 0) cls = CLS_SAME;
                 else if (k == 1) cls = CLS_E + (cx & 1);
@@ -392,19 +399,23 @@ __global__ void __launch_bounds__(1024) kb_step_kernel(const Params p) {
                 else if (k == 3) cls = CLS_NE + (cx & 1);
                 else cls = CLS_NW + (cx & 1);
                 // rank base: contacts of this (cell, direction) group owned by lower-id bots of the cell
-                int rank = 0;
-                for (int it = own_s;; ++it) {
-                    const int a2 = cellItems[it];
-                    if (a2 >= a) break;
-                    rank += (int)((dirCnt[a2] >> (6 * k)) & 63u);
-                }
-                const int s = oc ? (int)cellEnd[oc - 1] : 0, en = (int)cellEnd[oc];
-                for (int it = s; it < en; ++it) {
-                    const int b = cellItems[it];
-                    if (k == 0 && b <= a) continue;
+                int rbase = 0;
+                for (unsigned a2 = head[cell]; a2 != EMPTY32; a2 = (nextb[a2] == EMPTY16 ? EMPTY32 : nextb[a2]))
+                    if ((int)a2 < a) rbase += (int)((dirCnt[a2] >> (6 * k)) & 63u);
+                for (unsigned b = head[oc]; b != EMPTY32; b = (nextb[b] == EMPTY16 ? EMPTY32 : nextb[b])) {
+                    if (k == 0 && (int)b <= a) continue;
                     const float dx = px[b] - ax, dy = py[b] - ay;
                     const float dd = dx * dx + dy * dy;
                     if (dd > rr2) continue;
+                    // position of b among a's touching partners of this direction, in ascending id order
+                    int j = 0;
+                    if (nk > 1) {
+                        for (unsigned b2 = head[oc]; b2 != EMPTY32; b2 = (nextb[b2] == EMPTY16 ? EMPTY32 : nextb[b2])) {
+                            if (b2 >= b || (k == 0 && (int)b2 <= a)) continue;
+                            const float ex = px[b2] - ax, ey = py[b2] - ay;
+                            if (!(ex * ex + ey * ey > rr2)) j++;
+                        }
+                    }
                     // warm start: impulse of the same pair in the previous substep (b2Contact::Update id match)
                     float acc = 0.0f;
                     bool found = false;
@@ -418,25 +429,26 @@ __global__ void __launch_bounds__(1024) kb_step_kernel(const Params p) {
                             if (g.ws_key[idx] == (unsigned)a) { acc = g.ws_acc[idx]; break; }
                         }
                     }
-                    const int slot = nslot < S ? nslot : 255;
-                    if (slot == 255) atomicOr(&misc[M_STATUS], 2u);
-                    nslot++;
-                    int r = rank++;
-                    if (r >= RMAX) { r = RMAX - 1; atomicOr(&misc[M_STATUS], 4u); }
+                    int slot = nslot + j;
+                    if (slot >= S) { slot = 255; atomicOr(&misc[M_STATUS], 2u); }
+                    int r = rbase + j;
+                    if (r > 255) { r = 255; atomicOr(&misc[M_STATUS], 4u); }
                     const unsigned c = atomicAdd(&misc[M_NCON], 1u);
                     if (c >= (unsigned)p.cap) { atomicOr(&misc[M_STATUS], 1u); continue; }
-                    // b2WorldManifold::Initialize (circles)
-                    float nx = 1.0f, ny = 0.0f;
-                    if (dd > B2_EPSILON * B2_EPSILON) {
-                        const float len = sqrtf(dd);
-                        const float inv = 1.0f / len;
-                        nx = dx * inv; ny = dy * inv;
+                    ca[c] = (unsigned short)a; cb[c] = (unsigned short)b;
+                    ccls[c] = (unsigned char)cls; crank[c] = (unsigned char)r; cslot[c] = (unsigned char)slot;
+                    cacc[c] = acc;
+                    // island hooking: larger root goes under the smaller one
+                    unsigned ra = a, rb = b;
+                    for (;;) {
+                        while (true) { unsigned t = ((volatile unsigned *)parent)[ra]; if (t == ra) break; ra = t; }
+                        while (true) { unsigned t = ((volatile unsigned *)parent)[rb]; if (t == rb) break; rb = t; }
+                        if (ra == rb) break;
+                        if (ra < rb) { unsigned t = ra; ra = rb; rb = t; }
+                        if (atomicCAS(&parent[ra], ra, rb) == ra) break;
                     }
-                    const int key = cls * RMAX + r;
-                    ca[c] = (unsigned short)a; cb[c] = (unsigned short)b; ckey[c] = (unsigned short)key;
-                    cacc[c] = acc; cnx[c] = nx; cny[c] = ny; cslot[c] = (unsigned char)slot;
-                    atomicAdd(&roundStart[key], 1u);
                 }
+                nslot += nk;
             }
             // walls: b2CollideEdgeAndCircle (region AB) against the chain loop of kilobots_env.py:48-51
             int wrank = 0;
@@ -450,103 +462,163 @@ __global__ void __launch_bounds__(1024) kb_step_kernel(const Params p) {
                     const size_t idx = ((size_t)e * S + sl) * N + a;
                     if (g.ws_key[idx] == KEY_WALL + (unsigned)wl) { acc = g.ws_acc[idx]; break; }
                 }
-                const int slot = nslot < S ? nslot : 255;
-                if (slot == 255) atomicOr(&misc[M_STATUS], 2u);
+                int slot = nslot;
+                if (slot >= S) { slot = 255; atomicOr(&misc[M_STATUS], 2u); }
                 nslot++;
                 const int r = wrank++;
                 const unsigned c = atomicAdd(&misc[M_NCON], 1u);
                 if (c >= (unsigned)p.cap) { atomicOr(&misc[M_STATUS], 1u); continue; }
-                if (dist < 0.0f) { nx = -nx; ny = -ny; }  // normal flips towards the circle centre
-                const int key = CLS_WALL * RMAX + r;
-                ca[c] = (unsigned short)(WALL_CODE + wl); cb[c] = (unsigned short)a; ckey[c] = (unsigned short)key;
-                cacc[c] = acc; cnx[c] = nx; cny[c] = ny; cslot[c] = (unsigned char)slot;
-                atomicAdd(&roundStart[key], 1u);
+                ca[c] = (unsigned short)(WALL_CODE + wl); cb[c] = (unsigned short)a;
+                // bit 7: the centre is outside the wall line, so the manifold normal points outwards
+                ccls[c] = (unsigned char)(CLS_WALL | (dist < 0.0f ? 0x80 : 0)); crank[c] = (unsigned char)r; cslot[c] = (unsigned char)slot;
+                cacc[c] = acc;
             }
             wsCntNew[a] = (unsigned char)(nslot < S ? nslot : S);
         }
         __syncthreads();
+        KB_STAMP(2);
         const int ncon = min((int)misc[M_NCON], p.cap);
 
-        // ---- rounds: counting sort of contacts by key, list of non-empty rounds ----
-        for (int k = tid; k < NKEYS; k += nt) roundFlag[k] = roundStart[k] ? 1u : 0u;
-        __syncthreads();
-        block_excl_scan(roundStart, NKEYS + 1, wsum);
-        block_excl_scan(roundFlag, NKEYS, wsum);
-        for (int k = tid; k < NKEYS; k += nt) {
-            if (roundStart[k + 1] > roundStart[k]) roundList[roundFlag[k]] = (unsigned short)k;
-        }
-        if (tid == 0) {
-            int last = NKEYS - 1;
-            misc[M_NROUNDS] = roundFlag[last] + ((roundStart[NKEYS] > roundStart[last]) ? 1u : 0u);
-        }
-        for (int c = tid; c < ncon; c += nt) {
-            const int key = ckey[c];
-            const unsigned pos = roundStart[key] + atomicAdd(&roundFill[key], 1u);
-            order[pos] = (unsigned short)c;
-        }
-        // islands: lock-free union-find over dynamic-dynamic contacts (larger root hooks under smaller)
-        for (int c = tid; c < ncon; c += nt) {
-            if (ca[c] >= WALL_CODE) continue;
-            unsigned ra = ca[c], rb = cb[c];
-            for (;;) {
-                while (true) { unsigned q = ((volatile unsigned *)parent)[ra]; if (q == ra) break; ra = q; }
-                while (true) { unsigned q = ((volatile unsigned *)parent)[rb]; if (q == rb) break; rb = q; }
-                if (ra == rb) break;
-                if (ra < rb) { unsigned t = ra; ra = rb; rb = t; }
-                if (atomicCAS(&parent[ra], ra, rb) == ra) break;
-            }
-        }
-        __syncthreads();
-        const int nrounds = (int)misc[M_NROUNDS];
+        // ---- islands: flatten roots; empty the grid for the next substep ----
         for (int b = tid; b < N; b += nt) {
             unsigned r = b;
-            while (true) { unsigned q = parent[r]; if (q == r) break; r = q; }
-            label[b] = (unsigned short)r;
+            while (true) { unsigned t = ((volatile unsigned *)parent)[r]; if (t == r) break; r = t; }
+            parent[b] = r;   // only ever replaces an ancestor by an older ancestor: concurrent walks stay valid
+            islCnt[b] = 0;
+            head[cellOf[b]] = EMPTY32;
             active[b] = 1; active[N + b] = 0;
         }
-        // (the next barrier is the one closing the first warm-start round)
+        __syncthreads();
+        for (int c = tid; c < ncon; c += nt) {
+            const unsigned root = parent[cb[c]];
+            const unsigned n = atomicAdd(&islCnt[root], 1u) + 1u;
+            if (n > (unsigned)GIANT_ISLAND) atomicMax(&misc[M_MAXISL], n);
+        }
+        __syncthreads();
+        // coop: one island is so large that a single wave would serialise the env -> whole-workgroup sweeps
+        const bool coop = (misc[M_MAXISL] > (unsigned)GIANT_ISLAND) || nw == 1;
+        const int W = coop ? 1 : nw;
+        for (int c = tid; c < ncon; c += nt) {
+            const unsigned root = parent[cb[c]];
+            const int w = coop ? 0 : (int)(root % (unsigned)nw);
+            const int cls = ccls[c] & 0x7F, r = crank[c];
+            const int bk = (w * NUM_CLS + cls) * RK + (r < RK - 1 ? r : RK - 1);
+            cbk[c] = (unsigned short)bk;
+            atomicAdd(&bkStart[bk], 1u);
+            if (r >= RK - 1) atomicMax(&bkMaxRank[w * NUM_CLS + cls], (unsigned)r);
+        }
+        __syncthreads();
+        // exclusive scan of the bucket counts (<= 640 entries) by wave 0
+        if (wave == 0) {
+            const int nb = W * BK_PER_WAVE;
+            const int chunk = (nb + 63) / 64;
+            const int s0 = lane * chunk, e0 = min(nb, s0 + chunk);
+            unsigned sum = 0;
+            for (int i = s0; i < e0; ++i) sum += bkStart[i];
+            unsigned incl = sum;
+            for (int d = 1; d < 64; d <<= 1) {
+                unsigned t = __shfl_up(incl, d);
+                if (lane >= d) incl += t;
+            }
+            unsigned run = incl - sum;
+            for (int i = s0; i < e0; ++i) { unsigned v = bkStart[i]; bkStart[i] = run; run += v; }
+            if (lane == 63) bkStart[nb] = incl;
+        }
+        __syncthreads();
+        for (int c = tid; c < ncon; c += nt) {
+            const int bk = cbk[c];
+            const unsigned pos = bkStart[bk] + atomicAdd(&bkFill[bk], 1u);
+            order[pos] = (unsigned short)c;
+        }
+        // every (virtual) wave compacts the list of its non-empty buckets, in key order
+        if (wave < W) {
+            const int base = wave * BK_PER_WAVE;
+            const bool ne = lane < BK_PER_WAVE && bkStart[base + lane + 1] > bkStart[base + lane];
+            const unsigned long long m = __ballot(ne);
+            if (ne) bkList[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(base + lane);
+            if (lane == 0) nList[wave] = (unsigned char)__popcll(m);
+        }
+        __syncthreads();
+        KB_STAMP(3);
 
-        // ---- b2ContactSolver::WarmStart, in round order ----
-        for (int ri = 0; ri < nrounds; ++ri) {
-            const int key = roundList[ri];
-            const int s = (int)roundStart[key], en = (int)roundStart[key + 1];
-            for (int i = s + tid; i < en; i += nt) {
-                const int c = order[i];
-                const int a = ca[c], b = cb[c];
-                const float Px = cacc[c] * cnx[c], Py = cacc[c] * cny[c];
-                if (a < WALL_CODE) { vx[a] -= p.im_bot * Px; vy[a] -= p.im_bot * Py; }
-                vx[b] += p.im_bot * Px; vy[b] += p.im_bot * Py;
-            }
-            __syncthreads();
+        // ---- solver ----
+        // A "round" = all contacts of one key owned by this (virtual) wave.  coop: the workgroup is one
+        // virtual wave and rounds are separated by s_barrier; otherwise each wave runs alone.
+        const int myw = coop ? 0 : wave;
+        const int lid = coop ? tid : lane;
+        const int stride = coop ? nt : 64;
+        const int nl = nList[myw];
+#define KB_ROUND_SYNC() do { if (coop) __syncthreads(); else wave_sync(); } while (0)
+#define KB_FOR_ROUNDS(...)                                                                          \
+        for (int li = 0; li < nl; ++li) {                                                           \
+            const int bk = bkList[myw * BK_PER_WAVE + li];                                          \
+            const int s_ = (int)bkStart[bk], e_ = (int)bkStart[bk + 1];                             \
+            if ((bk % RK) < RK - 1) {                                                               \
+                for (int i_ = s_ + lid; i_ < e_; i_ += stride) { const int c = order[i_]; __VA_ARGS__ }    \
+                KB_ROUND_SYNC();                                                                    \
+            } else {                                                                                \
+                const int maxr_ = (int)bkMaxRank[bk / RK];                                          \
+                for (int r_ = RK - 1; r_ <= maxr_; ++r_) {                                          \
+                    for (int i_ = s_ + lid; i_ < e_; i_ += stride) {                                \
+                        const int c = order[i_];                                                    \
+                        if ((int)crank[c] == r_) { __VA_ARGS__ }                                           \
+                    }                                                                               \
+                    KB_ROUND_SYNC();                                                                \
+                }                                                                                   \
+            }                                                                                       \
         }
-        // ---- SolveVelocityConstraints: friction 0, restitution 0, one manifold point ----
+
+        // velocity-phase normal of contact c from the start-of-step positions (b2WorldManifold::Initialize)
+#define KB_VEL_NORMAL(a, b, nx, ny)                                                                 \
+        float nx, ny;                                                                               \
+        if (a >= WALL_CODE) {                                                                       \
+            float dist_;                                                                            \
+            wall_geom(p, a - WALL_CODE, px[b], py[b], dist_, nx, ny);                               \
+            if (dist_ < 0.0f) { nx = -nx; ny = -ny; }                                               \
+        } else {                                                                                    \
+            const float dx_ = px[b] - px[a], dy_ = py[b] - py[a];                                   \
+            const float dd_ = dx_ * dx_ + dy_ * dy_;                                                \
+            nx = 1.0f; ny = 0.0f;                                                                   \
+            if (dd_ > B2_EPSILON * B2_EPSILON) {                                                    \
+                const float len_ = sqrtf(dd_);                                                      \
+                const float inv_ = 1.0f / len_;                                                     \
+                nx = dx_ * inv_; ny = dy_ * inv_;                                                   \
+            }                                                                                       \
+        }
+
+        // b2ContactSolver::WarmStart
+        KB_FOR_ROUNDS({
+            const int a = ca[c], b = cb[c];
+            KB_VEL_NORMAL(a, b, nx, ny)
+            const float acc = cacc[c];
+            const float Px = acc * nx, Py = acc * ny;
+            if (a < WALL_CODE) { vx[a] -= p.im_bot * Px; vy[a] -= p.im_bot * Py; }
+            vx[b] += p.im_bot * Px; vy[b] += p.im_bot * Py;
+        })
+        // SolveVelocityConstraints: friction 0, restitution 0, one manifold point
         for (int it = 0; it < p.vel_iters; ++it) {
-            for (int ri = 0; ri < nrounds; ++ri) {
-                const int key = roundList[ri];
-                const int s = (int)roundStart[key], en = (int)roundStart[key + 1];
-                for (int i = s + tid; i < en; i += nt) {
-                    const int c = order[i];
-                    const int a = ca[c], b = cb[c];
-                    const float nx = cnx[c], ny = cny[c];
-                    float vax = 0.0f, vay = 0.0f, ima = 0.0f;
-                    if (a < WALL_CODE) { vax = vx[a]; vay = vy[a]; ima = p.im_bot; }
-                    const float vbx = vx[b], vby = vy[b];
-                    const float dvx = vbx - vax, dvy = vby - vay;
-                    const float vn = dvx * nx + dvy * ny;
-                    const float k = ima + p.im_bot;
-                    const float nm = k > 0.0f ? 1.0f / k : 0.0f;
-                    float lambda = -(nm * vn);
-                    const float accOld = cacc[c];
-                    const float newimp = fmaxf(accOld + lambda, 0.0f);
-                    lambda = newimp - accOld;
-                    cacc[c] = newimp;
-                    const float Px = lambda * nx, Py = lambda * ny;
-                    if (a < WALL_CODE) { vx[a] = vax - ima * Px; vy[a] = vay - ima * Py; }
-                    vx[b] = vbx + p.im_bot * Px; vy[b] = vby + p.im_bot * Py;
-                }
-                __syncthreads();
-            }
+            KB_FOR_ROUNDS({
+                const int a = ca[c], b = cb[c];
+                KB_VEL_NORMAL(a, b, nx, ny)
+                float vax = 0.0f, vay = 0.0f, ima = 0.0f;
+                if (a < WALL_CODE) { vax = vx[a]; vay = vy[a]; ima = p.im_bot; }
+                const float vbx = vx[b], vby = vy[b];
+                const float dvx = vbx - vax, dvy = vby - vay;
+                const float vn = dvx * nx + dvy * ny;
+                const float k = ima + p.im_bot;
+                const float nm = k > 0.0f ? 1.0f / k : 0.0f;
+                float lambda = -(nm * vn);
+                const float accOld = cacc[c];
+                const float newimp = fmaxf(accOld + lambda, 0.0f);
+                lambda = newimp - accOld;
+                cacc[c] = newimp;
+                const float Px = lambda * nx, Py = lambda * ny;
+                if (a < WALL_CODE) { vx[a] = vax - ima * Px; vy[a] = vay - ima * Py; }
+                vx[b] = vbx + p.im_bot * Px; vy[b] = vby + p.im_bot * Py;
+            })
         }
+        __syncthreads();
+        KB_STAMP(4);
         // ---- StoreImpulses -> warm-start cache of the next substep ----
         for (int c = tid; c < ncon; c += nt) {
             const int sl = cslot[c];
@@ -558,9 +630,12 @@ __global__ void __launch_bounds__(1024) kb_step_kernel(const Params p) {
             g.ws_key[idx] = key; g.ws_acc[idx] = cacc[c];
         }
         // ---- integrate positions (b2Island::Solve) ----
-        for (int b = tid; b < N; b += nt) {
+#pragma unroll
+        for (int q = 0; q < BPT; ++q) {
+            const int b = tid + q * nt;
+            if (b >= N) continue;
             g.ws_cnt[o + b] = wsCntNew[b];
-            float vxx = vx[b], vyy = vy[b], ww = bw[b];
+            float vxx = vx[b], vyy = vy[b], ww = bw[q];
             const float tx = h * vxx, ty = h * vyy;
             if (tx * tx + ty * ty > B2_MAX_TRANSLATION_SQ) {
                 const float ratio = B2_MAX_TRANSLATION / sqrtf(tx * tx + ty * ty);
@@ -572,28 +647,28 @@ __global__ void __launch_bounds__(1024) kb_step_kernel(const Params p) {
                 ww *= ratio;
             }
             px[b] += h * vxx; py[b] += h * vyy;
-            th[b] += h * ww;
+            th[q] += h * ww;
         }
         __syncthreads();
+        KB_STAMP(5);
         // ---- SolvePositionConstraints; an island stops once its minSeparation >= -3 slop ----
         for (int it = 0; it < p.pos_iters; ++it) {
             unsigned char *act = active + (it & 1) * N, *nxt = active + ((it + 1) & 1) * N;
-            for (int ri = 0; ri < nrounds; ++ri) {
-                const int key = roundList[ri];
-                const int s = (int)roundStart[key], en = (int)roundStart[key + 1];
-                for (int i = s + tid; i < en; i += nt) {
-                    const int c = order[i];
-                    const int a = ca[c], b = cb[c];
-                    const int isl = label[b];
-                    if (!act[isl]) continue;
+            bool viol = false;
+            KB_FOR_ROUNDS({
+                const int a = ca[c], b = cb[c];
+                const int isl = (int)parent[b];
+                if (act[isl]) {
                     float nx, ny, sep, ima = 0.0f;
                     const float bx = px[b], by = py[b];
                     float axx = 0.0f, ayy = 0.0f;
                     if (a >= WALL_CODE) {
                         float dist, wx, wy;
                         wall_geom(p, a - WALL_CODE, bx, by, dist, wx, wy);
-                        nx = cnx[c]; ny = cny[c];  // manifold normal fixed at detection
-                        const float along = (nx == wx && ny == wy) ? dist : -dist;
+                        // manifold normal fixed at detection: flipped iff the centre was outside then
+                        const bool flipped = (ccls[c] & 0x80) != 0;
+                        nx = flipped ? -wx : wx; ny = flipped ? -wy : wy;
+                        const float along = flipped ? -dist : dist;
                         sep = along - B2_POLYGON_RADIUS - p.r_bot;
                     } else {
                         axx = px[a]; ayy = py[a]; ima = p.im_bot;
@@ -603,7 +678,7 @@ __global__ void __launch_bounds__(1024) kb_step_kernel(const Params p) {
                         if (!(len < B2_EPSILON)) { const float inv = 1.0f / len; nx = dx * inv; ny = dy * inv; }
                         sep = (dx * nx + dy * ny) - p.r_bot - p.r_bot;
                     }
-                    if (sep < -3.0f * B2_LINEAR_SLOP) { nxt[isl] = 1; misc[M_ANY0 + ((it + 1) & 1)] = 1u; }
+                    if (sep < -3.0f * B2_LINEAR_SLOP) { nxt[isl] = 1; viol = true; }
                     const float C = kb_clampf(B2_BAUMGARTE * (sep + B2_LINEAR_SLOP), -B2_MAX_LINEAR_CORRECTION, 0.0f);
                     const float K = ima + p.im_bot;
                     const float imp = K > 0.0f ? -C / K : 0.0f;
@@ -611,24 +686,45 @@ __global__ void __launch_bounds__(1024) kb_step_kernel(const Params p) {
                     if (a < WALL_CODE) { px[a] = axx - ima * Px; py[a] = ayy - ima * Py; }
                     px[b] = bx + p.im_bot * Px; py[b] = by + p.im_bot * Py;
                 }
+            })
+            bool any;
+            if (coop) {
+                if (viol) misc[M_ANY] = 1u;
                 __syncthreads();
+                any = misc[M_ANY] != 0u;
+                __syncthreads();
+                if (tid == 0) misc[M_ANY] = 0u;
+            } else {
+                any = __any(viol);
             }
-            const bool any = misc[M_ANY0 + ((it + 1) & 1)] != 0u;
-            __syncthreads();
             if (!any) break;
-            // prepare the flags the next iteration writes
-            for (int b = tid; b < N; b += nt) act[b] = 0;
-            if (tid == 0) misc[M_ANY0 + (it & 1)] = 0u;
-            __syncthreads();
+            // the flags the next sweep sets must start cleared (only islands of this virtual wave)
+            if (myw < W) {
+                const int s_ = (int)bkStart[myw * BK_PER_WAVE], e_ = (int)bkStart[(myw + 1) * BK_PER_WAVE];
+                for (int i_ = s_ + lid; i_ < e_; i_ += stride) act[parent[cb[order[i_]]]] = 0;
+            }
+            KB_ROUND_SYNC();
         }
         __syncthreads();
+        KB_STAMP(6);
+#undef KB_FOR_ROUNDS
+#undef KB_VEL_NORMAL
+#undef KB_ROUND_SYNC
     }
 
     // ---- write back ----
-    for (int b = tid; b < N; b += nt) { g.x[o + b] = px[b]; g.y[o + b] = py[b]; g.theta[o + b] = th[b]; }
+#pragma unroll
+    for (int q = 0; q < BPT; ++q) {
+        const int b = tid + q * nt;
+        if (b < N) { g.x[o + b] = px[b]; g.y[o + b] = py[b]; g.theta[o + b] = th[q]; }
+    }
     if (tid == 0) {
         if (p.light_type == KB_LIGHT_CIRCULAR && p.light_action && drive) { g.light_x[e] = lx; g.light_y[e] = ly; }
         if (misc[M_STATUS]) atomicOr(&g.status[e], (int)misc[M_STATUS]);
+#ifdef KB_PROFILE
+        prof_acc[7] += clock64() - prof_t;
+        for (int k = 0; k < 8; ++k) g.status[p.E + 8 * e + k] += (int)(prof_acc[k] >> 4);   // units of 16 cycles
+#endif
     }
 }
 
@@ -737,7 +833,7 @@ int kb_create(const kb_config *cfg, kb_sim **out) {
         delete s;
         return fail(KB_ELDS, "kb_create: configuration needs more than 160 KiB of LDS per env");
     }
-    s->threads = p.N <= 64 ? 64 : (p.N <= 128 ? 128 : 256);
+    s->threads = p.N <= 64 ? 64 : (p.N <= 128 ? 128 : 256);   // N <= BPT * threads
     *out = s;
     return KB_OK;
 }
@@ -822,7 +918,8 @@ int kb_lds_bytes(const kb_sim *sim) { return sim ? sim->p.L.total : KB_EINVAL; }
 int kb_contact_capacity(const kb_sim *sim) { return sim ? sim->p.cap : KB_EINVAL; }
 int kb_block_threads(const kb_sim *sim) { return sim ? sim->threads : KB_EINVAL; }
 int kb_set_block_threads(kb_sim *sim, int threads) {
-    if (!sim || threads < 64 || threads > 1024 || (threads & 63)) return fail(KB_EINVAL, "kb_set_block_threads: multiple of 64 in [64, 1024]");
+    if (!sim || threads < 64 || threads > 64 * MAX_WAVES || (threads & 63)) return fail(KB_EINVAL, "kb_set_block_threads: multiple of 64 in [64, 256]");
+    if (sim->p.N > BPT * threads) return fail(KB_EINVAL, "kb_set_block_threads: need num_bots <= 4 * threads");
     sim->threads = threads;
     return KB_OK;
 }

@@ -138,7 +138,7 @@ int kb_get_poses(kb_sim *sim, float *d_out, void *stream);
 int kb_lds_bytes(const kb_sim *sim);            /* dynamic LDS per workgroup (one env per workgroup) */
 int kb_contact_capacity(const kb_sim *sim);     /* contacts per env */
 int kb_block_threads(const kb_sim *sim);
-int kb_set_block_threads(kb_sim *sim, int threads);  /* multiple of 64, <= 1024 */
+int kb_set_block_threads(kb_sim *sim, int threads);  /* multiple of 64 in [64, 256], num_bots <= 4 * threads */
 const char *kb_last_error(void);
 const char *kb_version(void);
 

@@ -287,7 +287,7 @@ def test_block_size_does_not_change_results():
     xy, th = scenes.gaussian_spawn(E, N, sigma=0.2, seed=41)
     a = dev(scenes.random_actions(E, N, seed=42))
     outs = []
-    for threads in (64, 256, 1024):
+    for threads in (64, 128, 256):
         g = KilobotSim(E, N)
         g.block_threads = threads
         g.set_poses_m(xy, th)

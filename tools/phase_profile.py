@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Phase shares of kb_step_kernel from the diagnostic build (-DKB_PROFILE): shader cycles of wave 0
+per phase, averaged over envs.  Usage (GPU box):
+    python -m gym_kilobots_amd.build  # product
+    python -c "from gym_kilobots_amd import build; build.build_profile()"
+    KB_HIP_LIB=gym_kilobots_amd/libkilobots_hip_prof.so python tools/phase_profile.py [--envs E --bots N]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from gym_kilobots_amd.sim import KilobotSim  # noqa: E402
+from tests import scenes  # noqa: E402
+
+PHASES = ['drive+grid', 'count pass', 'emit pass', 'islands+buckets', 'warm+velocity', 'store+integrate', 'position', 'tail']
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--envs', type=int, default=4096)
+    ap.add_argument('--bots', type=int, default=1024)
+    ap.add_argument('--warm', type=int, default=60)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--fused', type=int, default=1)
+    args = ap.parse_args()
+    E, N = args.envs, args.bots
+    assert 'prof' in os.environ.get('KB_HIP_LIB', ''), 'run with KB_HIP_LIB=.../libkilobots_hip_prof.so'
+    sim = KilobotSim(E, N)
+    sim.status = torch.zeros(E + 8 * E, dtype=torch.int32, device=sim.device)   # status + stamp area
+    sim._bind()
+    xy1, th1 = scenes.lattice_spawn(8, N, seed=1000)
+    reps = (E + 7) // 8
+    sim.set_poses_m(np.tile(xy1, (reps, 1, 1))[:E], np.tile(th1, (reps, 1))[:E])
+    acts = [torch.from_numpy(np.tile(scenes.random_actions(8, N, seed=2000 + k), (reps, 1, 1))[:E].copy()).cuda() for k in range(8)]
+    for k in range(args.warm):
+        sim.step(1, actions=acts[k % 8])
+    torch.cuda.synchronize()
+    sim.status[E:].zero_()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for k in range(args.steps):
+        sim.step(args.fused, actions=acts[k % 8])
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / args.steps
+    st = sim.status[E:].reshape(E, 8).double().cpu().numpy() * 16 / (args.steps * args.fused)
+    mean = st.mean(0)
+    print('launch %.3f ms (%d substeps per launch); cycles per env-substep (wave 0), mean over %d envs:' % (ms, args.fused, E))
+    for name, c in zip(PHASES, mean):
+        print('  %-18s %9.0f  %5.1f%%' % (name, c, 100 * c / mean.sum()))
+    print('  %-18s %9.0f' % ('total', mean.sum()))
+
+
+if __name__ == '__main__':
+    main()
