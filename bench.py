@@ -31,8 +31,8 @@ HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=100)
-    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=60)
     ap.add_argument('--envs', type=int, default=4096, help='envs per GPU')
     ap.add_argument('--bots', type=int, default=1024)
     ap.add_argument('--threads', type=int, default=0, help='workgroup size override')
@@ -188,7 +188,7 @@ def cpu_baseline(args, N, xy1, th1):
         o.set_actions(acts[n % 8])
         o.step(1, threads=cores)
         n += 1
-        if time.perf_counter() - t0 > 12.0 or n >= 400:
+        if time.perf_counter() - t0 > 12.0:
             break
     dt = time.perf_counter() - t0
     return {'value': Ec * N * n / dt, 'unit': 'kilobot-steps/s', 'cores': cores, 'kind': 'port',

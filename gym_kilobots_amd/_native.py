@@ -35,6 +35,7 @@ class KbConfig(C.Structure):
         ('obj_density', C.c_float), ('obj_friction', C.c_float),
         ('obj_linear_damping', C.c_float), ('obj_angular_damping', C.c_float),
         ('toi_walls', C.c_int32),
+        ('solver_mode', C.c_int32),
     ]
 
 
@@ -45,7 +46,7 @@ BUFFER_FIELDS = ['x', 'y', 'theta', 'v', 'w', 'acc_v', 'acc_w', 'motor_l', 'moto
                  'light_x', 'light_y', 'light_vx', 'light_vy',
                  'ox', 'oy', 'otheta', 'ovx', 'ovy', 'ow',
                  'ws_key', 'ws_acc', 'ws_cnt',
-                 'light_value', 'light_gx', 'light_gy', 'cmd_vx', 'cmd_vy', 'cmd_w', 'status']
+                 'light_value', 'light_gx', 'light_gy', 'cmd_vx', 'cmd_vy', 'cmd_w', 'status', 'scratch']
 
 
 class KbBuffers(C.Structure):
@@ -53,7 +54,7 @@ class KbBuffers(C.Structure):
 
 
 EXPORTS = ['kb_create', 'kb_destroy', 'kb_bind', 'kb_set_actions', 'kb_step', 'kb_get_poses',
-           'kb_lds_bytes', 'kb_contact_capacity', 'kb_block_threads', 'kb_set_block_threads',
+           'kb_lds_bytes', 'kb_contact_capacity', 'kb_scratch_bytes', 'kb_block_threads', 'kb_set_block_threads',
            'kb_last_error', 'kb_version']
 
 _lib = None
@@ -88,6 +89,8 @@ def load():
     for name in ('kb_lds_bytes', 'kb_contact_capacity', 'kb_block_threads'):
         getattr(lib, name).argtypes = [_P]
         getattr(lib, name).restype = C.c_int
+    lib.kb_scratch_bytes.argtypes = [_P]
+    lib.kb_scratch_bytes.restype = C.c_size_t
     lib.kb_set_block_threads.argtypes = [_P, C.c_int]
     lib.kb_set_block_threads.restype = C.c_int
     lib.kb_last_error.argtypes = []
@@ -125,6 +128,7 @@ def default_config(num_envs, num_bots, drive_mode=DRIVE_VELOCITY, light_type=LIG
     c.obj_density, c.obj_friction = 2.0, 0.01
     c.obj_linear_damping = c.obj_angular_damping = 0.8
     c.toi_walls = 0
+    c.solver_mode = 0
     for k, v in kw.items():
         cur = getattr(c, k)
         if hasattr(cur, '__len__'):

@@ -58,20 +58,36 @@ constexpr unsigned short EMPTY16 = 0xFFFFu;
 // contact classes in canonical order; +1 on E/N/NE/NW for odd base-cell parity
 constexpr int CLS_SAME = 0, CLS_E = 1, CLS_N = 3, CLS_NE = 5, CLS_NW = 7, CLS_WALL = 9, NUM_CLS = 10;
 constexpr int RK = 4;                 // rank buckets per class; the last one holds every rank >= RK-1
-constexpr int MAX_WAVES = 4;       // workgroups are at most 256 threads
+#ifndef KB_MAX_WAVES
+#define KB_MAX_WAVES 8
+#endif
+#ifndef KB_BPT
+#define KB_BPT 2
+#endif
+#ifndef KB_KREG
+#define KB_KREG 2
+#endif
+#ifndef KB_MIN_WAVES_PER_SIMD
+#define KB_MIN_WAVES_PER_SIMD 4
+#endif
+constexpr int MAX_WAVES = KB_MAX_WAVES;   // waves per workgroup
 constexpr int BK_PER_WAVE = NUM_CLS * RK;
 constexpr int MAX_BUCKETS = MAX_WAVES * BK_PER_WAVE;
-constexpr int BPT = 4;                // bots per thread (max): N <= BPT * blockDim.x
+constexpr int BPT = KB_BPT;                // bots per thread (max): N <= BPT * blockDim.x
 constexpr int GIANT_ISLAND = 256;     // contacts; larger islands are swept by the whole workgroup
+constexpr int KREG = KB_KREG;               // contacts a lane can keep in registers (register-resident solver)
+constexpr int CAP_LDS = 1024;         // contacts staged in LDS; denser envs stage in the global scratch slice
 
-enum { M_NCON = 0, M_TOTAL = 1, M_ANY = 2, M_STATUS = 3, M_MAXISL = 4, M_COUNT = 8 };
+enum { M_NCON = 0, M_TOTAL = 1, M_ANY = 2, M_STATUS = 3, M_MAXISL = 4, M_WCNT = 8, M_WFILL = 8 + MAX_WAVES, M_COUNT = 8 + 2 * MAX_WAVES };
 
 struct Layout {  // byte offsets into dynamic LDS
     int px, py, vx, vy;
-    int head, dirCnt, parent, bkStart, bkFill, bkMaxRank, misc, wsum;
-    int cacc;
-    int ca, cb, cbk, order, next, cellOf, bkList;
-    int ccls, crank, cslot, wsCnt, wsCntNew, active, nList;
+    int head, dirCnt, parent, misc, wsum;
+    int wsOff, newOff, oldKey, oldAcc;
+    int sPair, sInfo, sAcc, cbk, order;
+    int bkStart, bkFill, bkMaxRank, bkList;
+    int next, cellOf;
+    int wsCnt, wsCntNew, active, nList;
     int total;
 };
 
@@ -79,26 +95,27 @@ struct Params {
     kb_buffers buf;
     const float *actions;
     const float *light_action;
-    int N, E, S, gw, gh, ncell, cap, n_substeps, flags, drive_mode, light_type, vel_iters, pos_iters;
+    int N, NP, E, S, gw, gh, ncell, cap, capL, n_substeps, flags, drive_mode, light_type, vel_iters, pos_iters;
+    int solver_mode;
     float xmin, ymin, xmax, ymax, inv_cell, r_bot, im_bot, kl_bot, ka_bot, h;
     float light_radius, light_lo[2], light_hi[2], act_lo[2], act_hi[2];
     Layout L;
 };
 
-Layout make_layout(int N, int ncell, int cap) {
+Layout make_layout(int NP, int ncell, int capL) {
     Layout L;
     int o = 0;
     auto take = [&](int bytes) { int r = o; o += (bytes + 15) & ~15; return r; };
-    L.px = take(4 * N); L.py = take(4 * N); L.vx = take(4 * N); L.vy = take(4 * N);
-    L.head = take(4 * ncell); L.dirCnt = take(4 * N); L.parent = take(4 * N);
-    L.bkStart = take(4 * (MAX_BUCKETS + 1)); L.bkFill = take(4 * MAX_BUCKETS);
-    L.bkMaxRank = take(4 * MAX_WAVES * NUM_CLS);
+    L.px = take(4 * NP); L.py = take(4 * NP); L.vx = take(4 * NP); L.vy = take(4 * NP);
+    L.head = take(4 * ncell); L.dirCnt = take(4 * NP); L.parent = take(4 * NP);
     L.misc = take(4 * M_COUNT); L.wsum = take(4 * 16);
-    L.cacc = take(4 * cap);
-    L.ca = take(2 * cap); L.cb = take(2 * cap); L.cbk = take(2 * cap); L.order = take(2 * cap);
-    L.next = take(2 * N); L.cellOf = take(2 * N); L.bkList = take(2 * MAX_BUCKETS);
-    L.ccls = take(cap); L.crank = take(cap); L.cslot = take(cap);
-    L.wsCnt = take(N); L.wsCntNew = take(N); L.active = take(2 * N); L.nList = take(MAX_WAVES);
+    L.wsOff = take(2 * NP); L.newOff = take(2 * NP); L.oldKey = take(2 * capL); L.oldAcc = take(4 * capL);
+    L.sPair = take(4 * capL); L.sInfo = take(4 * capL); L.sAcc = take(4 * capL);
+    L.cbk = take(2 * capL); L.order = take(2 * capL);
+    L.bkStart = take(4 * (MAX_BUCKETS + 1)); L.bkFill = take(4 * MAX_BUCKETS);
+    L.bkMaxRank = take(4 * MAX_WAVES * NUM_CLS); L.bkList = take(2 * MAX_BUCKETS);
+    L.next = take(2 * NP); L.cellOf = take(2 * NP);
+    L.wsCnt = take(NP); L.wsCntNew = take(NP); L.active = take(2 * NP); L.nList = take(16);
     L.total = o;
     return L;
 }
@@ -186,7 +203,7 @@ __device__ __forceinline__ void wall_geom(const Params &p, int wl, float x, floa
 }
 
 #ifdef KB_PROFILE
-// diagnostic build: wave 0 / lane 0 accumulates shader cycles per phase into g.status[E + 8*e + phase]
+// diagnostic build: thread 0 accumulates shader cycles per phase into g.status[E + 8*e + phase]
 #define KB_STAMP(ph) do { if (tid == 0) { long long t_ = clock64(); prof_acc[ph] += t_ - prof_t; prof_t = t_; } } while (0)
 #else
 #define KB_STAMP(ph) do { } while (0)
@@ -195,12 +212,43 @@ __device__ __forceinline__ void wall_geom(const Params &p, int wl, float x, floa
 __device__ __forceinline__ int dir_dx(int k) { return (k == 1 || k == 3) ? 1 : (k == 4 ? -1 : 0); }
 __device__ __forceinline__ int dir_dy(int k) { return (k >= 2) ? 1 : 0; }
 
-__global__ void __launch_bounds__(256, 2) kb_step_kernel(const Params p) {
+// exclusive scan of NP (multiple of 4, <= 4 * blockDim.x) u8 counts into u16 offsets; returns the total.
+// All threads must call; contains two workgroup barriers.
+__device__ __forceinline__ unsigned block_scan_u8(const unsigned char *cnt, unsigned short *off, int NP, unsigned *wsum) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    const bool in = 4 * tid < NP;
+    const unsigned c4 = in ? *reinterpret_cast<const unsigned *>(cnt + 4 * tid) : 0u;
+    const unsigned c0 = c4 & 255u, c1 = (c4 >> 8) & 255u, c2 = (c4 >> 16) & 255u, c3 = c4 >> 24;
+    const unsigned sum = c0 + c1 + c2 + c3;
+    unsigned incl = sum;
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    unsigned base = 0, total = 0;
+    for (int w = 0; w < nw; ++w) { const unsigned s = wsum[w]; if (w < wave) base += s; total += s; }
+    if (in) {
+        const unsigned r0 = base + incl - sum, r1 = r0 + c0, r2 = r1 + c1, r3 = r2 + c2;
+        reinterpret_cast<unsigned *>(off + 4 * tid)[0] = r0 | (r1 << 16);
+        reinterpret_cast<unsigned *>(off + 4 * tid)[1] = r2 | (r3 << 16);
+    }
+    __syncthreads();
+    return total;
+}
+
+#define KB_NEXT(b) (nextb[b] == EMPTY16 ? EMPTY32 : (unsigned)nextb[b])
+
+// One instantiation per (drive law, light model): keeps only that law's code (and registers) in the kernel.
+template <int DRIVE_MODE, int LIGHT_TYPE>
+__global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_step_kernel(const Params p) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int e = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
-    const int N = p.N, S = p.S;
+    const int N = p.N, NP = p.NP, S = p.S;
     const size_t o = (size_t)e * N;
+    const size_t wo = (size_t)e * p.cap;       // this env's slice of the packed warm-start / scratch arrays
     const float h = p.h;
 
     float *px = (float *)(smem + p.L.px), *py = (float *)(smem + p.L.py);
@@ -208,58 +256,87 @@ __global__ void __launch_bounds__(256, 2) kb_step_kernel(const Params p) {
     unsigned *head = (unsigned *)(smem + p.L.head), *dirCnt = (unsigned *)(smem + p.L.dirCnt);
     unsigned *islCnt = dirCnt;  // alias: dirCnt is dead once the contacts are emitted
     unsigned *parent = (unsigned *)(smem + p.L.parent);
+    unsigned *misc = (unsigned *)(smem + p.L.misc), *wsum = (unsigned *)(smem + p.L.wsum);
+    unsigned short *wsOff = (unsigned short *)(smem + p.L.wsOff), *newOff = (unsigned short *)(smem + p.L.newOff);
+    unsigned short *oldKey = (unsigned short *)(smem + p.L.oldKey);
+    float *oldAcc = (float *)(smem + p.L.oldAcc);
+    unsigned *lPair = (unsigned *)(smem + p.L.sPair), *lInfo = (unsigned *)(smem + p.L.sInfo);
+    float *lAcc = (float *)(smem + p.L.sAcc);
+    unsigned short *lCbk = (unsigned short *)(smem + p.L.cbk), *lOrder = (unsigned short *)(smem + p.L.order);
     unsigned *bkStart = (unsigned *)(smem + p.L.bkStart), *bkFill = (unsigned *)(smem + p.L.bkFill);
     unsigned *bkMaxRank = (unsigned *)(smem + p.L.bkMaxRank);
-    unsigned *misc = (unsigned *)(smem + p.L.misc);
-    float *cacc = (float *)(smem + p.L.cacc);
-    unsigned short *ca = (unsigned short *)(smem + p.L.ca), *cb = (unsigned short *)(smem + p.L.cb);
-    unsigned short *cbk = (unsigned short *)(smem + p.L.cbk), *order = (unsigned short *)(smem + p.L.order);
-    unsigned short *nextb = (unsigned short *)(smem + p.L.next), *cellOf = (unsigned short *)(smem + p.L.cellOf);
     unsigned short *bkList = (unsigned short *)(smem + p.L.bkList);
-    unsigned char *ccls = smem + p.L.ccls, *crank = smem + p.L.crank, *cslot = smem + p.L.cslot;
+    unsigned short *nextb = (unsigned short *)(smem + p.L.next), *cellOf = (unsigned short *)(smem + p.L.cellOf);
     unsigned char *wsCnt = smem + p.L.wsCnt, *wsCntNew = smem + p.L.wsCntNew;
     unsigned char *active = smem + p.L.active, *nList = smem + p.L.nList;
 
     const kb_buffers &g = p.buf;
+    // contact staging in global scratch, used when an env has more contacts than fit the LDS staging area
+    unsigned *gPair = reinterpret_cast<unsigned *>(g.scratch) + wo * 4;
+    unsigned *gInfo = gPair + p.cap;
+    float *gAcc = reinterpret_cast<float *>(gInfo + p.cap);
+    unsigned short *gCbk = reinterpret_cast<unsigned short *>(gAcc + p.cap), *gOrder = gCbk + p.cap;
+
 #ifdef KB_PROFILE
-    long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long prof_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long prof_t = clock64();
 #endif
 
     // ---- load state; optional fused set_action (kilobot.py:235-241, 283-289) ----
-    float th[BPT], bw[BPT];
+    float th[BPT], bw[BPT], cv[BPT], cw[BPT], av[BPT], aw[BPT];
+    const bool velmode = DRIVE_MODE == KB_DRIVE_VELOCITY || DRIVE_MODE == KB_DRIVE_ACCEL;
 #pragma unroll
     for (int q = 0; q < BPT; ++q) {
         const int b = tid + q * nt;
-        th[q] = 0.0f; bw[q] = 0.0f;
+        th[q] = 0.0f; bw[q] = 0.0f; cv[q] = 0.0f; cw[q] = 0.0f; av[q] = 0.0f; aw[q] = 0.0f;
         if (b < N) {
             px[b] = g.x[o + b]; py[b] = g.y[o + b]; th[q] = g.theta[o + b];
+            wsCnt[b] = g.ws_cnt[o + b];
+            if (velmode) { cv[q] = g.v[o + b]; cw[q] = g.w[o + b]; }
+            if (DRIVE_MODE == KB_DRIVE_ACCEL) { av[q] = g.acc_v[o + b]; aw[q] = g.acc_w[o + b]; }
             if (p.actions) {
                 const float2 a = reinterpret_cast<const float2 *>(p.actions)[o + b];
                 const float mw = 0.5f * 3.14159265358979323846f;
-                if (p.drive_mode == KB_DRIVE_VELOCITY) {
-                    g.v[o + b] = fmaxf(fminf(a.x, 0.01f), 0.0f);
-                    g.w[o + b] = fmaxf(fminf(a.y, mw), -mw);
-                } else if (p.drive_mode == KB_DRIVE_ACCEL) {
-                    const float aw = 0.2f * 3.14159265358979323846f;
-                    g.acc_v[o + b] = fmaxf(fminf(a.x, 0.005f), -0.005f);
-                    g.acc_w[o + b] = fmaxf(fminf(a.y, aw), -aw);
+                if (DRIVE_MODE == KB_DRIVE_VELOCITY) {
+                    cv[q] = fmaxf(fminf(a.x, 0.01f), 0.0f);
+                    cw[q] = fmaxf(fminf(a.y, mw), -mw);
+                    g.v[o + b] = cv[q]; g.w[o + b] = cw[q];
+                } else if (DRIVE_MODE == KB_DRIVE_ACCEL) {
+                    const float aw_ = 0.2f * 3.14159265358979323846f;
+                    av[q] = fmaxf(fminf(a.x, 0.005f), -0.005f);
+                    aw[q] = fmaxf(fminf(a.y, aw_), -aw_);
+                    g.acc_v[o + b] = av[q]; g.acc_w[o + b] = aw[q];
                 }
             }
         }
     }
+    for (int b = N + tid; b < NP; b += nt) { wsCnt[b] = 0; wsCntNew[b] = 0; }
     for (int c = tid; c < p.ncell; c += nt) head[c] = EMPTY32;
     if (tid == 0) misc[M_STATUS] = 0;
     float lx = 0.0f, ly = 0.0f;
-    if (p.light_type == KB_LIGHT_CIRCULAR) { lx = g.light_x[e]; ly = g.light_y[e]; }
+    if (LIGHT_TYPE == KB_LIGHT_CIRCULAR) { lx = g.light_x[e]; ly = g.light_y[e]; }
     const bool drive = !(p.flags & KB_STEP_NO_DRIVE);
     const float rr = p.r_bot + p.r_bot, rr2 = rr * rr;
     const float rw = B2_POLYGON_RADIUS + p.r_bot, rw2 = rw * rw;
+    // b2ContactSolver: normalMass = 1 / (invMassA + invMassB); walls are static (invMass 0)
+    const float kbb = p.im_bot + p.im_bot, kwb = 0.0f + p.im_bot;
+    const float nm_bb = kbb > 0.0f ? 1.0f / kbb : 0.0f, nm_wb = kwb > 0.0f ? 1.0f / kwb : 0.0f;
+    __syncthreads();
+    // warm-start list of the previous substep: offsets, and an LDS image of the packed entries if it fits
+    unsigned oldTotal = block_scan_u8(wsCnt, wsOff, NP, wsum);
+    bool oldInLds = oldTotal <= (unsigned)p.capL;
+    if (oldInLds) {
+        for (unsigned i = tid; i < oldTotal; i += nt) {
+            const unsigned k = g.ws_key[wo + i];
+            oldKey[i] = (unsigned short)(k >= KEY_WALL ? WALL_CODE + (k - KEY_WALL) : k);
+            oldAcc[i] = g.ws_acc[wo + i];
+        }
+    }
     __syncthreads();
 
     for (int sub = 0; sub < p.n_substeps; ++sub) {
         // ---- light.step: SinglePositionLight.step, light.py:59-75 (uniform per env) ----
-        if (p.light_action && p.light_type == KB_LIGHT_CIRCULAR && drive) {
+        if (p.light_action && LIGHT_TYPE == KB_LIGHT_CIRCULAR && drive) {
             float ax = fminf(fmaxf(p.light_action[2 * e + 0], p.act_lo[0]), p.act_hi[0]);
             float ay = fminf(fmaxf(p.light_action[2 * e + 1], p.act_lo[1]), p.act_hi[1]);
             float nlx = lx + ax * h, nly = ly + ay * h;
@@ -276,9 +353,9 @@ __global__ void __launch_bounds__(256, 2) kb_step_kernel(const Params p) {
             if (drive) {
                 const float t = th[q];
                 float lval = 0.0f, lgx = 0.0f, lgy = 0.0f;
-                if (p.light_type == KB_LIGHT_CIRCULAR) {
+                if (LIGHT_TYPE == KB_LIGHT_CIRCULAR) {
                     float sx = bx, sy = by;
-                    if (p.drive_mode != KB_DRIVE_SIMPLE_PHOTOTAXIS) {  // kilobot.py:54-55: world point of (0, -r)
+                    if (DRIVE_MODE != KB_DRIVE_SIMPLE_PHOTOTAXIS) {  // kilobot.py:54-55: world point of (0, -r)
                         float s, c;
                         kb_sincosf(t, s, c);
                         const float lx0 = 0.0f, ly0 = -p.r_bot;
@@ -288,12 +365,12 @@ __global__ void __launch_bounds__(256, 2) kb_step_kernel(const Params p) {
                     kb_light_circular(sx / WORLD_SCALE, sy / WORLD_SCALE, lx, ly, p.light_radius, lval, lgx, lgy);
                     if (g.light_value) { g.light_value[o + b] = lval; g.light_gx[o + b] = lgx; g.light_gy[o + b] = lgy; }
                 }
-                switch (p.drive_mode) {
+                switch (DRIVE_MODE) {
                 case KB_DRIVE_ACCEL: {  // kilobot.py:294-300
-                    float v = g.v[o + b] + g.acc_v[o + b] * h, ww = g.w[o + b] + g.acc_w[o + b] * h;
+                    float v = cv[q] + av[q] * h, ww = cw[q] + aw[q] * h;
                     const float mw = 0.5f * 3.14159265358979323846f;
                     v = fminf(fmaxf(v, 0.0f), 0.01f); ww = fminf(fmaxf(ww, -mw), mw);
-                    g.v[o + b] = v; g.w[o + b] = ww;
+                    cv[q] = v; cw[q] = ww;
                     float s, c;
                     kb_sincosf(t, s, c);
                     float sp = v * WORLD_SCALE;
@@ -302,8 +379,8 @@ __global__ void __launch_bounds__(256, 2) kb_step_kernel(const Params p) {
                 case KB_DRIVE_VELOCITY: {  // kilobot.py:253-258
                     float s, c;
                     kb_sincosf(t, s, c);
-                    float sp = g.v[o + b] * WORLD_SCALE;
-                    bvx = c * sp; bvy = s * sp; bww = g.w[o + b];
+                    float sp = cv[q] * WORLD_SCALE;
+                    bvx = c * sp; bvy = s * sp; bww = cw[q];
                 } break;
                 case KB_DRIVE_PHOTOTAXIS: {  // kilobot.py:318-333
                     int upd = g.pt_update[o + b];
@@ -333,9 +410,8 @@ __global__ void __launch_bounds__(256, 2) kb_step_kernel(const Params p) {
             }
             if (g.cmd_vx) { g.cmd_vx[o + b] = bvx; g.cmd_vy[o + b] = bvy; g.cmd_w[o + b] = bww; }
             // b2Island::Solve: v *= 1/(1 + h c)  (SimplePhototaxisKilobot sets linearDamping = 0, kilobot.py:203)
-            const float kl = (p.drive_mode == KB_DRIVE_SIMPLE_PHOTOTAXIS) ? 1.0f / (1.0f + h * 0.0f) : p.kl_bot;
+            const float kl = (DRIVE_MODE == KB_DRIVE_SIMPLE_PHOTOTAXIS) ? 1.0f / (1.0f + h * 0.0f) : p.kl_bot;
             vx[b] = bvx * kl; vy[b] = bvy * kl; bw[q] = bww * p.ka_bot;
-            wsCnt[b] = g.ws_cnt[o + b];
             parent[b] = b;
             // broadphase: push the bot on its cell's list
             int cx = (int)floorf((bx - p.xmin) * p.inv_cell);
@@ -346,98 +422,143 @@ __global__ void __launch_bounds__(256, 2) kb_step_kernel(const Params p) {
             cellOf[b] = (unsigned short)cell;
             nextb[b] = (unsigned short)atomicExch(&head[cell], (unsigned)b);
         }
-        for (int k = tid; k < nw * BK_PER_WAVE; k += nt) { bkStart[k] = 0; bkFill[k] = 0; }
-        for (int k = tid; k < nw * NUM_CLS; k += nt) bkMaxRank[k] = 0;
-        if (tid == 0) { bkStart[nw * BK_PER_WAVE] = 0; misc[M_NCON] = 0; misc[M_TOTAL] = 0; misc[M_ANY] = 0; misc[M_MAXISL] = 0; }
+        if (tid < M_COUNT && tid != M_STATUS) misc[tid] = 0;
         __syncthreads();
         KB_STAMP(0);
 
-        // ---- narrowphase pass 1: per bot, number of contacts it owns per direction ----
+        // ---- narrowphase pass 1 (thread per bot): find the contacts each bot owns (5-cell half stencil + walls),
+        //      append them to the staging list, count them per direction ----
+        auto find_pass = [&](unsigned *sPair, unsigned *sInfo, int stageCap_) __attribute__((always_inline)) {
 #pragma unroll 1
-        for (int a = tid; a < N; a += nt) {
-            const int cell = cellOf[a];
-            const int cx = cell % p.gw, cy = cell / p.gw;
-            const float ax = px[a], ay = py[a];
-            unsigned cnt = 0;
+            for (int a = tid; a < N; a += nt) {
+                const int cell = cellOf[a];
+                const int cx = cell % p.gw, cy = cell / p.gw;
+                const float ax = px[a], ay = py[a];
+                unsigned cnt = 0, mine = 0;
 #pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                const int ox = cx + dir_dx(k), oy = cy + dir_dy(k);
-                if (ox < 0 || ox >= p.gw || oy >= p.gh) continue;
-                unsigned ck = 0;
-                for (unsigned b = head[oy * p.gw + ox]; b != EMPTY32; b = (nextb[b] == EMPTY16 ? EMPTY32 : nextb[b])) {
-                    if (k == 0 && (int)b <= a) continue;
-                    const float dx = px[b] - ax, dy = py[b] - ay;
-                    const float dd = dx * dx + dy * dy;
-                    if (dd > rr2) continue;  // b2CollideCircles
-                    ck++;
+                for (int k = 0; k < 5; ++k) {
+                    const int ox = cx + dir_dx(k), oy = cy + dir_dy(k);
+                    if (ox < 0 || ox >= p.gw || oy >= p.gh) continue;
+                    unsigned ck = 0;
+                    for (unsigned b = head[oy * p.gw + ox]; b != EMPTY32; b = KB_NEXT(b)) {
+                        if (k == 0 && (int)b <= a) continue;
+                        const float dx = px[b] - ax, dy = py[b] - ay;
+                        const float dd = dx * dx + dy * dy;
+                        if (dd > rr2) continue;  // b2CollideCircles
+                        ck++;
+                        const unsigned c = atomicAdd(&misc[M_NCON], 1u);
+                        if (c < (unsigned)stageCap_) { sPair[c] = (unsigned)a | (b << 16); sInfo[c] = (unsigned)k; }
+                    }
+                    mine += ck;
+                    if (ck > 63u) { ck = 63u; atomicOr(&misc[M_STATUS], 4u); }
+                    cnt |= ck << (6 * k);
                 }
-                if (ck > 63u) { ck = 63u; atomicOr(&misc[M_STATUS], 4u); }
-                cnt |= ck << (6 * k);
-            }
-            dirCnt[a] = cnt;
-        }
-        __syncthreads();
-        KB_STAMP(1);
-
-        // ---- narrowphase pass 2: emit contacts (class, rank), warm-start impulses, hook islands ----
-#pragma unroll 1
-        for (int a = tid; a < N; a += nt) {
-            const int cell = cellOf[a];
-            const int cx = cell % p.gw, cy = cell / p.gw;
-            const float ax = px[a], ay = py[a];
-            const unsigned mycnt = dirCnt[a];
-            int nslot = 0;
+                // walls: b2CollideEdgeAndCircle (region AB) against the chain loop of kilobots_env.py:48-51
 #pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                const int nk = (int)((mycnt >> (6 * k)) & 63u);
-                if (nk == 0) continue;
-                const int oc = (cy + dir_dy(k)) * p.gw + (cx + dir_dx(k));
-                int cls;
-                if (k == 0) cls = CLS_SAME;
-                else if (k == 1) cls = CLS_E + (cx & 1);
-                else if (k == 2) cls = CLS_N + (cy & 1);
-                else if (k == 3) cls = CLS_NE + (cx & 1);
-                else cls = CLS_NW + (cx & 1);
-                // rank base: contacts of this (cell, direction) group owned by lower-id bots of the cell
-                int rbase = 0;
-                for (unsigned a2 = head[cell]; a2 != EMPTY32; a2 = (nextb[a2] == EMPTY16 ? EMPTY32 : nextb[a2]))
-                    if ((int)a2 < a) rbase += (int)((dirCnt[a2] >> (6 * k)) & 63u);
-                for (unsigned b = head[oc]; b != EMPTY32; b = (nextb[b] == EMPTY16 ? EMPTY32 : nextb[b])) {
-                    if (k == 0 && (int)b <= a) continue;
-                    const float dx = px[b] - ax, dy = py[b] - ay;
-                    const float dd = dx * dx + dy * dy;
-                    if (dd > rr2) continue;
+                for (int wl = 0; wl < 4; ++wl) {
+                    float dist, nx, ny;
+                    wall_geom(p, wl, ax, ay, dist, nx, ny);
+                    if (dist * dist > rw2) continue;
+                    mine++;
+                    const unsigned c = atomicAdd(&misc[M_NCON], 1u);
+                    // info bits 0-2: 5 + wall; bit 7: centre outside the wall line (manifold normal points outwards)
+                    if (c < (unsigned)stageCap_) {
+                        sPair[c] = (unsigned)(WALL_CODE + wl) | ((unsigned)a << 16);
+                        sInfo[c] = (unsigned)(5 + wl) | (dist < 0.0f ? 0x80u : 0u);
+                    }
+                }
+                dirCnt[a] = cnt;
+                if (mine > (unsigned)S) { atomicOr(&misc[M_STATUS], 2u); mine = S; }
+                wsCntNew[a] = (unsigned char)mine;
+            }
+        };
+        bool big = p.solver_mode >= 3;
+        if (!big) {
+            find_pass(lPair, lInfo, p.capL);
+            __syncthreads();
+            big = (int)misc[M_NCON] > p.capL;    // does not fit the LDS staging area: redo into the global scratch slice
+            __syncthreads();
+            if (big && tid == 0) misc[M_NCON] = 0;
+            if (big) __syncthreads();
+        }
+        if (big) {
+            find_pass(gPair, gInfo, p.cap);
+            __syncthreads();
+        }
+        KB_STAMP(1);
+        const int stageCap = big ? p.cap : p.capL;
+        if ((int)misc[M_NCON] > stageCap && tid == 0) atomicOr(&misc[M_STATUS], 1u);
+        const int ncon = min((int)misc[M_NCON], stageCap);
+
+        // ---- narrowphase pass 2 (thread per contact): class, rank, warm-start slot + impulse, island hooking ----
+        auto ws_find = [&](int owner, unsigned key16) __attribute__((always_inline)) -> float {
+            const int cnt = wsCnt[owner], off = wsOff[owner];
+            if (oldInLds) {
+                for (int s = 0; s < cnt; ++s)
+                    if (oldKey[off + s] == (unsigned short)key16) return oldAcc[off + s];
+            } else {
+                const unsigned key32 = key16 >= (unsigned)WALL_CODE ? KEY_WALL + (key16 - WALL_CODE) : key16;
+                for (int s = 0; s < cnt; ++s)
+                    if (g.ws_key[wo + off + s] == key32) return g.ws_acc[wo + off + s];
+            }
+            return -1.0f;   // accumulated impulses are >= 0
+        };
+        auto label_pass = [&](unsigned *sPair, unsigned *sInfo, float *sAcc) __attribute__((always_inline)) {
+            for (int c = tid; c < ncon; c += nt) {
+                const unsigned pr = sPair[c], inf0 = sInfo[c];
+                const int k = inf0 & 15;
+                int cls, r, slot;
+                float acc;
+                if (k >= 5) {   // wall contact, owned by the bot
+                    const int a = pr >> 16, wl = k - 5;
+                    const float ax = px[a], ay = py[a];
+                    const unsigned dc = dirCnt[a];
+                    int nbots = 0;
+#pragma unroll
+                    for (int k2 = 0; k2 < 5; ++k2) nbots += (int)((dc >> (6 * k2)) & 63u);
+                    r = 0;
+#pragma unroll
+                    for (int w2 = 0; w2 < 3; ++w2) {
+                        float dist, nx, ny;
+                        wall_geom(p, w2, ax, ay, dist, nx, ny);
+                        if (w2 < wl && !(dist * dist > rw2)) r++;
+                    }
+                    cls = CLS_WALL | (int)(inf0 & 0x80u);
+                    slot = nbots + r;
+                    acc = ws_find(a, (unsigned)(WALL_CODE + wl));
+                } else {
+                    const int a = pr & 0xFFFF;
+                    const unsigned b = pr >> 16;
+                    const int cell = cellOf[a];
+                    const int cx = cell % p.gw, cy = cell / p.gw;
+                    const float ax = px[a], ay = py[a];
+                    if (k == 0) cls = CLS_SAME;
+                    else if (k == 1) cls = CLS_E + (cx & 1);
+                    else if (k == 2) cls = CLS_N + (cy & 1);
+                    else if (k == 3) cls = CLS_NE + (cx & 1);
+                    else cls = CLS_NW + (cx & 1);
+                    const unsigned dc = dirCnt[a];
+                    int sbase = 0;
+                    for (int k2 = 0; k2 < k; ++k2) sbase += (int)((dc >> (6 * k2)) & 63u);
+                    // rank base: contacts of this (cell, direction) group owned by lower-id bots of the cell
+                    int rbase = 0;
+                    for (unsigned a2 = head[cell]; a2 != EMPTY32; a2 = KB_NEXT(a2))
+                        if ((int)a2 < a) rbase += (int)((dirCnt[a2] >> (6 * k)) & 63u);
                     // position of b among a's touching partners of this direction, in ascending id order
                     int j = 0;
-                    if (nk > 1) {
-                        for (unsigned b2 = head[oc]; b2 != EMPTY32; b2 = (nextb[b2] == EMPTY16 ? EMPTY32 : nextb[b2])) {
+                    if (((dc >> (6 * k)) & 63u) > 1u) {
+                        const int oc = (cy + dir_dy(k)) * p.gw + (cx + dir_dx(k));
+                        for (unsigned b2 = head[oc]; b2 != EMPTY32; b2 = KB_NEXT(b2)) {
                             if (b2 >= b || (k == 0 && (int)b2 <= a)) continue;
                             const float ex = px[b2] - ax, ey = py[b2] - ay;
                             if (!(ex * ex + ey * ey > rr2)) j++;
                         }
                     }
+                    r = rbase + j;
+                    slot = sbase + j;
                     // warm start: impulse of the same pair in the previous substep (b2Contact::Update id match)
-                    float acc = 0.0f;
-                    bool found = false;
-                    for (int sl = 0; sl < (int)wsCnt[a] && sl < S; ++sl) {
-                        const size_t idx = ((size_t)e * S + sl) * N + a;
-                        if (g.ws_key[idx] == (unsigned)b) { acc = g.ws_acc[idx]; found = true; break; }
-                    }
-                    if (!found) {
-                        for (int sl = 0; sl < (int)wsCnt[b] && sl < S; ++sl) {
-                            const size_t idx = ((size_t)e * S + sl) * N + b;
-                            if (g.ws_key[idx] == (unsigned)a) { acc = g.ws_acc[idx]; break; }
-                        }
-                    }
-                    int slot = nslot + j;
-                    if (slot >= S) { slot = 255; atomicOr(&misc[M_STATUS], 2u); }
-                    int r = rbase + j;
-                    if (r > 255) { r = 255; atomicOr(&misc[M_STATUS], 4u); }
-                    const unsigned c = atomicAdd(&misc[M_NCON], 1u);
-                    if (c >= (unsigned)p.cap) { atomicOr(&misc[M_STATUS], 1u); continue; }
-                    ca[c] = (unsigned short)a; cb[c] = (unsigned short)b;
-                    ccls[c] = (unsigned char)cls; crank[c] = (unsigned char)r; cslot[c] = (unsigned char)slot;
-                    cacc[c] = acc;
+                    acc = ws_find(a, b);
+                    if (acc < 0.0f) acc = ws_find((int)b, (unsigned)a);
                     // island hooking: larger root goes under the smaller one
                     unsigned ra = a, rb = b;
                     for (;;) {
@@ -448,282 +569,485 @@ __global__ void __launch_bounds__(256, 2) kb_step_kernel(const Params p) {
                         if (atomicCAS(&parent[ra], ra, rb) == ra) break;
                     }
                 }
-                nslot += nk;
+                if (acc < 0.0f) acc = 0.0f;
+                if (slot >= S) slot = 255;
+                if (r > 255) { r = 255; atomicOr(&misc[M_STATUS], 4u); }
+                sInfo[c] = (unsigned)cls | ((unsigned)r << 8) | ((unsigned)slot << 16);
+                sAcc[c] = acc;
             }
-            // walls: b2CollideEdgeAndCircle (region AB) against the chain loop of kilobots_env.py:48-51
-            int wrank = 0;
-#pragma unroll
-            for (int wl = 0; wl < 4; ++wl) {
-                float dist, nx, ny;
-                wall_geom(p, wl, ax, ay, dist, nx, ny);
-                if (dist * dist > rw2) continue;
-                float acc = 0.0f;
-                for (int sl = 0; sl < (int)wsCnt[a] && sl < S; ++sl) {
-                    const size_t idx = ((size_t)e * S + sl) * N + a;
-                    if (g.ws_key[idx] == KEY_WALL + (unsigned)wl) { acc = g.ws_acc[idx]; break; }
-                }
-                int slot = nslot;
-                if (slot >= S) { slot = 255; atomicOr(&misc[M_STATUS], 2u); }
-                nslot++;
-                const int r = wrank++;
-                const unsigned c = atomicAdd(&misc[M_NCON], 1u);
-                if (c >= (unsigned)p.cap) { atomicOr(&misc[M_STATUS], 1u); continue; }
-                ca[c] = (unsigned short)(WALL_CODE + wl); cb[c] = (unsigned short)a;
-                // bit 7: the centre is outside the wall line, so the manifold normal points outwards
-                ccls[c] = (unsigned char)(CLS_WALL | (dist < 0.0f ? 0x80 : 0)); crank[c] = (unsigned char)r; cslot[c] = (unsigned char)slot;
-                cacc[c] = acc;
-            }
-            wsCntNew[a] = (unsigned char)(nslot < S ? nslot : S);
-        }
+        };
+        if (big) label_pass(gPair, gInfo, gAcc); else label_pass(lPair, lInfo, lAcc);
         __syncthreads();
         KB_STAMP(2);
-        const int ncon = min((int)misc[M_NCON], p.cap);
 
-        // ---- islands: flatten roots; empty the grid for the next substep ----
+        // ---- islands: flatten roots; empty the grid for the next substep; offsets of the new ws list ----
         for (int b = tid; b < N; b += nt) {
             unsigned r = b;
             while (true) { unsigned t = ((volatile unsigned *)parent)[r]; if (t == r) break; r = t; }
             parent[b] = r;   // only ever replaces an ancestor by an older ancestor: concurrent walks stay valid
             islCnt[b] = 0;
             head[cellOf[b]] = EMPTY32;
-            active[b] = 1; active[N + b] = 0;
+            active[b] = 1; active[NP + b] = 0;
         }
-        __syncthreads();
-        for (int c = tid; c < ncon; c += nt) {
-            const unsigned root = parent[cb[c]];
-            const unsigned n = atomicAdd(&islCnt[root], 1u) + 1u;
-            if (n > (unsigned)GIANT_ISLAND) atomicMax(&misc[M_MAXISL], n);
-        }
-        __syncthreads();
-        // coop: one island is so large that a single wave would serialise the env -> whole-workgroup sweeps
-        const bool coop = (misc[M_MAXISL] > (unsigned)GIANT_ISLAND) || nw == 1;
-        const int W = coop ? 1 : nw;
-        for (int c = tid; c < ncon; c += nt) {
-            const unsigned root = parent[cb[c]];
-            const int w = coop ? 0 : (int)(root % (unsigned)nw);
-            const int cls = ccls[c] & 0x7F, r = crank[c];
-            const int bk = (w * NUM_CLS + cls) * RK + (r < RK - 1 ? r : RK - 1);
-            cbk[c] = (unsigned short)bk;
-            atomicAdd(&bkStart[bk], 1u);
-            if (r >= RK - 1) atomicMax(&bkMaxRank[w * NUM_CLS + cls], (unsigned)r);
-        }
-        __syncthreads();
-        // exclusive scan of the bucket counts (<= 640 entries) by wave 0
-        if (wave == 0) {
-            const int nb = W * BK_PER_WAVE;
-            const int chunk = (nb + 63) / 64;
-            const int s0 = lane * chunk, e0 = min(nb, s0 + chunk);
-            unsigned sum = 0;
-            for (int i = s0; i < e0; ++i) sum += bkStart[i];
-            unsigned incl = sum;
-            for (int d = 1; d < 64; d <<= 1) {
-                unsigned t = __shfl_up(incl, d);
-                if (lane >= d) incl += t;
+        const unsigned newTotal = block_scan_u8(wsCntNew, newOff, NP, wsum);   // (barriers inside)
+        const bool newInLds = newTotal <= (unsigned)p.capL;
+        // per contact: island size (giant islands force the cooperative sweep) and contacts per wave
+        auto census = [&](const unsigned *sPair) __attribute__((always_inline)) {
+            for (int c = tid; c < ncon; c += nt) {
+                const unsigned root = parent[sPair[c] >> 16];
+                const unsigned n = atomicAdd(&islCnt[root], 1u) + 1u;
+                if (n > (unsigned)GIANT_ISLAND) atomicMax(&misc[M_MAXISL], n);
+                atomicAdd(&misc[M_WCNT + (root % (unsigned)nw)], 1u);
             }
-            unsigned run = incl - sum;
-            for (int i = s0; i < e0; ++i) { unsigned v = bkStart[i]; bkStart[i] = run; run += v; }
-            if (lane == 63) bkStart[nb] = incl;
-        }
+        };
+        if (big) census(gPair); else census(lPair);
         __syncthreads();
-        for (int c = tid; c < ncon; c += nt) {
-            const int bk = cbk[c];
-            const unsigned pos = bkStart[bk] + atomicAdd(&bkFill[bk], 1u);
-            order[pos] = (unsigned short)c;
-        }
-        // every (virtual) wave compacts the list of its non-empty buckets, in key order
-        if (wave < W) {
-            const int base = wave * BK_PER_WAVE;
-            const bool ne = lane < BK_PER_WAVE && bkStart[base + lane + 1] > bkStart[base + lane];
-            const unsigned long long m = __ballot(ne);
-            if (ne) bkList[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(base + lane);
-            if (lane == 0) nList[wave] = (unsigned char)__popcll(m);
-        }
-        __syncthreads();
+        unsigned maxw = 0;
+        for (int w = 0; w < nw; ++w) maxw = max(maxw, misc[M_WCNT + w]);
+        // solver selection (block-uniform):
+        //   coop: one island is so large that a single wave would serialise the env
+        //   reg : every wave can hold its contacts in registers (<= KREG per lane) -> no contact arrays in the sweeps
+        //   list: per-wave sweeps over the staged contact arrays
+        const bool coop = misc[M_MAXISL] > (unsigned)GIANT_ISLAND || nw == 1 || p.solver_mode == 2 || p.solver_mode == 4;
+        const bool reg = !coop && !big && maxw <= 64u * KREG && p.solver_mode == 0;
+        // ---- counting sort of the contacts by (wave, class, rank bucket): `order` lists every (virtual) wave's
+        //      contacts key by key; bkList = its non-empty keys in canonical order ----
+        auto bucket_sort = [&](const unsigned *sPair, const unsigned *sInfo, unsigned short *cbk,
+                               unsigned short *order) __attribute__((always_inline)) {
+            const int W = coop ? 1 : nw;
+            for (int k = tid; k < W * BK_PER_WAVE; k += nt) { bkStart[k] = 0; bkFill[k] = 0; }
+            for (int k = tid; k < W * NUM_CLS; k += nt) bkMaxRank[k] = 0;
+            if (tid == 0) bkStart[W * BK_PER_WAVE] = 0;
+            __syncthreads();
+            for (int c = tid; c < ncon; c += nt) {
+                const unsigned root = parent[sPair[c] >> 16];
+                const int w = coop ? 0 : (int)(root % (unsigned)nw);
+                const unsigned inf = sInfo[c];
+                const int cls = inf & 0x7F, r = (inf >> 8) & 0xFF;
+                const int bk = (w * NUM_CLS + cls) * RK + (r < RK - 1 ? r : RK - 1);
+                cbk[c] = (unsigned short)bk;
+                atomicAdd(&bkStart[bk], 1u);
+                if (r >= RK - 1) atomicMax(&bkMaxRank[w * NUM_CLS + cls], (unsigned)r);
+            }
+            __syncthreads();
+            if (wave == 0) {   // exclusive scan of the bucket counts (<= 160 entries)
+                const int nb = W * BK_PER_WAVE;
+                const int chunk = (nb + 63) / 64;
+                const int s0 = lane * chunk, e0 = min(nb, s0 + chunk);
+                unsigned sum = 0;
+                for (int i = s0; i < e0; ++i) sum += bkStart[i];
+                unsigned incl = sum;
+                for (int d = 1; d < 64; d <<= 1) {
+                    unsigned t = __shfl_up(incl, d);
+                    if (lane >= d) incl += t;
+                }
+                unsigned run = incl - sum;
+                for (int i = s0; i < e0; ++i) { unsigned v = bkStart[i]; bkStart[i] = run; run += v; }
+                if (lane == 63) bkStart[nb] = incl;
+            }
+            __syncthreads();
+            for (int c = tid; c < ncon; c += nt) {
+                const int bk = cbk[c];
+                order[bkStart[bk] + atomicAdd(&bkFill[bk], 1u)] = (unsigned short)c;
+            }
+            if (wave < W) {   // every (virtual) wave compacts the list of its non-empty buckets, in key order
+                const int base = wave * BK_PER_WAVE;
+                const bool ne = lane < BK_PER_WAVE && bkStart[base + lane + 1] > bkStart[base + lane];
+                const unsigned long long m = __ballot(ne);
+                if (ne) bkList[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(base + lane);
+                if (lane == 0) nList[wave] = (unsigned char)__popcll(m);
+            }
+            __syncthreads();
+        };
+        if (big) bucket_sort(gPair, gInfo, gCbk, gOrder); else bucket_sort(lPair, lInfo, lCbk, lOrder);
         KB_STAMP(3);
 
-        // ---- solver ----
-        // A "round" = all contacts of one key owned by this (virtual) wave.  coop: the workgroup is one
-        // virtual wave and rounds are separated by s_barrier; otherwise each wave runs alone.
-        const int myw = coop ? 0 : wave;
-        const int lid = coop ? tid : lane;
-        const int stride = coop ? nt : 64;
-        const int nl = nList[myw];
+        if (reg) {
+            // =========================== register-resident solver ===========================
+            // wave w owns the contacts of the islands with root % nw == w; lane l holds contacts l, l+64, ...
+            const unsigned mybase = bkStart[wave * BK_PER_WAVE];
+            const unsigned mycnt = bkStart[(wave + 1) * BK_PER_WAVE] - mybase;
+            int ra[KREG], rb[KREG], rkey[KREG], rrank[KREG], rslot[KREG], risl[KREG];
+            float racc[KREG], rnx[KREG], rny[KREG];
+            bool rvalid[KREG], rflip[KREG];
+            unsigned mlo = 0, mhi = 0;
+#pragma unroll
+            for (int j = 0; j < KREG; ++j) {
+                const unsigned idx = lane + 64u * j;
+                rvalid[j] = idx < mycnt;
+                ra[j] = 0; rb[j] = 0; rkey[j] = 0; rrank[j] = 0; rslot[j] = 255; risl[j] = 0;
+                racc[j] = 0.0f; rnx[j] = 1.0f; rny[j] = 0.0f; rflip[j] = false;
+                if (rvalid[j]) {
+                    const int c = lOrder[mybase + idx];
+                    const unsigned pr = lPair[c], inf = lInfo[c];
+                    const int a = pr & 0xFFFF, b = pr >> 16;
+                    const int cls = inf & 0x7F, r = (inf >> 8) & 0xFF;
+                    ra[j] = a; rb[j] = b; rrank[j] = r; rslot[j] = (inf >> 16) & 0xFF; racc[j] = lAcc[c];
+                    rflip[j] = (inf & 0x80) != 0;
+                    risl[j] = (int)parent[b];
+                    const int key = cls * RK + (r < RK - 1 ? r : RK - 1);
+                    rkey[j] = key;
+                    if (key < 32) mlo |= 1u << key; else mhi |= 1u << (key - 32);
+                    // velocity-phase normal from the start-of-step positions (b2WorldManifold::Initialize)
+                    if (a >= WALL_CODE) {
+                        float dist, nx, ny;
+                        wall_geom(p, a - WALL_CODE, px[b], py[b], dist, nx, ny);
+                        if (rflip[j]) { nx = -nx; ny = -ny; }
+                        rnx[j] = nx; rny[j] = ny;
+                    } else {
+                        const float dx = px[b] - px[a], dy = py[b] - py[a];
+                        const float dd = dx * dx + dy * dy;
+                        if (dd > B2_EPSILON * B2_EPSILON) {
+                            const float len = sqrtf(dd);
+                            const float inv = 1.0f / len;
+                            rnx[j] = dx * inv; rny[j] = dy * inv;
+                        }
+                    }
+                }
+            }
+            // keys present in this wave (wave-uniform 40-bit mask)
+            for (int d = 32; d >= 1; d >>= 1) { mlo |= __shfl_xor(mlo, d); mhi |= __shfl_xor(mhi, d); }
+            mlo = __builtin_amdgcn_readfirstlane(mlo); mhi = __builtin_amdgcn_readfirstlane(mhi);
+            const unsigned long long keymask = ((unsigned long long)mhi << 32) | mlo;
+#ifdef KB_PROFILE
+            if (tid == 0) { prof_acc[8] += __popcll(keymask); prof_acc[9] += mycnt; prof_acc[11] += 1; }
+#endif
+
+#define KB_REG_ROUNDS(...)                                                                          \
+            for (unsigned long long m_ = keymask; m_; m_ &= m_ - 1) {                               \
+                const int key_ = __builtin_ctzll(m_);                                               \
+                if ((key_ % RK) < RK - 1) {                                                         \
+                    _Pragma("unroll") for (int j = 0; j < KREG; ++j)                                \
+                        if (rvalid[j] && rkey[j] == key_) { __VA_ARGS__ }                           \
+                    wave_sync();                                                                    \
+                } else {                                                                            \
+                    const int maxr_ = (int)bkMaxRank[wave * NUM_CLS + key_ / RK];                   \
+                    for (int r_ = RK - 1; r_ <= maxr_; ++r_) {                                      \
+                        _Pragma("unroll") for (int j = 0; j < KREG; ++j)                            \
+                            if (rvalid[j] && rkey[j] == key_ && rrank[j] == r_) { __VA_ARGS__ }     \
+                        wave_sync();                                                                \
+                    }                                                                               \
+                }                                                                                   \
+            }
+
+            // b2ContactSolver::WarmStart
+            KB_REG_ROUNDS({
+                const int a = ra[j], b = rb[j];
+                const float Px = racc[j] * rnx[j], Py = racc[j] * rny[j];
+                if (a < WALL_CODE) { vx[a] -= p.im_bot * Px; vy[a] -= p.im_bot * Py; }
+                vx[b] += p.im_bot * Px; vy[b] += p.im_bot * Py;
+            })
+            // SolveVelocityConstraints: friction 0, restitution 0, one manifold point
+            for (int it = 0; it < p.vel_iters; ++it) {
+                KB_REG_ROUNDS({
+                    const int a = ra[j], b = rb[j];
+                    const float nx = rnx[j], ny = rny[j];
+                    float vax = 0.0f, vay = 0.0f, ima = 0.0f;
+                    if (a < WALL_CODE) { vax = vx[a]; vay = vy[a]; ima = p.im_bot; }
+                    const float vbx = vx[b], vby = vy[b];
+                    const float dvx = vbx - vax, dvy = vby - vay;
+                    const float vn = dvx * nx + dvy * ny;
+                    const float nm = a < WALL_CODE ? nm_bb : nm_wb;
+                    float lambda = -(nm * vn);
+                    const float accOld = racc[j];
+                    const float newimp = fmaxf(accOld + lambda, 0.0f);
+                    lambda = newimp - accOld;
+                    racc[j] = newimp;
+                    const float Px = lambda * nx, Py = lambda * ny;
+                    if (a < WALL_CODE) { vx[a] = vax - ima * Px; vy[a] = vay - ima * Py; }
+                    vx[b] = vbx + p.im_bot * Px; vy[b] = vby + p.im_bot * Py;
+                })
+            }
+            __syncthreads();
+            KB_STAMP(4);
+            // StoreImpulses -> packed warm-start list of the next substep (LDS image and/or global)
+            const bool last = sub == p.n_substeps - 1;
+#pragma unroll
+            for (int j = 0; j < KREG; ++j) {
+                if (!rvalid[j] || rslot[j] == 255) continue;
+                const int a = ra[j], b = rb[j];
+                const int owner = a < WALL_CODE ? a : b;
+                const unsigned key16 = a < WALL_CODE ? (unsigned)b : (unsigned)a;
+                const unsigned pos = (unsigned)newOff[owner] + (unsigned)rslot[j];
+                if (pos >= (unsigned)p.cap) continue;
+                if (newInLds) { oldKey[pos] = (unsigned short)key16; oldAcc[pos] = racc[j]; }
+                if (last || !newInLds) {
+                    g.ws_key[wo + pos] = key16 >= (unsigned)WALL_CODE ? KEY_WALL + (key16 - WALL_CODE) : key16;
+                    g.ws_acc[wo + pos] = racc[j];
+                }
+            }
+            // integrate positions (b2Island::Solve)
+#pragma unroll
+            for (int q = 0; q < BPT; ++q) {
+                const int b = tid + q * nt;
+                if (b >= N) continue;
+                float vxx = vx[b], vyy = vy[b], ww = bw[q];
+                const float tx = h * vxx, ty = h * vyy;
+                if (tx * tx + ty * ty > B2_MAX_TRANSLATION_SQ) {
+                    const float ratio = B2_MAX_TRANSLATION / sqrtf(tx * tx + ty * ty);
+                    vxx *= ratio; vyy *= ratio;
+                }
+                const float rot = h * ww;
+                if (rot * rot > B2_MAX_ROTATION_SQ) {
+                    const float ratio = B2_MAX_ROTATION / fabsf(rot);
+                    ww *= ratio;
+                }
+                px[b] += h * vxx; py[b] += h * vyy;
+                th[q] += h * ww;
+            }
+            __syncthreads();
+            KB_STAMP(5);
+            // SolvePositionConstraints; an island stops once its minSeparation >= -3 slop
+            for (int it = 0; it < p.pos_iters; ++it) {
+                unsigned char *act = active + (it & 1) * NP, *nxt = active + ((it + 1) & 1) * NP;
+                bool viol = false;
+                KB_REG_ROUNDS({
+                    const int a = ra[j], b = rb[j];
+                    const int isl = risl[j];
+                    if (act[isl]) {
+                        float nx, ny, sep, ima = 0.0f;
+                        const float bx = px[b], by = py[b];
+                        float axx = 0.0f, ayy = 0.0f;
+                        if (a >= WALL_CODE) {
+                            float dist, wx, wy;
+                            wall_geom(p, a - WALL_CODE, bx, by, dist, wx, wy);
+                            nx = rflip[j] ? -wx : wx; ny = rflip[j] ? -wy : wy;   // manifold normal fixed at detection
+                            const float along = rflip[j] ? -dist : dist;
+                            sep = along - B2_POLYGON_RADIUS - p.r_bot;
+                        } else {
+                            axx = px[a]; ayy = py[a]; ima = p.im_bot;
+                            const float dx = bx - axx, dy = by - ayy;
+                            const float len = sqrtf(dx * dx + dy * dy);
+                            nx = dx; ny = dy;
+                            if (!(len < B2_EPSILON)) { const float inv = 1.0f / len; nx = dx * inv; ny = dy * inv; }
+                            sep = (dx * nx + dy * ny) - p.r_bot - p.r_bot;
+                        }
+                        if (sep < -3.0f * B2_LINEAR_SLOP) { nxt[isl] = 1; viol = true; }
+                        const float C = kb_clampf(B2_BAUMGARTE * (sep + B2_LINEAR_SLOP), -B2_MAX_LINEAR_CORRECTION, 0.0f);
+                        const float K = ima + p.im_bot;
+                        const float imp = K > 0.0f ? -C / K : 0.0f;
+                        const float Px = imp * nx, Py = imp * ny;
+                        if (a < WALL_CODE) { px[a] = axx - ima * Px; py[a] = ayy - ima * Py; }
+                        px[b] = bx + p.im_bot * Px; py[b] = by + p.im_bot * Py;
+                    }
+                })
+#ifdef KB_PROFILE
+                if (tid == 0) prof_acc[10] += 1;
+#endif
+                if (!__any(viol)) break;
+                // the flags the next sweep sets must start cleared (only this wave's islands)
+#pragma unroll
+                for (int j = 0; j < KREG; ++j) if (rvalid[j]) act[risl[j]] = 0;
+                wave_sync();
+            }
+#undef KB_REG_ROUNDS
+        } else {
+            // =========================== list solver (staged contact arrays) ===========================
+            auto solve_list = [&](unsigned *sPair, unsigned *sInfo, float *sAcc, unsigned short *cbk,
+                                  unsigned short *order) __attribute__((always_inline)) {
+                // a "round" = all contacts of one key owned by this (virtual) wave.  coop: the workgroup is one
+                // virtual wave and rounds are separated by s_barrier; otherwise every wave runs alone.
+                const int myw = coop ? 0 : wave;
+                const int lid = coop ? tid : lane;
+                const int stride = coop ? nt : 64;
+                const int nl = nList[myw];
 #define KB_ROUND_SYNC() do { if (coop) __syncthreads(); else wave_sync(); } while (0)
 #define KB_FOR_ROUNDS(...)                                                                          \
-        for (int li = 0; li < nl; ++li) {                                                           \
-            const int bk = bkList[myw * BK_PER_WAVE + li];                                          \
-            const int s_ = (int)bkStart[bk], e_ = (int)bkStart[bk + 1];                             \
-            if ((bk % RK) < RK - 1) {                                                               \
-                for (int i_ = s_ + lid; i_ < e_; i_ += stride) { const int c = order[i_]; __VA_ARGS__ }    \
-                KB_ROUND_SYNC();                                                                    \
-            } else {                                                                                \
-                const int maxr_ = (int)bkMaxRank[bk / RK];                                          \
-                for (int r_ = RK - 1; r_ <= maxr_; ++r_) {                                          \
-                    for (int i_ = s_ + lid; i_ < e_; i_ += stride) {                                \
-                        const int c = order[i_];                                                    \
-                        if ((int)crank[c] == r_) { __VA_ARGS__ }                                           \
+                for (int li = 0; li < nl; ++li) {                                                   \
+                    const int bk = bkList[myw * BK_PER_WAVE + li];                                  \
+                    const int s_ = (int)bkStart[bk], e_ = (int)bkStart[bk + 1];                     \
+                    if ((bk % RK) < RK - 1) {                                                       \
+                        for (int i_ = s_ + lid; i_ < e_; i_ += stride) { const int c = order[i_]; __VA_ARGS__ } \
+                        KB_ROUND_SYNC();                                                            \
+                    } else {                                                                        \
+                        const int maxr_ = (int)bkMaxRank[bk / RK];                                  \
+                        for (int r_ = RK - 1; r_ <= maxr_; ++r_) {                                  \
+                            for (int i_ = s_ + lid; i_ < e_; i_ += stride) {                        \
+                                const int c = order[i_];                                            \
+                                if ((int)((sInfo[c] >> 8) & 0xFF) == r_) { __VA_ARGS__ }            \
+                            }                                                                       \
+                            KB_ROUND_SYNC();                                                        \
+                        }                                                                           \
                     }                                                                               \
-                    KB_ROUND_SYNC();                                                                \
-                }                                                                                   \
-            }                                                                                       \
-        }
-
-        // velocity-phase normal of contact c from the start-of-step positions (b2WorldManifold::Initialize)
-#define KB_VEL_NORMAL(a, b, nx, ny)                                                                 \
-        float nx, ny;                                                                               \
-        if (a >= WALL_CODE) {                                                                       \
-            float dist_;                                                                            \
-            wall_geom(p, a - WALL_CODE, px[b], py[b], dist_, nx, ny);                               \
-            if (dist_ < 0.0f) { nx = -nx; ny = -ny; }                                               \
-        } else {                                                                                    \
-            const float dx_ = px[b] - px[a], dy_ = py[b] - py[a];                                   \
-            const float dd_ = dx_ * dx_ + dy_ * dy_;                                                \
-            nx = 1.0f; ny = 0.0f;                                                                   \
-            if (dd_ > B2_EPSILON * B2_EPSILON) {                                                    \
-                const float len_ = sqrtf(dd_);                                                      \
-                const float inv_ = 1.0f / len_;                                                     \
-                nx = dx_ * inv_; ny = dy_ * inv_;                                                   \
-            }                                                                                       \
-        }
-
-        // b2ContactSolver::WarmStart
-        KB_FOR_ROUNDS({
-            const int a = ca[c], b = cb[c];
-            KB_VEL_NORMAL(a, b, nx, ny)
-            const float acc = cacc[c];
-            const float Px = acc * nx, Py = acc * ny;
-            if (a < WALL_CODE) { vx[a] -= p.im_bot * Px; vy[a] -= p.im_bot * Py; }
-            vx[b] += p.im_bot * Px; vy[b] += p.im_bot * Py;
-        })
-        // SolveVelocityConstraints: friction 0, restitution 0, one manifold point
-        for (int it = 0; it < p.vel_iters; ++it) {
-            KB_FOR_ROUNDS({
-                const int a = ca[c], b = cb[c];
-                KB_VEL_NORMAL(a, b, nx, ny)
-                float vax = 0.0f, vay = 0.0f, ima = 0.0f;
-                if (a < WALL_CODE) { vax = vx[a]; vay = vy[a]; ima = p.im_bot; }
-                const float vbx = vx[b], vby = vy[b];
-                const float dvx = vbx - vax, dvy = vby - vay;
-                const float vn = dvx * nx + dvy * ny;
-                const float k = ima + p.im_bot;
-                const float nm = k > 0.0f ? 1.0f / k : 0.0f;
-                float lambda = -(nm * vn);
-                const float accOld = cacc[c];
-                const float newimp = fmaxf(accOld + lambda, 0.0f);
-                lambda = newimp - accOld;
-                cacc[c] = newimp;
-                const float Px = lambda * nx, Py = lambda * ny;
-                if (a < WALL_CODE) { vx[a] = vax - ima * Px; vy[a] = vay - ima * Py; }
-                vx[b] = vbx + p.im_bot * Px; vy[b] = vby + p.im_bot * Py;
-            })
-        }
-        __syncthreads();
-        KB_STAMP(4);
-        // ---- StoreImpulses -> warm-start cache of the next substep ----
-        for (int c = tid; c < ncon; c += nt) {
-            const int sl = cslot[c];
-            if (sl == 255) continue;
-            const int a = ca[c], b = cb[c];
-            const int owner = a < WALL_CODE ? a : b;
-            const unsigned key = a < WALL_CODE ? (unsigned)b : KEY_WALL + (unsigned)(a - WALL_CODE);
-            const size_t idx = ((size_t)e * S + sl) * N + owner;
-            g.ws_key[idx] = key; g.ws_acc[idx] = cacc[c];
-        }
-        // ---- integrate positions (b2Island::Solve) ----
-#pragma unroll
-        for (int q = 0; q < BPT; ++q) {
-            const int b = tid + q * nt;
-            if (b >= N) continue;
-            g.ws_cnt[o + b] = wsCntNew[b];
-            float vxx = vx[b], vyy = vy[b], ww = bw[q];
-            const float tx = h * vxx, ty = h * vyy;
-            if (tx * tx + ty * ty > B2_MAX_TRANSLATION_SQ) {
-                const float ratio = B2_MAX_TRANSLATION / sqrtf(tx * tx + ty * ty);
-                vxx *= ratio; vyy *= ratio;
-            }
-            const float rot = h * ww;
-            if (rot * rot > B2_MAX_ROTATION_SQ) {
-                const float ratio = B2_MAX_ROTATION / fabsf(rot);
-                ww *= ratio;
-            }
-            px[b] += h * vxx; py[b] += h * vyy;
-            th[q] += h * ww;
-        }
-        __syncthreads();
-        KB_STAMP(5);
-        // ---- SolvePositionConstraints; an island stops once its minSeparation >= -3 slop ----
-        for (int it = 0; it < p.pos_iters; ++it) {
-            unsigned char *act = active + (it & 1) * N, *nxt = active + ((it + 1) & 1) * N;
-            bool viol = false;
-            KB_FOR_ROUNDS({
-                const int a = ca[c], b = cb[c];
-                const int isl = (int)parent[b];
-                if (act[isl]) {
-                    float nx, ny, sep, ima = 0.0f;
-                    const float bx = px[b], by = py[b];
-                    float axx = 0.0f, ayy = 0.0f;
-                    if (a >= WALL_CODE) {
-                        float dist, wx, wy;
-                        wall_geom(p, a - WALL_CODE, bx, by, dist, wx, wy);
-                        // manifold normal fixed at detection: flipped iff the centre was outside then
-                        const bool flipped = (ccls[c] & 0x80) != 0;
-                        nx = flipped ? -wx : wx; ny = flipped ? -wy : wy;
-                        const float along = flipped ? -dist : dist;
-                        sep = along - B2_POLYGON_RADIUS - p.r_bot;
-                    } else {
-                        axx = px[a]; ayy = py[a]; ima = p.im_bot;
-                        const float dx = bx - axx, dy = by - ayy;
-                        const float len = sqrtf(dx * dx + dy * dy);
-                        nx = dx; ny = dy;
-                        if (!(len < B2_EPSILON)) { const float inv = 1.0f / len; nx = dx * inv; ny = dy * inv; }
-                        sep = (dx * nx + dy * ny) - p.r_bot - p.r_bot;
-                    }
-                    if (sep < -3.0f * B2_LINEAR_SLOP) { nxt[isl] = 1; viol = true; }
-                    const float C = kb_clampf(B2_BAUMGARTE * (sep + B2_LINEAR_SLOP), -B2_MAX_LINEAR_CORRECTION, 0.0f);
-                    const float K = ima + p.im_bot;
-                    const float imp = K > 0.0f ? -C / K : 0.0f;
-                    const float Px = imp * nx, Py = imp * ny;
-                    if (a < WALL_CODE) { px[a] = axx - ima * Px; py[a] = ayy - ima * Py; }
-                    px[b] = bx + p.im_bot * Px; py[b] = by + p.im_bot * Py;
                 }
-            })
-            bool any;
-            if (coop) {
-                if (viol) misc[M_ANY] = 1u;
+#define KB_VEL_NORMAL(a, b, flip, nx, ny)                                                           \
+                float nx, ny;                                                                       \
+                if (a >= WALL_CODE) {                                                               \
+                    float dist_;                                                                    \
+                    wall_geom(p, a - WALL_CODE, px[b], py[b], dist_, nx, ny);                       \
+                    if (flip) { nx = -nx; ny = -ny; }                                               \
+                } else {                                                                            \
+                    const float dx_ = px[b] - px[a], dy_ = py[b] - py[a];                           \
+                    const float dd_ = dx_ * dx_ + dy_ * dy_;                                        \
+                    nx = 1.0f; ny = 0.0f;                                                           \
+                    if (dd_ > B2_EPSILON * B2_EPSILON) {                                            \
+                        const float len_ = sqrtf(dd_);                                              \
+                        const float inv_ = 1.0f / len_;                                             \
+                        nx = dx_ * inv_; ny = dy_ * inv_;                                           \
+                    }                                                                               \
+                }
+                // b2ContactSolver::WarmStart
+                KB_FOR_ROUNDS({
+                    const unsigned pr = sPair[c];
+                    const int a = pr & 0xFFFF, b = pr >> 16;
+                    const bool flip = (sInfo[c] & 0x80) != 0;
+                    KB_VEL_NORMAL(a, b, flip, nx, ny)
+                    const float acc = sAcc[c];
+                    const float Px = acc * nx, Py = acc * ny;
+                    if (a < WALL_CODE) { vx[a] -= p.im_bot * Px; vy[a] -= p.im_bot * Py; }
+                    vx[b] += p.im_bot * Px; vy[b] += p.im_bot * Py;
+                })
+                // SolveVelocityConstraints
+                for (int it = 0; it < p.vel_iters; ++it) {
+                    KB_FOR_ROUNDS({
+                        const unsigned pr = sPair[c];
+                        const int a = pr & 0xFFFF, b = pr >> 16;
+                        const bool flip = (sInfo[c] & 0x80) != 0;
+                        KB_VEL_NORMAL(a, b, flip, nx, ny)
+                        float vax = 0.0f, vay = 0.0f, ima = 0.0f;
+                        if (a < WALL_CODE) { vax = vx[a]; vay = vy[a]; ima = p.im_bot; }
+                        const float vbx = vx[b], vby = vy[b];
+                        const float dvx = vbx - vax, dvy = vby - vay;
+                        const float vn = dvx * nx + dvy * ny;
+                        const float nm = a < WALL_CODE ? nm_bb : nm_wb;
+                        float lambda = -(nm * vn);
+                        const float accOld = sAcc[c];
+                        const float newimp = fmaxf(accOld + lambda, 0.0f);
+                        lambda = newimp - accOld;
+                        sAcc[c] = newimp;
+                        const float Px = lambda * nx, Py = lambda * ny;
+                        if (a < WALL_CODE) { vx[a] = vax - ima * Px; vy[a] = vay - ima * Py; }
+                        vx[b] = vbx + p.im_bot * Px; vy[b] = vby + p.im_bot * Py;
+                    })
+                }
                 __syncthreads();
-                any = misc[M_ANY] != 0u;
+                KB_STAMP(4);
+                // StoreImpulses -> packed warm-start list of the next substep
+                const bool last = sub == p.n_substeps - 1;
+                for (int c = tid; c < ncon; c += nt) {
+                    const unsigned inf = sInfo[c];
+                    const int sl = (inf >> 16) & 0xFF;
+                    if (sl == 255) continue;
+                    const unsigned pr = sPair[c];
+                    const int a = pr & 0xFFFF, b = pr >> 16;
+                    const int owner = a < WALL_CODE ? a : b;
+                    const unsigned key16 = a < WALL_CODE ? (unsigned)b : (unsigned)a;
+                    const unsigned pos = (unsigned)newOff[owner] + (unsigned)sl;
+                    if (pos >= (unsigned)p.cap) continue;
+                    const float acc = sAcc[c];
+                    if (newInLds) { oldKey[pos] = (unsigned short)key16; oldAcc[pos] = acc; }
+                    if (last || !newInLds) {
+                        g.ws_key[wo + pos] = key16 >= (unsigned)WALL_CODE ? KEY_WALL + (key16 - WALL_CODE) : key16;
+                        g.ws_acc[wo + pos] = acc;
+                    }
+                }
+                // integrate positions (b2Island::Solve)
+#pragma unroll
+                for (int q = 0; q < BPT; ++q) {
+                    const int b = tid + q * nt;
+                    if (b >= N) continue;
+                    float vxx = vx[b], vyy = vy[b], ww = bw[q];
+                    const float tx = h * vxx, ty = h * vyy;
+                    if (tx * tx + ty * ty > B2_MAX_TRANSLATION_SQ) {
+                        const float ratio = B2_MAX_TRANSLATION / sqrtf(tx * tx + ty * ty);
+                        vxx *= ratio; vyy *= ratio;
+                    }
+                    const float rot = h * ww;
+                    if (rot * rot > B2_MAX_ROTATION_SQ) {
+                        const float ratio = B2_MAX_ROTATION / fabsf(rot);
+                        ww *= ratio;
+                    }
+                    px[b] += h * vxx; py[b] += h * vyy;
+                    th[q] += h * ww;
+                }
                 __syncthreads();
-                if (tid == 0) misc[M_ANY] = 0u;
-            } else {
-                any = __any(viol);
-            }
-            if (!any) break;
-            // the flags the next sweep sets must start cleared (only islands of this virtual wave)
-            if (myw < W) {
-                const int s_ = (int)bkStart[myw * BK_PER_WAVE], e_ = (int)bkStart[(myw + 1) * BK_PER_WAVE];
-                for (int i_ = s_ + lid; i_ < e_; i_ += stride) act[parent[cb[order[i_]]]] = 0;
-            }
-            KB_ROUND_SYNC();
-        }
-        __syncthreads();
-        KB_STAMP(6);
+                KB_STAMP(5);
+                // SolvePositionConstraints; an island stops once its minSeparation >= -3 slop
+                for (int it = 0; it < p.pos_iters; ++it) {
+                    unsigned char *act = active + (it & 1) * NP, *nxt = active + ((it + 1) & 1) * NP;
+                    bool viol = false;
+                    KB_FOR_ROUNDS({
+                        const unsigned pr = sPair[c];
+                        const int a = pr & 0xFFFF, b = pr >> 16;
+                        const int isl = (int)parent[b];
+                        if (act[isl]) {
+                            float nx, ny, sep, ima = 0.0f;
+                            const float bx = px[b], by = py[b];
+                            float axx = 0.0f, ayy = 0.0f;
+                            if (a >= WALL_CODE) {
+                                float dist, wx, wy;
+                                wall_geom(p, a - WALL_CODE, bx, by, dist, wx, wy);
+                                const bool flipped = (sInfo[c] & 0x80) != 0;   // manifold normal fixed at detection
+                                nx = flipped ? -wx : wx; ny = flipped ? -wy : wy;
+                                const float along = flipped ? -dist : dist;
+                                sep = along - B2_POLYGON_RADIUS - p.r_bot;
+                            } else {
+                                axx = px[a]; ayy = py[a]; ima = p.im_bot;
+                                const float dx = bx - axx, dy = by - ayy;
+                                const float len = sqrtf(dx * dx + dy * dy);
+                                nx = dx; ny = dy;
+                                if (!(len < B2_EPSILON)) { const float inv = 1.0f / len; nx = dx * inv; ny = dy * inv; }
+                                sep = (dx * nx + dy * ny) - p.r_bot - p.r_bot;
+                            }
+                            if (sep < -3.0f * B2_LINEAR_SLOP) { nxt[isl] = 1; viol = true; }
+                            const float C = kb_clampf(B2_BAUMGARTE * (sep + B2_LINEAR_SLOP), -B2_MAX_LINEAR_CORRECTION, 0.0f);
+                            const float K = ima + p.im_bot;
+                            const float imp = K > 0.0f ? -C / K : 0.0f;
+                            const float Px = imp * nx, Py = imp * ny;
+                            if (a < WALL_CODE) { px[a] = axx - ima * Px; py[a] = ayy - ima * Py; }
+                            px[b] = bx + p.im_bot * Px; py[b] = by + p.im_bot * Py;
+                        }
+                    })
+                    bool any;
+                    if (coop) {
+                        if (viol) misc[M_ANY] = 1u;
+                        __syncthreads();
+                        any = misc[M_ANY] != 0u;
+                        __syncthreads();
+                        if (tid == 0) misc[M_ANY] = 0u;
+                    } else {
+                        any = __any(viol);
+                    }
+                    if (!any) break;
+                    // the flags the next sweep sets must start cleared (only islands of this virtual wave)
+                    {
+                        const int s_ = (int)bkStart[myw * BK_PER_WAVE], e_ = (int)bkStart[(myw + 1) * BK_PER_WAVE];
+                        for (int i_ = s_ + lid; i_ < e_; i_ += stride) act[parent[sPair[order[i_]] >> 16]] = 0;
+                    }
+                    KB_ROUND_SYNC();
+                }
 #undef KB_FOR_ROUNDS
 #undef KB_VEL_NORMAL
 #undef KB_ROUND_SYNC
+            };
+            if (big) solve_list(gPair, gInfo, gAcc, gCbk, gOrder); else solve_list(lPair, lInfo, lAcc, lCbk, lOrder);
+        }
+        __syncthreads();
+        // the new warm-start list becomes the old one
+        for (int b = tid; b < NP; b += nt) { wsCnt[b] = wsCntNew[b]; wsOff[b] = newOff[b]; }
+        oldInLds = newInLds;
+        oldTotal = newTotal;
+        __syncthreads();
+        KB_STAMP(6);
     }
 
     // ---- write back ----
 #pragma unroll
     for (int q = 0; q < BPT; ++q) {
         const int b = tid + q * nt;
-        if (b < N) { g.x[o + b] = px[b]; g.y[o + b] = py[b]; g.theta[o + b] = th[q]; }
+        if (b < N) {
+            g.x[o + b] = px[b]; g.y[o + b] = py[b]; g.theta[o + b] = th[q];
+            if (p.n_substeps > 0) g.ws_cnt[o + b] = wsCnt[b];
+            if (DRIVE_MODE == KB_DRIVE_ACCEL && p.n_substeps > 0 && drive) { g.v[o + b] = cv[q]; g.w[o + b] = cw[q]; }
+        }
     }
     if (tid == 0) {
-        if (p.light_type == KB_LIGHT_CIRCULAR && p.light_action && drive) { g.light_x[e] = lx; g.light_y[e] = ly; }
+        if (LIGHT_TYPE == KB_LIGHT_CIRCULAR && p.light_action && drive) { g.light_x[e] = lx; g.light_y[e] = ly; }
         if (misc[M_STATUS]) atomicOr(&g.status[e], (int)misc[M_STATUS]);
 #ifdef KB_PROFILE
         prof_acc[7] += clock64() - prof_t;
-        for (int k = 0; k < 8; ++k) g.status[p.E + 8 * e + k] += (int)(prof_acc[k] >> 4);   // units of 16 cycles
+        for (int k = 0; k < 8; ++k) g.status[p.E + 12 * e + k] += (int)(prof_acc[k] >> 4);   // units of 16 cycles
+        for (int k = 8; k < 12; ++k) g.status[p.E + 12 * e + k] += (int)prof_acc[k];
 #endif
     }
 }
@@ -768,6 +1092,7 @@ struct kb_sim {
     kb_config cfg;
     Params p;
     bool bound;
+    bool attr_set;
     int threads;
 };
 
@@ -788,6 +1113,7 @@ int kb_create(const kb_config *cfg, kb_sim **out) {
         cfg->light_type == KB_LIGHT_NONE)
         return fail(KB_EINVAL, "kb_create: phototaxis drive modes need a light");
     if (cfg->ws_slots < 1 || cfg->ws_slots > 64) return fail(KB_EINVAL, "kb_create: 1 <= ws_slots <= 64 required");
+    if (cfg->solver_mode < 0 || cfg->solver_mode > 4) return fail(KB_EINVAL, "kb_create: solver_mode must be 0..4");
     if (!(cfg->dt > 0.0f) || cfg->vel_iters < 0 || cfg->pos_iters < 0 || !(cfg->world_width > 0.0f) ||
         !(cfg->world_height > 0.0f) || !(cfg->bot_radius > 0.0f) || !(cfg->bot_density > 0.0f))
         return fail(KB_EINVAL, "kb_create: non-positive dt / size / radius / density");
@@ -795,6 +1121,7 @@ int kb_create(const kb_config *cfg, kb_sim **out) {
     if (!s) return fail(KB_EINVAL, "kb_create: out of host memory");
     s->cfg = *cfg;
     s->bound = false;
+    s->attr_set = false;
     Params &p = s->p;
     memset(&p, 0, sizeof(p));
     p.N = cfg->num_bots; p.E = cfg->num_envs; p.S = cfg->ws_slots;
@@ -828,12 +1155,17 @@ int kb_create(const kb_config *cfg, kb_sim **out) {
     if (cap > 2304) cap = 2304;
     if (cap < 4L * p.N + 64) cap = 4L * p.N + 64;
     p.cap = (int)cap;
-    p.L = make_layout(p.N, p.ncell, p.cap);
+    p.capL = p.cap < CAP_LDS ? p.cap : CAP_LDS;
+    p.NP = (p.N + 3) & ~3;
+    p.solver_mode = cfg->solver_mode;
+    p.L = make_layout(p.NP, p.ncell, p.capL);
     if (p.L.total > 160 * 1024) {
         delete s;
         return fail(KB_ELDS, "kb_create: configuration needs more than 160 KiB of LDS per env");
     }
-    s->threads = p.N <= 64 ? 64 : (p.N <= 128 ? 128 : 256);   // N <= BPT * threads
+    s->threads = ((p.N + BPT - 1) / BPT + 63) & ~63;   // N <= BPT * threads
+    if (s->threads < 64) s->threads = 64;
+    if (s->threads > 64 * MAX_WAVES) { delete s; return fail(KB_EINVAL, "kb_create: num_bots exceeds bots-per-thread x workgroup size of this build"); }
     *out = s;
     return KB_OK;
 }
@@ -842,8 +1174,8 @@ void kb_destroy(kb_sim *sim) { delete sim; }
 
 int kb_bind(kb_sim *sim, const kb_buffers *b) {
     if (!sim || !b) return fail(KB_EINVAL, "kb_bind: NULL argument");
-    if (!b->x || !b->y || !b->theta || !b->ws_key || !b->ws_acc || !b->ws_cnt || !b->status)
-        return fail(KB_ENOTBOUND, "kb_bind: x, y, theta, ws_key, ws_acc, ws_cnt and status are required");
+    if (!b->x || !b->y || !b->theta || !b->ws_key || !b->ws_acc || !b->ws_cnt || !b->status || !b->scratch)
+        return fail(KB_ENOTBOUND, "kb_bind: x, y, theta, ws_key, ws_acc, ws_cnt, status and scratch are required");
     const int m = sim->cfg.drive_mode;
     if ((m == KB_DRIVE_VELOCITY || m == KB_DRIVE_ACCEL) && (!b->v || !b->w))
         return fail(KB_ENOTBOUND, "kb_bind: v and w are required in the velocity / acceleration modes");
@@ -889,14 +1221,24 @@ int kb_step(kb_sim *sim, const float *d_actions, const float *d_light_action, in
     p.light_action = d_light_action;
     p.n_substeps = n_substeps;
     p.flags = flags;
-    static thread_local int attr_set_for = -1;
-    if (p.L.total > 64 * 1024 && attr_set_for != p.L.total) {
-        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(kb_step_kernel),
+    typedef void (*step_fn)(const Params);
+    step_fn fn = nullptr;
+    const bool lit = p.light_type == KB_LIGHT_CIRCULAR;
+    switch (p.drive_mode) {
+    case KB_DRIVE_VELOCITY: fn = lit ? kb_step_kernel<KB_DRIVE_VELOCITY, KB_LIGHT_CIRCULAR> : kb_step_kernel<KB_DRIVE_VELOCITY, KB_LIGHT_NONE>; break;
+    case KB_DRIVE_ACCEL: fn = lit ? kb_step_kernel<KB_DRIVE_ACCEL, KB_LIGHT_CIRCULAR> : kb_step_kernel<KB_DRIVE_ACCEL, KB_LIGHT_NONE>; break;
+    case KB_DRIVE_MOTORS: fn = lit ? kb_step_kernel<KB_DRIVE_MOTORS, KB_LIGHT_CIRCULAR> : kb_step_kernel<KB_DRIVE_MOTORS, KB_LIGHT_NONE>; break;
+    case KB_DRIVE_SIMPLE_PHOTOTAXIS: fn = kb_step_kernel<KB_DRIVE_SIMPLE_PHOTOTAXIS, KB_LIGHT_CIRCULAR>; break;
+    case KB_DRIVE_PHOTOTAXIS: fn = kb_step_kernel<KB_DRIVE_PHOTOTAXIS, KB_LIGHT_CIRCULAR>; break;
+    default: return fail(KB_EINVAL, "kb_step: bad drive mode");
+    }
+    if (p.L.total > 64 * 1024 && !sim->attr_set) {
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, p.L.total);
         if (e2 != hipSuccess) return fail(KB_EHIP, "kb_step: hipFuncSetAttribute: %s", hipGetErrorString(e2));
-        attr_set_for = p.L.total;
+        sim->attr_set = true;
     }
-    hipLaunchKernelGGL(kb_step_kernel, dim3((unsigned)p.E), dim3((unsigned)sim->threads), (size_t)p.L.total,
+    hipLaunchKernelGGL(fn, dim3((unsigned)p.E), dim3((unsigned)sim->threads), (size_t)p.L.total,
                        (hipStream_t)stream, p);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return fail(KB_EHIP, "kb_step: %s", hipGetErrorString(err));
@@ -915,11 +1257,12 @@ int kb_get_poses(kb_sim *sim, float *d_out, void *stream) {
 }
 
 int kb_lds_bytes(const kb_sim *sim) { return sim ? sim->p.L.total : KB_EINVAL; }
+size_t kb_scratch_bytes(const kb_sim *sim) { return sim ? (size_t)sim->p.E * (size_t)sim->p.cap * 16u : 0; }
 int kb_contact_capacity(const kb_sim *sim) { return sim ? sim->p.cap : KB_EINVAL; }
 int kb_block_threads(const kb_sim *sim) { return sim ? sim->threads : KB_EINVAL; }
 int kb_set_block_threads(kb_sim *sim, int threads) {
-    if (!sim || threads < 64 || threads > 64 * MAX_WAVES || (threads & 63)) return fail(KB_EINVAL, "kb_set_block_threads: multiple of 64 in [64, 256]");
-    if (sim->p.N > BPT * threads) return fail(KB_EINVAL, "kb_set_block_threads: need num_bots <= 4 * threads");
+    if (!sim || threads < 64 || threads > 64 * MAX_WAVES || (threads & 63)) return fail(KB_EINVAL, "kb_set_block_threads: multiple of 64 up to the build maximum");
+    if (sim->p.N > BPT * threads) return fail(KB_EINVAL, "kb_set_block_threads: need num_bots <= bots-per-thread x threads");
     sim->threads = threads;
     return KB_OK;
 }

@@ -33,7 +33,7 @@ class KilobotSim:
         self.drive_mode, self.light_type = drive_mode, light_type
         self._h = C.c_void_p()
         nat.check(self._lib.kb_create(C.byref(self.cfg), C.byref(self._h)), 'kb_create')
-        E, N, S = num_envs, num_bots, self.cfg.ws_slots
+        E, N = num_envs, num_bots
         dev = self.device
         f = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
         self.x, self.y, self.theta = f(E, N), f(E, N), f(E, N)
@@ -56,9 +56,11 @@ class KilobotSim:
             self.pt_dir = torch.zeros(E, N, dtype=torch.uint8, device=dev)
         if light_type != LIGHT_NONE:
             self.light_x, self.light_y = f(E), f(E)
-        self.ws_key = torch.zeros(E, S, N, dtype=torch.int32, device=dev)
-        self.ws_acc = f(E, S, N)
+        cap = self._lib.kb_contact_capacity(self._h)
+        self.ws_key = torch.zeros(E, cap, dtype=torch.int32, device=dev)
+        self.ws_acc = f(E, cap)
         self.ws_cnt = torch.zeros(E, N, dtype=torch.uint8, device=dev)
+        self.scratch = torch.empty(self._lib.kb_scratch_bytes(self._h), dtype=torch.uint8, device=dev)
         self.status = torch.zeros(E, dtype=torch.int32, device=dev)
         self.light_value = self.light_gx = self.light_gy = None
         self.cmd_vx = self.cmd_vy = self.cmd_w = None

@@ -82,6 +82,9 @@ typedef struct kb_config {
     float obj_density, obj_friction;
     float obj_linear_damping, obj_angular_damping;
     int32_t toi_walls;                          /* reserved */
+    int32_t solver_mode;                        /* 0 = automatic.  Test knobs (results are identical in every mode):
+                                                   1 list solver, one wave per island set; 2 list solver, whole
+                                                   workgroup per sweep; 3 / 4 = 1 / 2 with contacts staged in `scratch` */
 } kb_config;
 
 /* Device buffers of one handle.  NULL is allowed for buffers the configuration never touches
@@ -99,13 +102,17 @@ typedef struct kb_buffers {
     float *light_x, *light_y;           /* [num_envs], metres; required when light_type != NONE */
     float *light_vx, *light_vy;         /* reserved */
     float *ox, *oy, *otheta, *ovx, *ovy, *ow; /* reserved (objects) */
-    uint32_t *ws_key;                   /* required: [num_envs][ws_slots][num_bots] */
-    float *ws_acc;                      /* required: [num_envs][ws_slots][num_bots] */
+    /* warm-start store (Box2D keeps the accumulated normal impulse in each b2Contact): per env a packed
+     * list of kb_contact_capacity() entries, owner bots ascending, ws_cnt[bot] entries per owner */
+    uint32_t *ws_key;                   /* required: [num_envs][kb_contact_capacity()] */
+    float *ws_acc;                      /* required: [num_envs][kb_contact_capacity()] */
     uint8_t *ws_cnt;                    /* required: [num_envs][num_bots]; zero it to forget all contacts */
     float *light_value, *light_gx, *light_gy; /* optional outputs: last sensed light (kilobots_env.py:176-180) */
     float *cmd_vx, *cmd_vy, *cmd_w;     /* optional outputs: body velocity written by the drive law */
     int32_t *status;                    /* required: [num_envs]; bit0 contact capacity overflow,
                                            bit1 warm-start slot overflow, bit2 rank/cell overflow */
+    void *scratch;                      /* required: kb_scratch_bytes() bytes; contact staging of envs whose
+                                           contacts do not fit the LDS staging area (contents are transient) */
 } kb_buffers;
 
 typedef struct kb_sim kb_sim;
@@ -136,9 +143,10 @@ int kb_get_poses(kb_sim *sim, float *d_out, void *stream);
 
 /* Introspection */
 int kb_lds_bytes(const kb_sim *sim);            /* dynamic LDS per workgroup (one env per workgroup) */
-int kb_contact_capacity(const kb_sim *sim);     /* contacts per env */
+int kb_contact_capacity(const kb_sim *sim);     /* contacts (and warm-start entries) per env */
+size_t kb_scratch_bytes(const kb_sim *sim);     /* size of kb_buffers.scratch */
 int kb_block_threads(const kb_sim *sim);
-int kb_set_block_threads(kb_sim *sim, int threads);  /* multiple of 64 in [64, 256], num_bots <= 4 * threads */
+int kb_set_block_threads(kb_sim *sim, int threads);  /* multiple of 64 in [64, 512], num_bots <= 2 * threads */
 const char *kb_last_error(void);
 const char *kb_version(void);
 

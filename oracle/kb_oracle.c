@@ -196,6 +196,7 @@ typedef struct {
     int *cell_start, *cell_items;
     contact_t *con; int ncon, cap;
     int *parent; unsigned char *active, *next_active;
+    int *woff, *wnoff;     /* packed warm-start offsets: previous / next substep */
     int status;
 } work_t;
 
@@ -206,10 +207,12 @@ static void uf_union(int *p, int a, int b) {
     if (a < b) p[b] = a; else p[a] = b;
 }
 
-static float ws_lookup(const kbo_state *st, int e, int N, int S, int owner, unsigned key) {
-    int cnt = st->ws_cnt[(size_t)e * N + owner];
-    for (int s = 0; s < cnt && s < S; ++s) {
-        size_t idx = ((size_t)e * S + s) * N + owner;
+/* warm-start store: per env a packed list of (key, impulse) entries, owner bots in ascending order,
+ * ws_cnt[owner] entries each; entry (owner, slot) sits at woff[owner] + slot */
+static float ws_lookup(const kbo_state *st, const work_t *w, int e, int owner, unsigned key) {
+    int cnt = st->ws_cnt[(size_t)e * w->N + owner];
+    for (int s = 0; s < cnt; ++s) {
+        size_t idx = (size_t)e * w->cap + (size_t)(w->woff[owner] + s);
         if (st->ws_key[idx] == key) return st->ws_acc[idx];
     }
     return -1.0f;  /* accumulated impulses are >= 0 */
@@ -227,6 +230,10 @@ static void add_contact(work_t *w, int a, int b, int cls, int group, float ima, 
 static void detect_env(const kbo_config *cfg, const derived_t *d, const kbo_state *st, int e, work_t *w) {
     const int N = w->N, S = w->S;
     const int ncell = d->gw * d->gh;
+    {   /* offsets of the previous substep's packed warm-start list */
+        int run = 0;
+        for (int b = 0; b < N; ++b) { w->woff[b] = run; run += st->ws_cnt[(size_t)e * N + b]; }
+    }
     /* cells */
     memset(w->cell_start, 0, sizeof(int) * (ncell + 1));
     for (int b = 0; b < N; ++b) {
@@ -263,8 +270,8 @@ static void detect_env(const kbo_config *cfg, const derived_t *d, const kbo_stat
                 int cls = dcls[k];
                 if (k == 1 || k == 3 || k == 4) cls += (w->cx[a] & 1);
                 else if (k == 2) cls += (w->cy[a] & 1);
-                float acc = ws_lookup(st, e, N, S, a, (unsigned)b);
-                if (acc < 0.0f) acc = ws_lookup(st, e, N, S, b, (unsigned)a);
+                float acc = ws_lookup(st, w, e, a, (unsigned)b);
+                if (acc < 0.0f) acc = ws_lookup(st, w, e, b, (unsigned)a);
                 if (acc < 0.0f) acc = 0.0f;
                 int slot = nslot < S ? nslot : -1;
                 if (slot < 0) w->status |= 2;
@@ -279,7 +286,7 @@ static void detect_env(const kbo_config *cfg, const derived_t *d, const kbo_stat
             float dist = wl == 0 ? w->px[a] - d->xmin : wl == 1 ? w->py[a] - d->ymin
                        : wl == 2 ? d->xmax - w->px[a] : d->ymax - w->py[a];
             if (dist * dist > rw2) continue;
-            float acc = ws_lookup(st, e, N, S, a, KEY_WALL + (unsigned)wl);
+            float acc = ws_lookup(st, w, e, a, KEY_WALL + (unsigned)wl);
             if (acc < 0.0f) acc = 0.0f;
             int slot = nslot < S ? nslot : -1;
             if (slot < 0) w->status |= 2;
@@ -303,7 +310,7 @@ static inline float wall_dist(const derived_t *d, int wl, float x, float y, floa
 
 /* b2Island::Solve for one env (all islands; islands only matter for the position-iteration early-out) */
 static void world_step_env(const kbo_config *cfg, const derived_t *d, kbo_state *st, int e, work_t *w) {
-    const int N = w->N, S = w->S;
+    const int N = w->N;
     const float h = d->h;
     detect_env(cfg, d, st, e, w);
 
@@ -360,11 +367,21 @@ static void world_step_env(const kbo_config *cfg, const derived_t *d, kbo_state 
     for (int i = 0; i < w->ncon; ++i) {
         contact_t *c = &w->con[i];
         if (c->slot < 0) continue;
-        size_t idx = ((size_t)e * S + c->slot) * N + c->owner;
-        unsigned key = c->a < 0 ? KEY_WALL + (unsigned)(-1 - c->a) : (unsigned)c->b;
-        st->ws_key[idx] = key; st->ws_acc[idx] = c->acc;
         size_t ci = (size_t)e * N + c->owner;
         if (st->ws_cnt[ci] < c->slot + 1) st->ws_cnt[ci] = (uint8_t)(c->slot + 1);
+    }
+    {
+        int run = 0;
+        for (int b = 0; b < N; ++b) { w->wnoff[b] = run; run += st->ws_cnt[(size_t)e * N + b]; }
+    }
+    for (int i = 0; i < w->ncon; ++i) {
+        contact_t *c = &w->con[i];
+        if (c->slot < 0) continue;
+        int pos = w->wnoff[c->owner] + c->slot;
+        if (pos >= w->cap) continue;
+        size_t idx = (size_t)e * w->cap + (size_t)pos;
+        unsigned key = c->a < 0 ? KEY_WALL + (unsigned)(-1 - c->a) : (unsigned)c->b;
+        st->ws_key[idx] = key; st->ws_acc[idx] = c->acc;
     }
     /* integrate positions */
     for (int b = 0; b < N; ++b) {
@@ -503,6 +520,15 @@ static void substep_env(const kbo_config *cfg, const derived_t *d, kbo_state *st
     if (st->status) st->status[e] |= w->status;
 }
 
+int kbo_contact_capacity(const kbo_config *cfg) {
+    /* contact capacity per env (must equal the HIP kernel's, kb_contact_capacity) */
+    long N = cfg->num_bots;
+    long cap = N * (N - 1) / 2 + 4L * N;
+    if (cap > 2304) cap = 2304;
+    if (cap < 4L * N + 64) cap = 4L * N + 64;
+    return (int)cap;
+}
+
 static int work_alloc(work_t *w, const kbo_config *cfg, const derived_t *d) {
     memset(w, 0, sizeof(*w));
     int N = cfg->num_bots, M = cfg->num_objects, T = N + M;
@@ -512,13 +538,9 @@ static int work_alloc(work_t *w, const kbo_config *cfg, const derived_t *d) {
     w->cell = (int *)malloc(sizeof(int) * T * 3); w->cx = w->cell + T; w->cy = w->cx + T;
     w->cell_start = (int *)malloc(sizeof(int) * (d->gw * d->gh + 1));
     w->cell_items = (int *)malloc(sizeof(int) * T);
-    /* contact capacity per env (must equal the HIP kernel's, kb_contact_capacity) */
-    long cap = (long)N * (N - 1) / 2 + 4L * N;
-    if (cap > 2304) cap = 2304;
-    if (cap < 4L * N + 64) cap = 4L * N + 64;
-    w->cap = (int)cap;
+    w->cap = kbo_contact_capacity(cfg);
     w->con = (contact_t *)malloc(sizeof(contact_t) * w->cap);
-    w->parent = (int *)malloc(sizeof(int) * T);
+    w->parent = (int *)malloc(sizeof(int) * T * 3); w->woff = w->parent + T; w->wnoff = w->woff + T;
     w->active = (unsigned char *)malloc(2 * (size_t)T); w->next_active = w->active + T;
     return (w->px && w->cell && w->cell_start && w->cell_items && w->con && w->parent && w->active) ? 0 : -1;
 }

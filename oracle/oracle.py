@@ -36,6 +36,7 @@ class Config(C.Structure):
         ('obj_density', C.c_float), ('obj_friction', C.c_float),
         ('obj_linear_damping', C.c_float), ('obj_angular_damping', C.c_float),
         ('toi_walls', C.c_int32),
+        ('solver_mode', C.c_int32),
     ]
 
 
@@ -82,6 +83,8 @@ def lib():
         _lib.kbo_set_actions.restype = C.c_int
         _lib.kbo_count_contacts.argtypes = [C.POINTER(Config), C.POINTER(State), C.c_int, _PI32, _PI32]
         _lib.kbo_count_contacts.restype = C.c_int
+        _lib.kbo_contact_capacity.argtypes = [C.POINTER(Config)]
+        _lib.kbo_contact_capacity.restype = C.c_int
         _lib.kbo_sincosf.argtypes = [C.c_float, _PF, _PF]
         _lib.kbo_sincosf.restype = None
     return _lib
@@ -122,7 +125,8 @@ class OracleSim:
 
     def __init__(self, cfg):
         self.cfg = cfg
-        E, N, S = cfg.num_envs, cfg.num_bots, cfg.ws_slots
+        E, N = cfg.num_envs, cfg.num_bots
+        self.cap = lib().kbo_contact_capacity(C.byref(cfg))
         f = lambda *s: np.zeros(s, np.float32)
         self.x, self.y, self.theta, self.v, self.w = f(E, N), f(E, N), f(E, N), f(E, N), f(E, N)
         self.acc_v, self.acc_w = f(E, N), f(E, N)
@@ -133,8 +137,8 @@ class OracleSim:
         self.pt_nochange = np.zeros((E, N), np.int32)
         self.pt_dir = np.zeros((E, N), np.uint8)
         self.light_x, self.light_y, self.light_vx, self.light_vy = f(E), f(E), f(E), f(E)
-        self.ws_key = np.full((E, S, N), 0xFFFFFFFF, np.uint32)
-        self.ws_acc = f(E, S, N)
+        self.ws_key = np.full((E, self.cap), 0xFFFFFFFF, np.uint32)
+        self.ws_acc = f(E, self.cap)
         self.ws_cnt = np.zeros((E, N), np.uint8)
         self.light_value, self.light_gx, self.light_gy = f(E, N), f(E, N), f(E, N)
         self.cmd_vx, self.cmd_vy, self.cmd_w = f(E, N), f(E, N), f(E, N)
