@@ -36,6 +36,7 @@ def main():
     ap.add_argument('--envs', type=int, default=4096, help='envs per GPU')
     ap.add_argument('--bots', type=int, default=1024)
     ap.add_argument('--threads', type=int, default=0, help='workgroup size override')
+    ap.add_argument('--objects', type=int, default=0, help='cfg4: 4 pushable discs per env (not the headline workload)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-envs', type=int, default=64)
     ap.add_argument('--traffic-json', default=os.path.join(ROOT, 'profiles', 'traffic_latest.json'))
@@ -65,14 +66,19 @@ def main():
     reps = (E + base - 1) // base
     xy = np.tile(xy1, (reps, 1, 1))[:E]
     th = np.tile(th1, (reps, 1))[:E]
-    sim = KilobotSim(E, N, device=dev)
+    sim = KilobotSim(E, N, device=dev, num_objects=args.objects)
     if args.threads:
         sim.block_threads = args.threads
     sim.set_poses_m(xy, th)
+    if args.objects:
+        sim.set_objects_m(np.tile(scenes.CFG4_OBJECTS[None, :args.objects], (E, 1, 1)))
     n_sets = 8
     actions = []
     for k in range(n_sets):
         a1 = scenes.random_actions(base, N, seed=2000 + 10 * rank + k)
+        if args.objects:      # cfg4: every second bot drives straight ahead at full speed (sustained contact)
+            a1[:, ::2, 0] = 0.01
+            a1[:, ::2, 1] = 0.0
         actions.append(torch.from_numpy(np.tile(a1, (reps, 1, 1))[:E].copy()).to(dev))
     x0 = sim.x.clone()
     y0 = sim.y.clone()
@@ -143,7 +149,7 @@ def main():
         'metric': 'kilobot-steps/sec', 'value': value, 'unit': 'kilobot-steps/s', 'n_gpus': world,
         'steps': K, 'warmup': args.warmup, 'ms_per_step': elapsed / K * 1e3, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': 'cfg3: %d envs x %d kilobots per GPU, empty arena 2.0x1.5 m, jittered lattice spawn, '
+        'config': {'workload': ('cfg4 (+%d pushable discs): ' % args.objects if args.objects else '') + 'cfg3: %d envs x %d kilobots per GPU, empty arena 2.0x1.5 m, jittered lattice spawn, '
                                'random velocity-control actions every substep; 1 step = 1 world substep (dt 0.1 s) in 1 launch'
                                % (E, N),
                    'envs_per_gpu': E, 'bots': N, 'total_envs': total_envs, 'substeps_per_launch': 1,

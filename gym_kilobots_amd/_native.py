@@ -46,7 +46,7 @@ BUFFER_FIELDS = ['x', 'y', 'theta', 'v', 'w', 'acc_v', 'acc_w', 'motor_l', 'moto
                  'light_x', 'light_y', 'light_vx', 'light_vy',
                  'ox', 'oy', 'otheta', 'ovx', 'ovy', 'ow',
                  'ws_key', 'ws_acc', 'ws_cnt',
-                 'light_value', 'light_gx', 'light_gy', 'cmd_vx', 'cmd_vy', 'cmd_w', 'status', 'scratch']
+                 'light_value', 'light_gx', 'light_gy', 'cmd_vx', 'cmd_vy', 'cmd_w', 'status', 'scratch', 'ows_acc']
 
 
 class KbBuffers(C.Structure):
@@ -112,6 +112,8 @@ def default_config(num_envs, num_bots, drive_mode=DRIVE_VELOCITY, light_type=LIG
     inf = float('inf')
     c = KbConfig()
     c.num_envs, c.num_bots, c.num_objects = num_envs, num_bots, 0
+    for i in range(MAX_OBJECTS):
+        c.obj_radius[i] = 0.075
     c.world_width, c.world_height = 2.0, 1.5
     c.dt, c.vel_iters, c.pos_iters = 0.1, 10, 10
     c.drive_mode, c.light_type = drive_mode, light_type

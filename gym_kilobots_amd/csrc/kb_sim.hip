@@ -50,13 +50,16 @@ constexpr float WORLD_SCALE = 25.0f;  // body.py:7
 constexpr float CELL_SIZE = 0.875f;   // world units, >= 2 * bot radius
 constexpr int MAX_CELLS = 8192;
 
-constexpr unsigned KEY_WALL = 0x10000u;
-constexpr int WALL_CODE = 0xFFF0;     // ca[] value of wall w is WALL_CODE + w
+constexpr unsigned KEY_WALL = 0x10000u, KEY_OBJ = 0x20000u;
+constexpr int WALL_CODE = 0xFFF0;     // body id of wall w is WALL_CODE + w
+constexpr int OBJ_CODE = 0xFFE0;      // 16-bit warm-start key of object m (its body id is N + m)
+constexpr int MAXOBJ = KB_MAX_OBJECTS, OWS = 12, OBJ_LIST = 32;
 constexpr unsigned EMPTY32 = 0xFFFFFFFFu;
 constexpr unsigned short EMPTY16 = 0xFFFFu;
 
 // contact classes in canonical order; +1 on E/N/NE/NW for odd base-cell parity
-constexpr int CLS_SAME = 0, CLS_E = 1, CLS_N = 3, CLS_NE = 5, CLS_NW = 7, CLS_WALL = 9, NUM_CLS = 10;
+constexpr int CLS_SAME = 0, CLS_E = 1, CLS_N = 3, CLS_NE = 5, CLS_NW = 7, CLS_WALL = 9,
+              CLS_BOT_OBJ = 10, CLS_OBJ_OBJ = 11, CLS_OBJ_WALL = 12, NUM_CLS = 13;
 constexpr int RK = 4;                 // rank buckets per class; the last one holds every rank >= RK-1
 #ifndef KB_MAX_WAVES
 #define KB_MAX_WAVES 8
@@ -78,7 +81,7 @@ constexpr int GIANT_ISLAND = 256;     // contacts; larger islands are swept by t
 constexpr int KREG = KB_KREG;               // contacts a lane can keep in registers (register-resident solver)
 constexpr int CAP_LDS = 1024;         // contacts staged in LDS; denser envs stage in the global scratch slice
 
-enum { M_NCON = 0, M_TOTAL = 1, M_ANY = 2, M_STATUS = 3, M_MAXISL = 4, M_WCNT = 8, M_WFILL = 8 + MAX_WAVES, M_COUNT = 8 + 2 * MAX_WAVES };
+enum { M_NCON = 0, M_TOTAL = 1, M_ANY = 2, M_STATUS = 3, M_MAXISL = 4, M_PROF = 5, M_WCNT = 8, M_WFILL = 8 + MAX_WAVES, M_COUNT = 8 + 2 * MAX_WAVES };
 
 struct Layout {  // byte offsets into dynamic LDS
     int px, py, vx, vy;
@@ -88,6 +91,7 @@ struct Layout {  // byte offsets into dynamic LDS
     int bkStart, bkFill, bkMaxRank, bkList;
     int next, cellOf;
     int wsCnt, wsCntNew, active, nList;
+    int objF, objCnt, objList, owsOld, owsNew;
     int total;
 };
 
@@ -95,19 +99,21 @@ struct Params {
     kb_buffers buf;
     const float *actions;
     const float *light_action;
-    int N, NP, E, S, gw, gh, ncell, cap, capL, n_substeps, flags, drive_mode, light_type, vel_iters, pos_iters;
+    int N, NP, NB, M, E, S, gw, gh, ncell, cap, capL, n_substeps, flags, drive_mode, light_type, vel_iters, pos_iters;
     int solver_mode;
     float xmin, ymin, xmax, ymax, inv_cell, r_bot, im_bot, kl_bot, ka_bot, h;
     float light_radius, light_lo[2], light_hi[2], act_lo[2], act_hi[2];
+    float r_obj[KB_MAX_OBJECTS], im_obj[KB_MAX_OBJECTS], kl_obj, ka_obj;
     Layout L;
 };
 
 Layout make_layout(int NP, int ncell, int capL) {
+    const int NB = NP + KB_MAX_OBJECTS;   // bodies: kilobots, then objects at index N + m
     Layout L;
     int o = 0;
     auto take = [&](int bytes) { int r = o; o += (bytes + 15) & ~15; return r; };
-    L.px = take(4 * NP); L.py = take(4 * NP); L.vx = take(4 * NP); L.vy = take(4 * NP);
-    L.head = take(4 * ncell); L.dirCnt = take(4 * NP); L.parent = take(4 * NP);
+    L.px = take(4 * NB); L.py = take(4 * NB); L.vx = take(4 * NB); L.vy = take(4 * NB);
+    L.head = take(4 * ncell); L.dirCnt = take(4 * NB); L.parent = take(4 * NB);
     L.misc = take(4 * M_COUNT); L.wsum = take(4 * 16);
     L.wsOff = take(2 * NP); L.newOff = take(2 * NP); L.oldKey = take(2 * capL); L.oldAcc = take(4 * capL);
     L.sPair = take(4 * capL); L.sInfo = take(4 * capL); L.sAcc = take(4 * capL);
@@ -115,7 +121,9 @@ Layout make_layout(int NP, int ncell, int capL) {
     L.bkStart = take(4 * (MAX_BUCKETS + 1)); L.bkFill = take(4 * MAX_BUCKETS);
     L.bkMaxRank = take(4 * MAX_WAVES * NUM_CLS); L.bkList = take(2 * MAX_BUCKETS);
     L.next = take(2 * NP); L.cellOf = take(2 * NP);
-    L.wsCnt = take(NP); L.wsCntNew = take(NP); L.active = take(2 * NP); L.nList = take(16);
+    L.wsCnt = take(NP); L.wsCntNew = take(NP); L.active = take(2 * NB); L.nList = take(16);
+    L.objF = take(4 * 2 * KB_MAX_OBJECTS); L.objCnt = take(4 * KB_MAX_OBJECTS); L.objList = take(2 * KB_MAX_OBJECTS * 32);
+    L.owsOld = take(4 * KB_MAX_OBJECTS * 12); L.owsNew = take(4 * KB_MAX_OBJECTS * 12);
     L.total = o;
     return L;
 }
@@ -241,7 +249,7 @@ __device__ __forceinline__ unsigned block_scan_u8(const unsigned char *cnt, unsi
 #define KB_NEXT(b) (nextb[b] == EMPTY16 ? EMPTY32 : (unsigned)nextb[b])
 
 // One instantiation per (drive law, light model): keeps only that law's code (and registers) in the kernel.
-template <int DRIVE_MODE, int LIGHT_TYPE>
+template <int DRIVE_MODE, int LIGHT_TYPE, bool OBJ>
 __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_step_kernel(const Params p) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int e = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
@@ -269,6 +277,18 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
     unsigned short *nextb = (unsigned short *)(smem + p.L.next), *cellOf = (unsigned short *)(smem + p.L.cellOf);
     unsigned char *wsCnt = smem + p.L.wsCnt, *wsCntNew = smem + p.L.wsCntNew;
     unsigned char *active = smem + p.L.active, *nList = smem + p.L.nList;
+    float *objIm = (float *)(smem + p.L.objF), *objR = objIm + MAXOBJ;   // inverse mass / radius of object m
+    unsigned *objCnt = (unsigned *)(smem + p.L.objCnt);                 // kilobots touching object m
+    unsigned short *objList = (unsigned short *)(smem + p.L.objList);   // ... and who they are
+    float *owsOld = (float *)(smem + p.L.owsOld), *owsNew = (float *)(smem + p.L.owsNew);   // object warm-start tables
+    const int M = OBJ ? p.M : 0, NB = p.NB;   // OBJ = false: every object loop below folds away
+    // inverse mass / radius of a body id: kilobot < N, object N + m, wall >= WALL_CODE (static, edge skin radius)
+    auto bim = [&](int id) __attribute__((always_inline)) -> float {
+        return id >= WALL_CODE ? 0.0f : ((!OBJ || id < N) ? p.im_bot : objIm[id - N]);
+    };
+    auto brad = [&](int id) __attribute__((always_inline)) -> float {
+        return id >= WALL_CODE ? B2_POLYGON_RADIUS : ((!OBJ || id < N) ? p.r_bot : objR[id - N]);
+    };
 
     const kb_buffers &g = p.buf;
     // contact staging in global scratch, used when an env has more contacts than fit the LDS staging area
@@ -311,6 +331,15 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
         }
     }
     for (int b = N + tid; b < NP; b += nt) { wsCnt[b] = 0; wsCntNew[b] = 0; }
+    // pushable objects: thread m owns object m (pose angle / angular velocity stay in its registers)
+    float oth = 0.0f, oww = 0.0f;
+    if (tid < M) {
+        const size_t oi = (size_t)e * M + tid;
+        px[N + tid] = g.ox[oi]; py[N + tid] = g.oy[oi]; vx[N + tid] = g.ovx[oi]; vy[N + tid] = g.ovy[oi];
+        oth = g.otheta[oi]; oww = g.ow[oi];
+        objIm[tid] = p.im_obj[tid]; objR[tid] = p.r_obj[tid];
+    }
+    for (int k = tid; k < M * OWS; k += nt) owsOld[k] = g.ows_acc[(size_t)e * MAXOBJ * OWS + k];
     for (int c = tid; c < p.ncell; c += nt) head[c] = EMPTY32;
     if (tid == 0) misc[M_STATUS] = 0;
     float lx = 0.0f, ly = 0.0f;
@@ -318,9 +347,6 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
     const bool drive = !(p.flags & KB_STEP_NO_DRIVE);
     const float rr = p.r_bot + p.r_bot, rr2 = rr * rr;
     const float rw = B2_POLYGON_RADIUS + p.r_bot, rw2 = rw * rw;
-    // b2ContactSolver: normalMass = 1 / (invMassA + invMassB); walls are static (invMass 0)
-    const float kbb = p.im_bot + p.im_bot, kwb = 0.0f + p.im_bot;
-    const float nm_bb = kbb > 0.0f ? 1.0f / kbb : 0.0f, nm_wb = kwb > 0.0f ? 1.0f / kwb : 0.0f;
     __syncthreads();
     // warm-start list of the previous substep: offsets, and an LDS image of the packed entries if it fits
     unsigned oldTotal = block_scan_u8(wsCnt, wsOff, NP, wsum);
@@ -328,7 +354,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
     if (oldInLds) {
         for (unsigned i = tid; i < oldTotal; i += nt) {
             const unsigned k = g.ws_key[wo + i];
-            oldKey[i] = (unsigned short)(k >= KEY_WALL ? WALL_CODE + (k - KEY_WALL) : k);
+            oldKey[i] = (unsigned short)(k >= KEY_OBJ ? OBJ_CODE + (k - KEY_OBJ) : (k >= KEY_WALL ? WALL_CODE + (k - KEY_WALL) : k));
             oldAcc[i] = g.ws_acc[wo + i];
         }
     }
@@ -422,6 +448,12 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
             cellOf[b] = (unsigned short)cell;
             nextb[b] = (unsigned short)atomicExch(&head[cell], (unsigned)b);
         }
+        if (tid < M) {   // b2Island::Solve damping of the objects; they keep their velocity between substeps
+            vx[N + tid] *= p.kl_obj; vy[N + tid] *= p.kl_obj; oww *= p.ka_obj;
+            parent[N + tid] = N + tid;
+            objCnt[tid] = 0;
+        }
+        for (int k = tid; k < M * OWS; k += nt) owsNew[k] = -1.0f;
         if (tid < M_COUNT && tid != M_STATUS) misc[tid] = 0;
         __syncthreads();
         KB_STAMP(0);
@@ -467,9 +499,44 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                         sInfo[c] = (unsigned)(5 + wl) | (dist < 0.0f ? 0x80u : 0u);
                     }
                 }
+                // pushable objects: b2CollideCircles kilobot - object m (info 9 + m)
+                for (int m = 0; m < M; ++m) {
+                    const float dx = px[N + m] - ax, dy = py[N + m] - ay;
+                    const float ro = p.r_bot + objR[m];
+                    if (dx * dx + dy * dy > ro * ro) continue;
+                    mine++;
+                    const unsigned pos = atomicAdd(&objCnt[m], 1u);
+                    if (pos < (unsigned)OBJ_LIST) objList[m * OBJ_LIST + pos] = (unsigned short)a;
+                    else atomicOr(&misc[M_STATUS], 4u);
+                    const unsigned c = atomicAdd(&misc[M_NCON], 1u);
+                    if (c < (unsigned)stageCap_) { sPair[c] = (unsigned)a | ((unsigned)(N + m) << 16); sInfo[c] = (unsigned)(9 + m); }
+                }
                 dirCnt[a] = cnt;
                 if (mine > (unsigned)S) { atomicOr(&misc[M_STATUS], 2u); mine = S; }
                 wsCntNew[a] = (unsigned char)mine;
+            }
+            if (tid < M) {   // object - object (info 17) and object - wall (info 18 + wall), found by the object's thread
+                const int m = tid;
+                const float ax = px[N + m], ay = py[N + m];
+                for (int m2 = m + 1; m2 < M; ++m2) {
+                    const float dx = px[N + m2] - ax, dy = py[N + m2] - ay;
+                    const float ro = objR[m] + objR[m2];
+                    if (dx * dx + dy * dy > ro * ro) continue;
+                    const unsigned c = atomicAdd(&misc[M_NCON], 1u);
+                    if (c < (unsigned)stageCap_) { sPair[c] = (unsigned)(N + m) | ((unsigned)(N + m2) << 16); sInfo[c] = 17u; }
+                }
+                const float rwo = B2_POLYGON_RADIUS + objR[m];
+#pragma unroll
+                for (int wl = 0; wl < 4; ++wl) {
+                    float dist, nx, ny;
+                    wall_geom(p, wl, ax, ay, dist, nx, ny);
+                    if (dist * dist > rwo * rwo) continue;
+                    const unsigned c = atomicAdd(&misc[M_NCON], 1u);
+                    if (c < (unsigned)stageCap_) {
+                        sPair[c] = (unsigned)(WALL_CODE + wl) | ((unsigned)(N + m) << 16);
+                        sInfo[c] = (unsigned)(18 + wl) | (dist < 0.0f ? 0x80u : 0u);
+                    }
+                }
             }
         };
         bool big = p.solver_mode >= 3;
@@ -479,6 +546,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
             big = (int)misc[M_NCON] > p.capL;    // does not fit the LDS staging area: redo into the global scratch slice
             __syncthreads();
             if (big && tid == 0) misc[M_NCON] = 0;
+            if (big && tid < M) objCnt[tid] = 0;
             if (big) __syncthreads();
         }
         if (big) {
@@ -497,7 +565,8 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                 for (int s = 0; s < cnt; ++s)
                     if (oldKey[off + s] == (unsigned short)key16) return oldAcc[off + s];
             } else {
-                const unsigned key32 = key16 >= (unsigned)WALL_CODE ? KEY_WALL + (key16 - WALL_CODE) : key16;
+                const unsigned key32 = key16 >= (unsigned)WALL_CODE ? KEY_WALL + (key16 - WALL_CODE)
+                                     : (key16 >= (unsigned)OBJ_CODE ? KEY_OBJ + (key16 - OBJ_CODE) : key16);
                 for (int s = 0; s < cnt; ++s)
                     if (g.ws_key[wo + off + s] == key32) return g.ws_acc[wo + off + s];
             }
@@ -506,10 +575,78 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
         auto label_pass = [&](unsigned *sPair, unsigned *sInfo, float *sAcc) __attribute__((always_inline)) {
             for (int c = tid; c < ncon; c += nt) {
                 const unsigned pr = sPair[c], inf0 = sInfo[c];
-                const int k = inf0 & 15;
+                const int k = inf0 & 31;
                 int cls, r, slot;
                 float acc;
-                if (k >= 5) {   // wall contact, owned by the bot
+                if (k >= 18) {          // object - wall, owned by the object: sequential rank over (object, wall)
+                    const int mo = (int)(pr >> 16) - N, wl = k - 18;
+                    r = 0;
+                    for (int m2 = 0; m2 <= mo; ++m2) {
+                        const float rwo = B2_POLYGON_RADIUS + objR[m2];
+                        for (int w2 = 0; w2 < 4; ++w2) {
+                            if (m2 == mo && w2 >= wl) break;
+                            float dist, nx, ny;
+                            wall_geom(p, w2, px[N + m2], py[N + m2], dist, nx, ny);
+                            if (!(dist * dist > rwo * rwo)) r++;
+                        }
+                    }
+                    cls = CLS_OBJ_WALL | (int)(inf0 & 0x80u);
+                    slot = 8 + wl;
+                    acc = owsOld[mo * OWS + slot];
+                } else if (k == 17) {   // object - object, owned by the lower object: rank = pair index
+                    const int m1 = (int)(pr & 0xFFFF) - N, m2 = (int)(pr >> 16) - N;
+                    r = 0;
+                    for (int i1 = 0; i1 <= m1; ++i1)
+                        for (int i2 = i1 + 1; i2 < M; ++i2) {
+                            if (i1 == m1 && i2 >= m2) break;
+                            const float dx = px[N + i2] - px[N + i1], dy = py[N + i2] - py[N + i1];
+                            const float ro = objR[i1] + objR[i2];
+                            if (!(dx * dx + dy * dy > ro * ro)) r++;
+                        }
+                    cls = CLS_OBJ_OBJ;
+                    slot = m2;
+                    acc = owsOld[m1 * OWS + slot];
+                    unsigned ra = pr & 0xFFFF, rb = pr >> 16;
+                    for (;;) {
+                        while (true) { unsigned t = ((volatile unsigned *)parent)[ra]; if (t == ra) break; ra = t; }
+                        while (true) { unsigned t = ((volatile unsigned *)parent)[rb]; if (t == rb) break; rb = t; }
+                        if (ra == rb) break;
+                        if (ra < rb) { unsigned t = ra; ra = rb; rb = t; }
+                        if (atomicCAS(&parent[ra], ra, rb) == ra) break;
+                    }
+                } else if (k >= 9) {    // kilobot - object m, owned by the kilobot; all of them strictly sequential
+                    const int a = pr & 0xFFFF, m = k - 9;
+                    const float ax = px[a], ay = py[a];
+                    r = 0;
+                    for (int m2 = 0; m2 < m; ++m2) r += (int)min(objCnt[m2], (unsigned)OBJ_LIST);
+                    const int nm_ = (int)min(objCnt[m], (unsigned)OBJ_LIST);
+                    for (int i = 0; i < nm_; ++i) r += (objList[m * OBJ_LIST + i] < a) ? 1 : 0;
+                    const unsigned dc = dirCnt[a];
+                    slot = 0;
+#pragma unroll
+                    for (int k2 = 0; k2 < 5; ++k2) slot += (int)((dc >> (6 * k2)) & 63u);
+#pragma unroll
+                    for (int w2 = 0; w2 < 4; ++w2) {
+                        float dist, nx, ny;
+                        wall_geom(p, w2, ax, ay, dist, nx, ny);
+                        if (!(dist * dist > rw2)) slot++;
+                    }
+                    for (int m2 = 0; m2 < m; ++m2) {
+                        const float dx = px[N + m2] - ax, dy = py[N + m2] - ay;
+                        const float ro = p.r_bot + objR[m2];
+                        if (!(dx * dx + dy * dy > ro * ro)) slot++;
+                    }
+                    cls = CLS_BOT_OBJ;
+                    acc = ws_find(a, (unsigned)(OBJ_CODE + m));
+                    unsigned ra = a, rb = N + m;
+                    for (;;) {
+                        while (true) { unsigned t = ((volatile unsigned *)parent)[ra]; if (t == ra) break; ra = t; }
+                        while (true) { unsigned t = ((volatile unsigned *)parent)[rb]; if (t == rb) break; rb = t; }
+                        if (ra == rb) break;
+                        if (ra < rb) { unsigned t = ra; ra = rb; rb = t; }
+                        if (atomicCAS(&parent[ra], ra, rb) == ra) break;
+                    }
+                } else if (k >= 5) {   // wall contact, owned by the bot
                     const int a = pr >> 16, wl = k - 5;
                     const float ax = px[a], ay = py[a];
                     const unsigned dc = dirCnt[a];
@@ -570,7 +707,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                     }
                 }
                 if (acc < 0.0f) acc = 0.0f;
-                if (slot >= S) slot = 255;
+                if (slot >= S && k < 17) slot = 255;
                 if (r > 255) { r = 255; atomicOr(&misc[M_STATUS], 4u); }
                 sInfo[c] = (unsigned)cls | ((unsigned)r << 8) | ((unsigned)slot << 16);
                 sAcc[c] = acc;
@@ -587,7 +724,15 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
             parent[b] = r;   // only ever replaces an ancestor by an older ancestor: concurrent walks stay valid
             islCnt[b] = 0;
             head[cellOf[b]] = EMPTY32;
-            active[b] = 1; active[NP + b] = 0;
+            active[b] = 1; active[NB + b] = 0;
+        }
+        if (tid < M) {
+            const int b = N + tid;
+            unsigned r = b;
+            while (true) { unsigned t = ((volatile unsigned *)parent)[r]; if (t == r) break; r = t; }
+            parent[b] = r;
+            islCnt[b] = 0;
+            active[b] = 1; active[NB + b] = 0;
         }
         const unsigned newTotal = block_scan_u8(wsCntNew, newOff, NP, wsum);   // (barriers inside)
         const bool newInLds = newTotal <= (unsigned)p.capL;
@@ -668,15 +813,24 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
             const unsigned mybase = bkStart[wave * BK_PER_WAVE];
             const unsigned mycnt = bkStart[(wave + 1) * BK_PER_WAVE] - mybase;
             int ra[KREG], rb[KREG], rkey[KREG], rrank[KREG], rslot[KREG], risl[KREG];
-            float racc[KREG], rnx[KREG], rny[KREG];
+            float racc[KREG], rnx[KREG], rny[KREG], rima[KREG], rimb[KREG], rra[KREG], rrb[KREG], rnm[KREG];
             bool rvalid[KREG], rflip[KREG];
             unsigned mlo = 0, mhi = 0;
+            // without objects the masses / radii of a contact follow from "is A a wall": no registers needed
+            const float kbb_ = p.im_bot + p.im_bot, kwb_ = 0.0f + p.im_bot;
+            const float nm_bb = kbb_ > 0.0f ? 1.0f / kbb_ : 0.0f, nm_wb = kwb_ > 0.0f ? 1.0f / kwb_ : 0.0f;
+#define R_IMA(j) (OBJ ? rima[j] : (ra[j] < WALL_CODE ? p.im_bot : 0.0f))
+#define R_IMB(j) (OBJ ? rimb[j] : p.im_bot)
+#define R_RA(j) (OBJ ? rra[j] : (ra[j] < WALL_CODE ? p.r_bot : B2_POLYGON_RADIUS))
+#define R_RB(j) (OBJ ? rrb[j] : p.r_bot)
+#define R_NM(j) (OBJ ? rnm[j] : (ra[j] < WALL_CODE ? nm_bb : nm_wb))
 #pragma unroll
             for (int j = 0; j < KREG; ++j) {
                 const unsigned idx = lane + 64u * j;
                 rvalid[j] = idx < mycnt;
                 ra[j] = 0; rb[j] = 0; rkey[j] = 0; rrank[j] = 0; rslot[j] = 255; risl[j] = 0;
                 racc[j] = 0.0f; rnx[j] = 1.0f; rny[j] = 0.0f; rflip[j] = false;
+                rima[j] = 0.0f; rimb[j] = 0.0f; rra[j] = 0.0f; rrb[j] = 0.0f; rnm[j] = 0.0f;
                 if (rvalid[j]) {
                     const int c = lOrder[mybase + idx];
                     const unsigned pr = lPair[c], inf = lInfo[c];
@@ -685,6 +839,11 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                     ra[j] = a; rb[j] = b; rrank[j] = r; rslot[j] = (inf >> 16) & 0xFF; racc[j] = lAcc[c];
                     rflip[j] = (inf & 0x80) != 0;
                     risl[j] = (int)parent[b];
+                    if (OBJ) {
+                        rima[j] = bim(a); rimb[j] = bim(b); rra[j] = brad(a); rrb[j] = brad(b);
+                        const float k_ = rima[j] + rimb[j];
+                        rnm[j] = k_ > 0.0f ? 1.0f / k_ : 0.0f;   // b2ContactSolver normalMass
+                    }
                     const int key = cls * RK + (r < RK - 1 ? r : RK - 1);
                     rkey[j] = key;
                     if (key < 32) mlo |= 1u << key; else mhi |= 1u << (key - 32);
@@ -734,28 +893,28 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
             KB_REG_ROUNDS({
                 const int a = ra[j], b = rb[j];
                 const float Px = racc[j] * rnx[j], Py = racc[j] * rny[j];
-                if (a < WALL_CODE) { vx[a] -= p.im_bot * Px; vy[a] -= p.im_bot * Py; }
-                vx[b] += p.im_bot * Px; vy[b] += p.im_bot * Py;
+                if (a < WALL_CODE) { vx[a] -= R_IMA(j) * Px; vy[a] -= R_IMA(j) * Py; }
+                vx[b] += R_IMB(j) * Px; vy[b] += R_IMB(j) * Py;
             })
             // SolveVelocityConstraints: friction 0, restitution 0, one manifold point
             for (int it = 0; it < p.vel_iters; ++it) {
                 KB_REG_ROUNDS({
                     const int a = ra[j], b = rb[j];
                     const float nx = rnx[j], ny = rny[j];
-                    float vax = 0.0f, vay = 0.0f, ima = 0.0f;
-                    if (a < WALL_CODE) { vax = vx[a]; vay = vy[a]; ima = p.im_bot; }
+                    float vax = 0.0f, vay = 0.0f;
+                    const float ima = R_IMA(j), imb = R_IMB(j);
+                    if (a < WALL_CODE) { vax = vx[a]; vay = vy[a]; }
                     const float vbx = vx[b], vby = vy[b];
                     const float dvx = vbx - vax, dvy = vby - vay;
                     const float vn = dvx * nx + dvy * ny;
-                    const float nm = a < WALL_CODE ? nm_bb : nm_wb;
-                    float lambda = -(nm * vn);
+                    float lambda = -(R_NM(j) * vn);
                     const float accOld = racc[j];
                     const float newimp = fmaxf(accOld + lambda, 0.0f);
                     lambda = newimp - accOld;
                     racc[j] = newimp;
                     const float Px = lambda * nx, Py = lambda * ny;
                     if (a < WALL_CODE) { vx[a] = vax - ima * Px; vy[a] = vay - ima * Py; }
-                    vx[b] = vbx + p.im_bot * Px; vy[b] = vby + p.im_bot * Py;
+                    vx[b] = vbx + imb * Px; vy[b] = vby + imb * Py;
                 })
             }
             __syncthreads();
@@ -767,12 +926,14 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                 if (!rvalid[j] || rslot[j] == 255) continue;
                 const int a = ra[j], b = rb[j];
                 const int owner = a < WALL_CODE ? a : b;
-                const unsigned key16 = a < WALL_CODE ? (unsigned)b : (unsigned)a;
+                if (owner >= N) { owsNew[(owner - N) * OWS + rslot[j]] = racc[j]; continue; }   // object-owned contact
+                const unsigned key16 = a >= WALL_CODE ? (unsigned)a : (b >= N ? (unsigned)(OBJ_CODE + (b - N)) : (unsigned)b);
                 const unsigned pos = (unsigned)newOff[owner] + (unsigned)rslot[j];
                 if (pos >= (unsigned)p.cap) continue;
                 if (newInLds) { oldKey[pos] = (unsigned short)key16; oldAcc[pos] = racc[j]; }
                 if (last || !newInLds) {
-                    g.ws_key[wo + pos] = key16 >= (unsigned)WALL_CODE ? KEY_WALL + (key16 - WALL_CODE) : key16;
+                    g.ws_key[wo + pos] = key16 >= (unsigned)WALL_CODE ? KEY_WALL + (key16 - WALL_CODE)
+                                       : (key16 >= (unsigned)OBJ_CODE ? KEY_OBJ + (key16 - OBJ_CODE) : key16);
                     g.ws_acc[wo + pos] = racc[j];
                 }
             }
@@ -795,17 +956,32 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                 px[b] += h * vxx; py[b] += h * vyy;
                 th[q] += h * ww;
             }
+            if (tid < M) {   // objects: same integrator (b2Island writes the clamped velocity back to the body)
+                const int b = N + tid;
+                float vxx = vx[b], vyy = vy[b], ww = oww;
+                const float tx = h * vxx, ty = h * vyy;
+                if (tx * tx + ty * ty > B2_MAX_TRANSLATION_SQ) {
+                    const float ratio = B2_MAX_TRANSLATION / sqrtf(tx * tx + ty * ty);
+                    vxx *= ratio; vyy *= ratio;
+                }
+                const float rot = h * ww;
+                if (rot * rot > B2_MAX_ROTATION_SQ) ww *= B2_MAX_ROTATION / fabsf(rot);
+                vx[b] = vxx; vy[b] = vyy; oww = ww;
+                px[b] += h * vxx; py[b] += h * vyy;
+                oth += h * ww;
+            }
             __syncthreads();
             KB_STAMP(5);
             // SolvePositionConstraints; an island stops once its minSeparation >= -3 slop
             for (int it = 0; it < p.pos_iters; ++it) {
-                unsigned char *act = active + (it & 1) * NP, *nxt = active + ((it + 1) & 1) * NP;
+                unsigned char *act = active + (it & 1) * NB, *nxt = active + ((it + 1) & 1) * NB;
                 bool viol = false;
                 KB_REG_ROUNDS({
                     const int a = ra[j], b = rb[j];
                     const int isl = risl[j];
                     if (act[isl]) {
-                        float nx, ny, sep, ima = 0.0f;
+                        float nx, ny, sep;
+                        const float ima = R_IMA(j), imb = R_IMB(j);
                         const float bx = px[b], by = py[b];
                         float axx = 0.0f, ayy = 0.0f;
                         if (a >= WALL_CODE) {
@@ -813,22 +989,22 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                             wall_geom(p, a - WALL_CODE, bx, by, dist, wx, wy);
                             nx = rflip[j] ? -wx : wx; ny = rflip[j] ? -wy : wy;   // manifold normal fixed at detection
                             const float along = rflip[j] ? -dist : dist;
-                            sep = along - B2_POLYGON_RADIUS - p.r_bot;
+                            sep = along - R_RA(j) - R_RB(j);
                         } else {
-                            axx = px[a]; ayy = py[a]; ima = p.im_bot;
+                            axx = px[a]; ayy = py[a];
                             const float dx = bx - axx, dy = by - ayy;
                             const float len = sqrtf(dx * dx + dy * dy);
                             nx = dx; ny = dy;
                             if (!(len < B2_EPSILON)) { const float inv = 1.0f / len; nx = dx * inv; ny = dy * inv; }
-                            sep = (dx * nx + dy * ny) - p.r_bot - p.r_bot;
+                            sep = (dx * nx + dy * ny) - R_RA(j) - R_RB(j);
                         }
                         if (sep < -3.0f * B2_LINEAR_SLOP) { nxt[isl] = 1; viol = true; }
                         const float C = kb_clampf(B2_BAUMGARTE * (sep + B2_LINEAR_SLOP), -B2_MAX_LINEAR_CORRECTION, 0.0f);
-                        const float K = ima + p.im_bot;
+                        const float K = ima + imb;
                         const float imp = K > 0.0f ? -C / K : 0.0f;
                         const float Px = imp * nx, Py = imp * ny;
                         if (a < WALL_CODE) { px[a] = axx - ima * Px; py[a] = ayy - ima * Py; }
-                        px[b] = bx + p.im_bot * Px; py[b] = by + p.im_bot * Py;
+                        px[b] = bx + imb * Px; py[b] = by + imb * Py;
                     }
                 })
 #ifdef KB_PROFILE
@@ -841,6 +1017,11 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                 wave_sync();
             }
 #undef KB_REG_ROUNDS
+#undef R_IMA
+#undef R_IMB
+#undef R_RA
+#undef R_RB
+#undef R_NM
         } else {
             // =========================== list solver (staged contact arrays) ===========================
             auto solve_list = [&](unsigned *sPair, unsigned *sInfo, float *sAcc, unsigned short *cbk,
@@ -894,8 +1075,9 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                     KB_VEL_NORMAL(a, b, flip, nx, ny)
                     const float acc = sAcc[c];
                     const float Px = acc * nx, Py = acc * ny;
-                    if (a < WALL_CODE) { vx[a] -= p.im_bot * Px; vy[a] -= p.im_bot * Py; }
-                    vx[b] += p.im_bot * Px; vy[b] += p.im_bot * Py;
+                    const float ima = bim(a), imb = bim(b);
+                    if (a < WALL_CODE) { vx[a] -= ima * Px; vy[a] -= ima * Py; }
+                    vx[b] += imb * Px; vy[b] += imb * Py;
                 })
                 // SolveVelocityConstraints
                 for (int it = 0; it < p.vel_iters; ++it) {
@@ -904,12 +1086,14 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                         const int a = pr & 0xFFFF, b = pr >> 16;
                         const bool flip = (sInfo[c] & 0x80) != 0;
                         KB_VEL_NORMAL(a, b, flip, nx, ny)
-                        float vax = 0.0f, vay = 0.0f, ima = 0.0f;
-                        if (a < WALL_CODE) { vax = vx[a]; vay = vy[a]; ima = p.im_bot; }
+                        float vax = 0.0f, vay = 0.0f;
+                        const float ima = bim(a), imb = bim(b);
+                        if (a < WALL_CODE) { vax = vx[a]; vay = vy[a]; }
                         const float vbx = vx[b], vby = vy[b];
                         const float dvx = vbx - vax, dvy = vby - vay;
                         const float vn = dvx * nx + dvy * ny;
-                        const float nm = a < WALL_CODE ? nm_bb : nm_wb;
+                        const float k = ima + imb;
+                        const float nm = k > 0.0f ? 1.0f / k : 0.0f;
                         float lambda = -(nm * vn);
                         const float accOld = sAcc[c];
                         const float newimp = fmaxf(accOld + lambda, 0.0f);
@@ -917,7 +1101,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                         sAcc[c] = newimp;
                         const float Px = lambda * nx, Py = lambda * ny;
                         if (a < WALL_CODE) { vx[a] = vax - ima * Px; vy[a] = vay - ima * Py; }
-                        vx[b] = vbx + p.im_bot * Px; vy[b] = vby + p.im_bot * Py;
+                        vx[b] = vbx + imb * Px; vy[b] = vby + imb * Py;
                     })
                 }
                 __syncthreads();
@@ -931,13 +1115,15 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                     const unsigned pr = sPair[c];
                     const int a = pr & 0xFFFF, b = pr >> 16;
                     const int owner = a < WALL_CODE ? a : b;
-                    const unsigned key16 = a < WALL_CODE ? (unsigned)b : (unsigned)a;
+                    const float acc = sAcc[c];
+                    if (owner >= N) { owsNew[(owner - N) * OWS + sl] = acc; continue; }   // object-owned contact
+                    const unsigned key16 = a >= WALL_CODE ? (unsigned)a : (b >= N ? (unsigned)(OBJ_CODE + (b - N)) : (unsigned)b);
                     const unsigned pos = (unsigned)newOff[owner] + (unsigned)sl;
                     if (pos >= (unsigned)p.cap) continue;
-                    const float acc = sAcc[c];
                     if (newInLds) { oldKey[pos] = (unsigned short)key16; oldAcc[pos] = acc; }
                     if (last || !newInLds) {
-                        g.ws_key[wo + pos] = key16 >= (unsigned)WALL_CODE ? KEY_WALL + (key16 - WALL_CODE) : key16;
+                        g.ws_key[wo + pos] = key16 >= (unsigned)WALL_CODE ? KEY_WALL + (key16 - WALL_CODE)
+                                           : (key16 >= (unsigned)OBJ_CODE ? KEY_OBJ + (key16 - OBJ_CODE) : key16);
                         g.ws_acc[wo + pos] = acc;
                     }
                 }
@@ -960,18 +1146,33 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                     px[b] += h * vxx; py[b] += h * vyy;
                     th[q] += h * ww;
                 }
+                if (tid < M) {   // objects
+                    const int b = N + tid;
+                    float vxx = vx[b], vyy = vy[b], ww = oww;
+                    const float tx = h * vxx, ty = h * vyy;
+                    if (tx * tx + ty * ty > B2_MAX_TRANSLATION_SQ) {
+                        const float ratio = B2_MAX_TRANSLATION / sqrtf(tx * tx + ty * ty);
+                        vxx *= ratio; vyy *= ratio;
+                    }
+                    const float rot = h * ww;
+                    if (rot * rot > B2_MAX_ROTATION_SQ) ww *= B2_MAX_ROTATION / fabsf(rot);
+                    vx[b] = vxx; vy[b] = vyy; oww = ww;
+                    px[b] += h * vxx; py[b] += h * vyy;
+                    oth += h * ww;
+                }
                 __syncthreads();
                 KB_STAMP(5);
                 // SolvePositionConstraints; an island stops once its minSeparation >= -3 slop
                 for (int it = 0; it < p.pos_iters; ++it) {
-                    unsigned char *act = active + (it & 1) * NP, *nxt = active + ((it + 1) & 1) * NP;
+                    unsigned char *act = active + (it & 1) * NB, *nxt = active + ((it + 1) & 1) * NB;
                     bool viol = false;
                     KB_FOR_ROUNDS({
                         const unsigned pr = sPair[c];
                         const int a = pr & 0xFFFF, b = pr >> 16;
                         const int isl = (int)parent[b];
                         if (act[isl]) {
-                            float nx, ny, sep, ima = 0.0f;
+                            float nx, ny, sep;
+                            const float ima = bim(a), imb = bim(b), rda = brad(a), rdb = brad(b);
                             const float bx = px[b], by = py[b];
                             float axx = 0.0f, ayy = 0.0f;
                             if (a >= WALL_CODE) {
@@ -980,22 +1181,22 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                                 const bool flipped = (sInfo[c] & 0x80) != 0;   // manifold normal fixed at detection
                                 nx = flipped ? -wx : wx; ny = flipped ? -wy : wy;
                                 const float along = flipped ? -dist : dist;
-                                sep = along - B2_POLYGON_RADIUS - p.r_bot;
+                                sep = along - rda - rdb;
                             } else {
-                                axx = px[a]; ayy = py[a]; ima = p.im_bot;
+                                axx = px[a]; ayy = py[a];
                                 const float dx = bx - axx, dy = by - ayy;
                                 const float len = sqrtf(dx * dx + dy * dy);
                                 nx = dx; ny = dy;
                                 if (!(len < B2_EPSILON)) { const float inv = 1.0f / len; nx = dx * inv; ny = dy * inv; }
-                                sep = (dx * nx + dy * ny) - p.r_bot - p.r_bot;
+                                sep = (dx * nx + dy * ny) - rda - rdb;
                             }
                             if (sep < -3.0f * B2_LINEAR_SLOP) { nxt[isl] = 1; viol = true; }
                             const float C = kb_clampf(B2_BAUMGARTE * (sep + B2_LINEAR_SLOP), -B2_MAX_LINEAR_CORRECTION, 0.0f);
-                            const float K = ima + p.im_bot;
+                            const float K = ima + imb;
                             const float imp = K > 0.0f ? -C / K : 0.0f;
                             const float Px = imp * nx, Py = imp * ny;
                             if (a < WALL_CODE) { px[a] = axx - ima * Px; py[a] = ayy - ima * Py; }
-                            px[b] = bx + p.im_bot * Px; py[b] = by + p.im_bot * Py;
+                            px[b] = bx + imb * Px; py[b] = by + imb * Py;
                         }
                     })
                     bool any;
@@ -1025,6 +1226,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
         __syncthreads();
         // the new warm-start list becomes the old one
         for (int b = tid; b < NP; b += nt) { wsCnt[b] = wsCntNew[b]; wsOff[b] = newOff[b]; }
+        for (int k = tid; k < M * OWS; k += nt) owsOld[k] = owsNew[k];
         oldInLds = newInLds;
         oldTotal = newTotal;
         __syncthreads();
@@ -1041,6 +1243,12 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
             if (DRIVE_MODE == KB_DRIVE_ACCEL && p.n_substeps > 0 && drive) { g.v[o + b] = cv[q]; g.w[o + b] = cw[q]; }
         }
     }
+    if (tid < M && p.n_substeps > 0) {
+        const size_t oi = (size_t)e * M + tid;
+        g.ox[oi] = px[N + tid]; g.oy[oi] = py[N + tid]; g.otheta[oi] = oth;
+        g.ovx[oi] = vx[N + tid]; g.ovy[oi] = vy[N + tid]; g.ow[oi] = oww;
+    }
+    if (p.n_substeps > 0) for (int k = tid; k < M * OWS; k += nt) g.ows_acc[(size_t)e * MAXOBJ * OWS + k] = owsOld[k];
     if (tid == 0) {
         if (LIGHT_TYPE == KB_LIGHT_CIRCULAR && p.light_action && drive) { g.light_x[e] = lx; g.light_y[e] = ly; }
         if (misc[M_STATUS]) atomicOr(&g.status[e], (int)misc[M_STATUS]);
@@ -1105,7 +1313,10 @@ int kb_create(const kb_config *cfg, kb_sim **out) {
     if (!cfg || !out) return fail(KB_EINVAL, "kb_create: NULL argument");
     if (cfg->num_envs < 1 || cfg->num_bots < 1 || cfg->num_bots > KB_MAX_BOTS)
         return fail(KB_EINVAL, "kb_create: num_envs >= 1 and 1 <= num_bots <= 1024 required");
-    if (cfg->num_objects != 0) return fail(KB_EINVAL, "kb_create: objects are not supported by this version");
+    if (cfg->num_objects < 0 || cfg->num_objects > KB_MAX_OBJECTS) return fail(KB_EINVAL, "kb_create: 0 <= num_objects <= 8 required");
+    for (int m = 0; m < cfg->num_objects; ++m)
+        if (!(cfg->obj_radius[m] > 0.0f)) return fail(KB_EINVAL, "kb_create: obj_radius must be positive");
+    if (cfg->num_objects > 0 && !(cfg->obj_density > 0.0f)) return fail(KB_EINVAL, "kb_create: obj_density must be positive");
     if (cfg->drive_mode < 0 || cfg->drive_mode > KB_DRIVE_PHOTOTAXIS) return fail(KB_EINVAL, "kb_create: bad drive_mode");
     if (cfg->light_type != KB_LIGHT_NONE && cfg->light_type != KB_LIGHT_CIRCULAR)
         return fail(KB_EINVAL, "kb_create: unsupported light_type");
@@ -1154,9 +1365,19 @@ int kb_create(const kb_config *cfg, kb_sim **out) {
     long cap = (long)p.N * (p.N - 1) / 2 + 4L * p.N;
     if (cap > 2304) cap = 2304;
     if (cap < 4L * p.N + 64) cap = 4L * p.N + 64;
+    cap += 40L * cfg->num_objects;
     p.cap = (int)cap;
     p.capL = p.cap < CAP_LDS ? p.cap : CAP_LDS;
     p.NP = (p.N + 3) & ~3;
+    p.NB = p.NP + KB_MAX_OBJECTS;
+    p.M = cfg->num_objects;
+    for (int m = 0; m < KB_MAX_OBJECTS; ++m) {
+        p.r_obj[m] = cfg->obj_radius[m] * WORLD_SCALE;
+        const float mo = cfg->obj_density * B2_PI * p.r_obj[m] * p.r_obj[m];   // b2CircleShape::ComputeMass
+        p.im_obj[m] = mo > 0.0f ? 1.0f / mo : 0.0f;
+    }
+    p.kl_obj = 1.0f / (1.0f + p.h * cfg->obj_linear_damping);
+    p.ka_obj = 1.0f / (1.0f + p.h * cfg->obj_angular_damping);
     p.solver_mode = cfg->solver_mode;
     p.L = make_layout(p.NP, p.ncell, p.capL);
     if (p.L.total > 160 * 1024) {
@@ -1184,6 +1405,8 @@ int kb_bind(kb_sim *sim, const kb_buffers *b) {
         return fail(KB_ENOTBOUND, "kb_bind: motor_l, motor_r required");
     if (m == KB_DRIVE_PHOTOTAXIS && (!b->pt_threshold || !b->pt_update || !b->pt_nochange || !b->pt_dir))
         return fail(KB_ENOTBOUND, "kb_bind: pt_* buffers required in the phototaxis mode");
+    if (sim->cfg.num_objects > 0 && (!b->ox || !b->oy || !b->otheta || !b->ovx || !b->ovy || !b->ow || !b->ows_acc))
+        return fail(KB_ENOTBOUND, "kb_bind: ox, oy, otheta, ovx, ovy, ow and ows_acc are required when num_objects > 0");
     if (sim->cfg.light_type != KB_LIGHT_NONE && (!b->light_x || !b->light_y))
         return fail(KB_ENOTBOUND, "kb_bind: light_x, light_y required when a light is configured");
     if ((b->light_value != nullptr) != (b->light_gx != nullptr) || (b->light_value != nullptr) != (b->light_gy != nullptr))
@@ -1224,14 +1447,17 @@ int kb_step(kb_sim *sim, const float *d_actions, const float *d_light_action, in
     typedef void (*step_fn)(const Params);
     step_fn fn = nullptr;
     const bool lit = p.light_type == KB_LIGHT_CIRCULAR;
+    const bool obj = p.M > 0;
+#define KB_PICK(D, L) (obj ? kb_step_kernel<D, L, true> : kb_step_kernel<D, L, false>)
     switch (p.drive_mode) {
-    case KB_DRIVE_VELOCITY: fn = lit ? kb_step_kernel<KB_DRIVE_VELOCITY, KB_LIGHT_CIRCULAR> : kb_step_kernel<KB_DRIVE_VELOCITY, KB_LIGHT_NONE>; break;
-    case KB_DRIVE_ACCEL: fn = lit ? kb_step_kernel<KB_DRIVE_ACCEL, KB_LIGHT_CIRCULAR> : kb_step_kernel<KB_DRIVE_ACCEL, KB_LIGHT_NONE>; break;
-    case KB_DRIVE_MOTORS: fn = lit ? kb_step_kernel<KB_DRIVE_MOTORS, KB_LIGHT_CIRCULAR> : kb_step_kernel<KB_DRIVE_MOTORS, KB_LIGHT_NONE>; break;
-    case KB_DRIVE_SIMPLE_PHOTOTAXIS: fn = kb_step_kernel<KB_DRIVE_SIMPLE_PHOTOTAXIS, KB_LIGHT_CIRCULAR>; break;
-    case KB_DRIVE_PHOTOTAXIS: fn = kb_step_kernel<KB_DRIVE_PHOTOTAXIS, KB_LIGHT_CIRCULAR>; break;
+    case KB_DRIVE_VELOCITY: fn = lit ? KB_PICK(KB_DRIVE_VELOCITY, KB_LIGHT_CIRCULAR) : KB_PICK(KB_DRIVE_VELOCITY, KB_LIGHT_NONE); break;
+    case KB_DRIVE_ACCEL: fn = lit ? KB_PICK(KB_DRIVE_ACCEL, KB_LIGHT_CIRCULAR) : KB_PICK(KB_DRIVE_ACCEL, KB_LIGHT_NONE); break;
+    case KB_DRIVE_MOTORS: fn = lit ? KB_PICK(KB_DRIVE_MOTORS, KB_LIGHT_CIRCULAR) : KB_PICK(KB_DRIVE_MOTORS, KB_LIGHT_NONE); break;
+    case KB_DRIVE_SIMPLE_PHOTOTAXIS: fn = KB_PICK(KB_DRIVE_SIMPLE_PHOTOTAXIS, KB_LIGHT_CIRCULAR); break;
+    case KB_DRIVE_PHOTOTAXIS: fn = KB_PICK(KB_DRIVE_PHOTOTAXIS, KB_LIGHT_CIRCULAR); break;
     default: return fail(KB_EINVAL, "kb_step: bad drive mode");
     }
+#undef KB_PICK
     if (p.L.total > 64 * 1024 && !sim->attr_set) {
         hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, p.L.total);

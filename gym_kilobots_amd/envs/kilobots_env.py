@@ -150,7 +150,11 @@ class KilobotsEnv(object):
         if self._light is not None:
             l = torch.stack([self._sim.light_x, self._sim.light_y], -1).double().cpu().numpy()
             light = l[0] if self.num_envs == 1 else l
-        return {'kilobots': kb, 'objects': np.array([o.get_state() for o in self._objects]), 'light': light}
+        objs = np.array([o.get_state() for o in self._objects])
+        if self._objects:
+            op = self._sim.object_poses().double().cpu().numpy()
+            objs = op[0] if self.num_envs == 1 else op
+        return {'kilobots': kb, 'objects': objs, 'light': light}
 
     def get_observation(self):
         return self.get_state()
@@ -190,8 +194,12 @@ class KilobotsEnv(object):
         kbs = self._kilobots
         if len(kbs) == 0:
             raise ValueError('the configured scene has no kilobots')
-        if len(self._objects) != 0:
-            raise UnknownObjectException('pushable objects are not supported by this version of the HIP step')
+        from ..lib.body import Circle
+        for ob in self._objects:
+            if not isinstance(ob, Circle) or isinstance(ob, Kilobot):
+                raise UnknownObjectException('only circular pushable objects (lib.Circle) run on the device in this version')
+        if len(self._objects) > nat.MAX_OBJECTS:
+            raise UnknownObjectException('at most %d objects per env' % nat.MAX_OBJECTS)
         kinds = {type(k).drive_mode for k in kbs}
         if len(kinds) != 1:
             raise ValueError('all kilobots of an env must share one drive law (got %s)' % sorted(kinds))
@@ -205,6 +213,12 @@ class KilobotsEnv(object):
                          bot_density=float(type(kbs[0])._density), bot_radius=float(type(kbs[0])._radius),
                          bot_linear_damping=float(type(kbs[0])._linear_damping),
                          bot_angular_damping=float(type(kbs[0])._angular_damping))
+        if self._objects:
+            ob0 = type(self._objects[0])
+            radii = [float(ob._radius) for ob in self._objects] + [0.075] * (nat.MAX_OBJECTS - len(self._objects))
+            overrides.update(num_objects=len(self._objects), obj_radius=radii, obj_density=float(ob0._density),
+                             obj_friction=float(ob0._friction), obj_linear_damping=float(ob0._linear_damping),
+                             obj_angular_damping=float(ob0._angular_damping))
         if self._light is not None:
             if not isinstance(self._light, CircularGradientLight):
                 raise UnknownLightTypeException('only CircularGradientLight runs on the device in this version')
@@ -230,6 +244,10 @@ class KilobotsEnv(object):
         th = np.broadcast_to(poses[None, :, 2], (self.num_envs, N))
         sim.set_poses_m(xy, th)
         sim.status.zero_()
+        if self._objects:
+            op = np.array([ob._init_pose for ob in self._objects], dtype=np.float64)
+            sim.set_objects_m(np.broadcast_to(op[None, :, :2], (self.num_envs, len(self._objects), 2)),
+                              np.broadcast_to(op[None, :, 2], (self.num_envs, len(self._objects))))
         if mode in (nat.DRIVE_VELOCITY, nat.DRIVE_ACCEL):
             v0 = np.array([k._velocity for k in kbs], dtype=np.float32)
             sim.v.copy_(torch.from_numpy(np.broadcast_to(v0[None, :, 0], (self.num_envs, N)).copy()))

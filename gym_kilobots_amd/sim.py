@@ -62,6 +62,12 @@ class KilobotSim:
         self.ws_cnt = torch.zeros(E, N, dtype=torch.uint8, device=dev)
         self.scratch = torch.empty(self._lib.kb_scratch_bytes(self._h), dtype=torch.uint8, device=dev)
         self.status = torch.zeros(E, dtype=torch.int32, device=dev)
+        self.num_objects = M = self.cfg.num_objects
+        self.ox = self.oy = self.otheta = self.ovx = self.ovy = self.ow = self.ows_acc = None
+        if M > 0:
+            self.ox, self.oy, self.otheta = f(E, M), f(E, M), f(E, M)
+            self.ovx, self.ovy, self.ow = f(E, M), f(E, M), f(E, M)
+            self.ows_acc = torch.full((E, nat.MAX_OBJECTS, 12), -1.0, dtype=torch.float32, device=dev)
         self.light_value = self.light_gx = self.light_gy = None
         self.cmd_vx = self.cmd_vy = self.cmd_w = None
         if debug_outputs:
@@ -119,6 +125,26 @@ class KilobotSim:
     def forget_contacts(self):
         """Drop all warm-start impulses (bodies were re-created / teleported)."""
         self.ws_cnt.zero_()
+        if self.ows_acc is not None:
+            self.ows_acc.fill_(-1.0)
+
+    def set_objects_m(self, xy_m, theta=None):
+        """Object poses in metres / radians; objects start at rest (Body.__init__, body.py:32-38)."""
+        xy = np.asarray(xy_m, np.float64) * WORLD_SCALE
+        self.ox.copy_(torch.from_numpy(np.ascontiguousarray(xy[..., 0].astype(np.float32))).reshape(self.ox.shape))
+        self.oy.copy_(torch.from_numpy(np.ascontiguousarray(xy[..., 1].astype(np.float32))).reshape(self.oy.shape))
+        if theta is None:
+            self.otheta.zero_()
+        else:
+            self.otheta.copy_(torch.from_numpy(np.ascontiguousarray(np.asarray(theta, np.float32))).reshape(self.otheta.shape))
+        self.ovx.zero_()
+        self.ovy.zero_()
+        self.ow.zero_()
+        self.forget_contacts()
+
+    def object_poses(self):
+        """[num_envs, num_objects, 3] float32 (x [m], y [m], theta): get_state()['objects'] of every env."""
+        return torch.stack([self.ox / WORLD_SCALE, self.oy / WORLD_SCALE, self.otheta], -1)
 
     def poses(self):
         """[num_envs, num_bots, 3] float32 (x [m], y [m], theta): get_state()['kilobots'] of every env."""

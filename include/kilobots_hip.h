@@ -65,7 +65,7 @@ enum kb_light_type {
 
 /* Scene constants.  Defaults of the reference are given in brackets. */
 typedef struct kb_config {
-    int32_t num_envs, num_bots, num_objects;    /* objects: must be 0 in this version */
+    int32_t num_envs, num_bots, num_objects;    /* num_objects: 0..8 circular pushable bodies per env */
     float world_width, world_height;            /* metres [2.0, 1.5]   kilobots_env.py:19 */
     float dt;                                   /* [0.1]               kilobots_env.py:25,32 */
     int32_t vel_iters, pos_iters;               /* [10, 10]            kilobots_env.py:26-27 */
@@ -78,9 +78,9 @@ typedef struct kb_config {
     float light_act_lo[2], light_act_hi[2];     /* [-0.01, 0.01]       light.py:49-54 */
     float light_max_velocity;                   /* reserved (MomentumLight) */
     int32_t ws_slots;                           /* warm-start slots per bot [8] */
-    float obj_radius[KB_MAX_OBJECTS];           /* reserved (objects) */
-    float obj_density, obj_friction;
-    float obj_linear_damping, obj_angular_damping;
+    float obj_radius[KB_MAX_OBJECTS];           /* metres; Circle(radius=...), body.py:181-192 */
+    float obj_density, obj_friction;            /* [2, 0.01] body.py:11-12; friction is not modelled */
+    float obj_linear_damping, obj_angular_damping; /* [0.8, 0.8] body.py:15-16 */
     int32_t toi_walls;                          /* reserved */
     int32_t solver_mode;                        /* 0 = automatic.  Test knobs (results are identical in every mode):
                                                    1 list solver, one wave per island set; 2 list solver, whole
@@ -101,7 +101,7 @@ typedef struct kb_buffers {
     uint8_t *pt_dir;                    /* PHOTOTAXIS mode: 0 = 'left', 1 = 'right' */
     float *light_x, *light_y;           /* [num_envs], metres; required when light_type != NONE */
     float *light_vx, *light_vy;         /* reserved */
-    float *ox, *oy, *otheta, *ovx, *ovy, *ow; /* reserved (objects) */
+    float *ox, *oy, *otheta, *ovx, *ovy, *ow; /* objects: [num_envs][num_objects] pose (world units, radians) and body velocity */
     /* warm-start store (Box2D keeps the accumulated normal impulse in each b2Contact): per env a packed
      * list of kb_contact_capacity() entries, owner bots ascending, ws_cnt[bot] entries per owner */
     uint32_t *ws_key;                   /* required: [num_envs][kb_contact_capacity()] */
@@ -113,6 +113,8 @@ typedef struct kb_buffers {
                                            bit1 warm-start slot overflow, bit2 rank/cell overflow */
     void *scratch;                      /* required: kb_scratch_bytes() bytes; contact staging of envs whose
                                            contacts do not fit the LDS staging area (contents are transient) */
+    float *ows_acc;                     /* objects: [num_envs][8][12] warm-start impulses of object-object (column =
+                                           partner) and object-wall (column 8 + wall) contacts; < 0 = none */
 } kb_buffers;
 
 typedef struct kb_sim kb_sim;

@@ -23,6 +23,9 @@
  *   - arena walls are the four infinite lines of the closed chain loop of
  *     kilobots_env.py:46-51 with exact axis normals.
  *   - no sleeping (world is created with doSleep=True, kilobots_env.py:45).
+ *   - pushable objects are circles (body.py:181-192); their Coulomb friction against walls (mixed
+ *     coefficient sqrt(0.01 * 0.2)) and against each other (0.01) is not modelled, so contacts never
+ *     spin an object; kilobot contacts are frictionless in the reference too (kilobot.py:26).
  */
 #include "kb_oracle.h"
 
@@ -61,7 +64,10 @@
 #define CLS_NE 5
 #define CLS_NW 7
 #define CLS_WALL 9
-#define CLS_BOT_OBJ 10          /* + object index */
+#define CLS_BOT_OBJ 10          /* kilobot - object, group = object, sequential inside a group */
+#define CLS_OBJ_OBJ 11          /* object - object, pairs in lexicographic order */
+#define CLS_OBJ_WALL 12         /* object - wall, group = object */
+#define OWS 12                  /* object warm-start table: KBO_MAX_OBJECTS partner objects + 4 walls */
 
 /* ---- sin/cos: Cephes single-precision algorithm (public domain, S. Moshier), restated ---- */
 void kbo_sincosf(float xx, float *sp, float *cp) {
@@ -293,6 +299,40 @@ static void detect_env(const kbo_config *cfg, const derived_t *d, const kbo_stat
             nslot++;
             add_contact(w, -1 - wl, a, CLS_WALL, a, 0.0f, d->im_bot, B2_POLYGON_RADIUS, d->r_bot, acc, a, slot);
         }
+        /* pushable objects: b2CollideCircles kilobot - object */
+        for (int m = 0; m < w->M; ++m) {
+            float dx = w->px[N + m] - w->px[a], dy = w->py[N + m] - w->py[a];
+            float ro = d->r_bot + d->r_obj[m];
+            if (dx * dx + dy * dy > ro * ro) continue;
+            float acc = ws_lookup(st, w, e, a, KEY_OBJ + (unsigned)m);
+            if (acc < 0.0f) acc = 0.0f;
+            int slot = nslot < S ? nslot : -1;
+            if (slot < 0) w->status |= 2;
+            nslot++;
+            add_contact(w, a, N + m, CLS_BOT_OBJ, m, d->im_bot, d->im_obj[m], d->r_bot, d->r_obj[m], acc, a, slot);
+        }
+    }
+    /* object - object and object - wall; warm start from the per-object table ows_acc[m][partner | 8 + wall] */
+    for (int m = 0; m < w->M; ++m) {
+        for (int m2 = m + 1; m2 < w->M; ++m2) {
+            float dx = w->px[N + m2] - w->px[N + m], dy = w->py[N + m2] - w->py[N + m];
+            float ro = d->r_obj[m] + d->r_obj[m2];
+            if (dx * dx + dy * dy > ro * ro) continue;
+            float acc = st->ows_acc[((size_t)e * KBO_MAX_OBJECTS + m) * OWS + m2];
+            if (!(acc >= 0.0f)) acc = 0.0f;
+            add_contact(w, N + m, N + m2, CLS_OBJ_OBJ, 0, d->im_obj[m], d->im_obj[m2], d->r_obj[m], d->r_obj[m2], acc, N + m, m2);
+        }
+    }
+    for (int m = 0; m < w->M; ++m) {
+        for (int wl = 0; wl < 4; ++wl) {
+            float rwo = B2_POLYGON_RADIUS + d->r_obj[m];
+            float dist = wl == 0 ? w->px[N + m] - d->xmin : wl == 1 ? w->py[N + m] - d->ymin
+                       : wl == 2 ? d->xmax - w->px[N + m] : d->ymax - w->py[N + m];
+            if (dist * dist > rwo * rwo) continue;
+            float acc = st->ows_acc[((size_t)e * KBO_MAX_OBJECTS + m) * OWS + 8 + wl];
+            if (!(acc >= 0.0f)) acc = 0.0f;
+            add_contact(w, -1 - wl, N + m, CLS_OBJ_WALL, m, 0.0f, d->im_obj[m], B2_POLYGON_RADIUS, d->r_obj[m], acc, N + m, 8 + wl);
+        }
     }
     qsort(w->con, w->ncon, sizeof(contact_t), contact_cmp);
     (void)cfg;
@@ -319,6 +359,7 @@ static void world_step_env(const kbo_config *cfg, const derived_t *d, kbo_state 
         float kl = (cfg->drive_mode == KBO_DRIVE_SIMPLE_PHOTOTAXIS) ? 1.0f / (1.0f + h * 0.0f) : d->kl_bot;
         w->vx[b] *= kl; w->vy[b] *= kl; w->bw[b] *= d->ka_bot;
     }
+    for (int m = 0; m < w->M; ++m) { w->vx[N + m] *= d->kl_obj; w->vy[N + m] *= d->kl_obj; w->bw[N + m] *= d->ka_obj; }
 
     /* b2ContactSolver::InitializeVelocityConstraints: normals from current poses */
     for (int i = 0; i < w->ncon; ++i) {
@@ -364,9 +405,15 @@ static void world_step_env(const kbo_config *cfg, const derived_t *d, kbo_state 
     }
     /* StoreImpulses -> warm-start cache of the next substep */
     memset(st->ws_cnt + (size_t)e * N, 0, (size_t)N);
+    for (int m = 0; m < w->M; ++m)
+        for (int k = 0; k < OWS; ++k) st->ows_acc[((size_t)e * KBO_MAX_OBJECTS + m) * OWS + k] = -1.0f;
     for (int i = 0; i < w->ncon; ++i) {
         contact_t *c = &w->con[i];
-        if (c->slot < 0) continue;
+        if (c->owner >= N) st->ows_acc[((size_t)e * KBO_MAX_OBJECTS + (c->owner - N)) * OWS + c->slot] = c->acc;
+    }
+    for (int i = 0; i < w->ncon; ++i) {
+        contact_t *c = &w->con[i];
+        if (c->slot < 0 || c->owner >= N) continue;
         size_t ci = (size_t)e * N + c->owner;
         if (st->ws_cnt[ci] < c->slot + 1) st->ws_cnt[ci] = (uint8_t)(c->slot + 1);
     }
@@ -376,11 +423,11 @@ static void world_step_env(const kbo_config *cfg, const derived_t *d, kbo_state 
     }
     for (int i = 0; i < w->ncon; ++i) {
         contact_t *c = &w->con[i];
-        if (c->slot < 0) continue;
+        if (c->slot < 0 || c->owner >= N) continue;
         int pos = w->wnoff[c->owner] + c->slot;
         if (pos >= w->cap) continue;
         size_t idx = (size_t)e * w->cap + (size_t)pos;
-        unsigned key = c->a < 0 ? KEY_WALL + (unsigned)(-1 - c->a) : (unsigned)c->b;
+        unsigned key = c->a < 0 ? KEY_WALL + (unsigned)(-1 - c->a) : (c->b >= N ? KEY_OBJ + (unsigned)(c->b - N) : (unsigned)c->b);
         st->ws_key[idx] = key; st->ws_acc[idx] = c->acc;
     }
     /* integrate positions */
@@ -398,14 +445,30 @@ static void world_step_env(const kbo_config *cfg, const derived_t *d, kbo_state 
         w->px[b] += h * w->vx[b]; w->py[b] += h * w->vy[b];
         st->theta[(size_t)e * N + b] += h * w->bw[b];
     }
+    for (int m = 0; m < w->M; ++m) {
+        const int b = N + m;
+        float tx = h * w->vx[b], ty = h * w->vy[b];
+        if (tx * tx + ty * ty > B2_MAX_TRANSLATION_SQ) {
+            float ratio = B2_MAX_TRANSLATION / sqrtf(tx * tx + ty * ty);
+            w->vx[b] *= ratio; w->vy[b] *= ratio;
+        }
+        float rot = h * w->bw[b];
+        if (rot * rot > B2_MAX_ROTATION_SQ) {
+            float ratio = B2_MAX_ROTATION / fabsf(rot);
+            w->bw[b] *= ratio;
+        }
+        w->px[b] += h * w->vx[b]; w->py[b] += h * w->vy[b];
+        st->otheta[(size_t)e * w->M + m] += h * w->bw[b];
+    }
     /* islands (connected components over dynamic-dynamic contacts) for the per-island early-out */
-    for (int b = 0; b < N; ++b) { w->parent[b] = b; }
+    const int T = N + w->M;
+    for (int b = 0; b < T; ++b) { w->parent[b] = b; }
     for (int i = 0; i < w->ncon; ++i) if (w->con[i].a >= 0) uf_union(w->parent, w->con[i].a, w->con[i].b);
-    for (int b = 0; b < N; ++b) { w->parent[b] = uf_find(w->parent, b); w->active[b] = 1; }
+    for (int b = 0; b < T; ++b) { w->parent[b] = uf_find(w->parent, b); w->active[b] = 1; }
     /* SolvePositionConstraints, b2ContactSolver.cpp; per island: break when minSeparation >= -3 slop */
     for (int it = 0; it < cfg->pos_iters; ++it) {
         int any = 0;
-        memset(w->next_active, 0, (size_t)N);
+        memset(w->next_active, 0, (size_t)T);
         for (int i = 0; i < w->ncon; ++i) {
             contact_t *c = &w->con[i];
             int isl = w->parent[c->b];
@@ -432,7 +495,7 @@ static void world_step_env(const kbo_config *cfg, const derived_t *d, kbo_state 
             if (c->a >= 0) { w->px[c->a] -= c->ima * Px; w->py[c->a] -= c->ima * Py; }
             w->px[c->b] += c->imb * Px; w->py[c->b] += c->imb * Py;
         }
-        memcpy(w->active, w->next_active, (size_t)N);
+        memcpy(w->active, w->next_active, (size_t)T);
         if (!any) break;
     }
 }
@@ -515,8 +578,18 @@ static void substep_env(const kbo_config *cfg, const derived_t *d, kbo_state *st
         w->vx[b] = bvx; w->vy[b] = bvy; w->bw[b] = bw;
         if (st->cmd_vx) { st->cmd_vx[o + b] = bvx; st->cmd_vy[o + b] = bvy; st->cmd_w[o + b] = bw; }
     }
+    for (int m = 0; m < w->M; ++m) {   /* objects keep their velocities between substeps (plain b2Body) */
+        const size_t oi = (size_t)e * w->M + m;
+        w->px[N + m] = st->ox[oi]; w->py[N + m] = st->oy[oi];
+        w->vx[N + m] = st->ovx[oi]; w->vy[N + m] = st->ovy[oi]; w->bw[N + m] = st->ow[oi];
+    }
     world_step_env(cfg, d, st, e, w);
     for (int b = 0; b < N; ++b) { st->x[o + b] = w->px[b]; st->y[o + b] = w->py[b]; }
+    for (int m = 0; m < w->M; ++m) {
+        const size_t oi = (size_t)e * w->M + m;
+        st->ox[oi] = w->px[N + m]; st->oy[oi] = w->py[N + m];
+        st->ovx[oi] = w->vx[N + m]; st->ovy[oi] = w->vy[N + m]; st->ow[oi] = w->bw[N + m];
+    }
     if (st->status) st->status[e] |= w->status;
 }
 
@@ -526,6 +599,7 @@ int kbo_contact_capacity(const kbo_config *cfg) {
     long cap = N * (N - 1) / 2 + 4L * N;
     if (cap > 2304) cap = 2304;
     if (cap < 4L * N + 64) cap = 4L * N + 64;
+    cap += 40L * cfg->num_objects;
     return (int)cap;
 }
 
@@ -550,7 +624,8 @@ static void work_free(work_t *w) {
 
 int kbo_step(const kbo_config *cfg, kbo_state *st, const float *light_action, int n_substeps, int flags,
              int num_threads) {
-    if (!cfg || !st || cfg->num_bots < 1 || cfg->num_envs < 1 || cfg->num_objects != 0) return -1;
+    if (!cfg || !st || cfg->num_bots < 1 || cfg->num_envs < 1 || cfg->num_objects < 0 || cfg->num_objects > KBO_MAX_OBJECTS) return -1;
+    if (cfg->num_objects > 0 && (!st->ox || !st->oy || !st->otheta || !st->ovx || !st->ovy || !st->ow || !st->ows_acc)) return -1;
     derived_t d; derive(cfg, &d);
     int nt = num_threads > 1 ? num_threads : 1;
     int err = 0;
@@ -599,15 +674,22 @@ int kbo_set_actions(const kbo_config *cfg, kbo_state *st, const float *actions) 
     return 0;
 }
 
-int kbo_count_contacts(const kbo_config *cfg, const kbo_state *st, int env, int *n_botbot, int *n_wall) {
+int kbo_count_contacts(const kbo_config *cfg, const kbo_state *st, int env, int *n_botbot, int *n_wall, int *n_obj) {
     derived_t d; derive(cfg, &d);
     work_t w;
     if (work_alloc(&w, cfg, &d) != 0) return -2;
     const size_t o = (size_t)env * cfg->num_bots;
     for (int b = 0; b < cfg->num_bots; ++b) { w.px[b] = st->x[o + b]; w.py[b] = st->y[o + b]; }
+    for (int m = 0; m < cfg->num_objects; ++m) {
+        w.px[cfg->num_bots + m] = st->ox[(size_t)env * cfg->num_objects + m];
+        w.py[cfg->num_bots + m] = st->oy[(size_t)env * cfg->num_objects + m];
+    }
     detect_env(cfg, &d, st, env, &w);
     int nb = 0, nw = 0;
-    for (int i = 0; i < w.ncon; ++i) { if (w.con[i].a < 0) nw++; else nb++; }
+    for (int i = 0; i < w.ncon; ++i) { if (w.con[i].cls >= CLS_BOT_OBJ) continue; if (w.con[i].a < 0) nw++; else nb++; }
+    int no = 0;
+    for (int i = 0; i < w.ncon; ++i) if (w.con[i].cls >= CLS_BOT_OBJ) no++;
+    if (n_obj) *n_obj = no;
     if (n_botbot) *n_botbot = nb;
     if (n_wall) *n_wall = nw;
     int r = w.status;

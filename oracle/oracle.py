@@ -57,6 +57,7 @@ class State(C.Structure):
         ('light_value', _PF), ('light_gx', _PF), ('light_gy', _PF),
         ('cmd_vx', _PF), ('cmd_vy', _PF), ('cmd_w', _PF),
         ('status', _PI32),
+        ('ows_acc', _PF),
     ]
 
 
@@ -81,7 +82,7 @@ def lib():
         _lib.kbo_step.restype = C.c_int
         _lib.kbo_set_actions.argtypes = [C.POINTER(Config), C.POINTER(State), _PF]
         _lib.kbo_set_actions.restype = C.c_int
-        _lib.kbo_count_contacts.argtypes = [C.POINTER(Config), C.POINTER(State), C.c_int, _PI32, _PI32]
+        _lib.kbo_count_contacts.argtypes = [C.POINTER(Config), C.POINTER(State), C.c_int, _PI32, _PI32, _PI32]
         _lib.kbo_count_contacts.restype = C.c_int
         _lib.kbo_contact_capacity.argtypes = [C.POINTER(Config)]
         _lib.kbo_contact_capacity.restype = C.c_int
@@ -94,6 +95,8 @@ def default_config(num_envs, num_bots, drive_mode=DRIVE_VELOCITY, light_type=LIG
     """Reference defaults: kilobots_env.py:19,25-28; kilobot.py:9,25-30,214; body.py:11-16."""
     c = Config()
     c.num_envs, c.num_bots, c.num_objects = num_envs, num_bots, 0
+    for i in range(MAX_OBJECTS):
+        c.obj_radius[i] = 0.075
     c.world_width, c.world_height = 2.0, 1.5
     c.dt, c.vel_iters, c.pos_iters = 0.1, 10, 10
     c.drive_mode, c.light_type = drive_mode, light_type
@@ -143,6 +146,10 @@ class OracleSim:
         self.light_value, self.light_gx, self.light_gy = f(E, N), f(E, N), f(E, N)
         self.cmd_vx, self.cmd_vy, self.cmd_w = f(E, N), f(E, N), f(E, N)
         self.status = np.zeros(E, np.int32)
+        M = cfg.num_objects
+        self.ox, self.oy, self.otheta = f(E, M), f(E, M), f(E, M)
+        self.ovx, self.ovy, self.ow = f(E, M), f(E, M), f(E, M)
+        self.ows_acc = np.full((E, MAX_OBJECTS, 12), -1.0, np.float32)
         self._st = State()
         for name, _t in State._fields_:
             arr = getattr(self, name, None)
@@ -156,6 +163,7 @@ class OracleSim:
         self.y[...] = xy[..., 1].astype(np.float32)
         self.theta[...] = np.asarray(theta, np.float32)
         self.ws_cnt[...] = 0
+        self.ows_acc[...] = -1.0
 
     def poses_m(self):
         return np.stack([self.x.astype(np.float64) / WORLD_SCALE, self.y.astype(np.float64) / WORLD_SCALE,
@@ -173,10 +181,25 @@ class OracleSim:
                            None if la is None else la.ctypes.data_as(_PF), n_substeps, flags, threads)
         assert r == 0, r
 
-    def count_contacts(self, env=0):
-        nb, nw = C.c_int32(0), C.c_int32(0)
-        lib().kbo_count_contacts(C.byref(self.cfg), C.byref(self._st), env, C.byref(nb), C.byref(nw))
-        return nb.value, nw.value
+    def count_contacts(self, env=0, with_objects=False):
+        nb, nw, no = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        lib().kbo_count_contacts(C.byref(self.cfg), C.byref(self._st), env, C.byref(nb), C.byref(nw), C.byref(no))
+        return (nb.value, nw.value, no.value) if with_objects else (nb.value, nw.value)
+
+    def set_objects_m(self, xy_m, theta=None):
+        """Object poses in metres / radians, at rest (Body.__init__, body.py:32-38)."""
+        xy = np.asarray(xy_m, np.float64) * WORLD_SCALE
+        self.ox[...] = xy[..., 0].astype(np.float32)
+        self.oy[...] = xy[..., 1].astype(np.float32)
+        self.otheta[...] = 0.0 if theta is None else np.asarray(theta, np.float32)
+        self.ovx[...] = 0
+        self.ovy[...] = 0
+        self.ow[...] = 0
+        self.ows_acc[...] = -1.0
+
+    def objects_m(self):
+        return np.stack([self.ox.astype(np.float64) / WORLD_SCALE, self.oy.astype(np.float64) / WORLD_SCALE,
+                         self.otheta.astype(np.float64)], -1)
 
 
 def sincosf(x):

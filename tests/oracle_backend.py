@@ -16,7 +16,8 @@ class OracleBackend:
         self.drive_mode, self.light_type = drive_mode, light_type
         for name in ('x', 'y', 'theta', 'v', 'w', 'acc_v', 'acc_w', 'motor_l', 'motor_r', 'pt_threshold',
                      'pt_update', 'pt_nochange', 'pt_dir', 'light_x', 'light_y', 'ws_cnt', 'status',
-                     'light_value', 'light_gx', 'light_gy', 'cmd_vx', 'cmd_vy', 'cmd_w'):
+                     'light_value', 'light_gx', 'light_gy', 'cmd_vx', 'cmd_vy', 'cmd_w',
+                     'ox', 'oy', 'otheta', 'ovx', 'ovy', 'ow'):
             setattr(self, name, torch.from_numpy(getattr(self.o, name)))     # shares memory
         if drive_mode not in (O.DRIVE_MOTORS, O.DRIVE_PHOTOTAXIS):
             self.motor_l = self.motor_r = None
@@ -27,6 +28,13 @@ class OracleBackend:
 
     def forget_contacts(self):
         self.o.ws_cnt[...] = 0
+        self.o.ows_acc[...] = -1.0
+
+    def set_objects_m(self, xy, th=None):
+        self.o.set_objects_m(xy, th)
+
+    def object_poses(self):
+        return torch.from_numpy(self.o.objects_m().astype(np.float32))
 
     def poses(self):
         return torch.from_numpy(self.o.poses_m().astype(np.float32))

@@ -32,3 +32,23 @@ def random_actions(E, N, seed):
     rng = np.random.RandomState(seed)
     a = rng.uniform([0.0, -np.pi / 2], [0.01, np.pi / 2], size=(E, N, 2))
     return a.astype(np.float32)
+
+
+CFG4_OBJECTS = np.array([[0.5, 0.35], [-0.5, 0.35], [-0.5, -0.35], [0.5, -0.35]])
+CFG4_RADIUS = 0.075
+
+
+def cfg4_actions(xy, th_unused, seed):
+    """cfg4: half the bots (even ids) head for the nearest object at full speed, the rest act randomly.
+    Velocity-control actions cannot set the heading directly, so the chasers get omega towards the target."""
+    E, N, _ = xy.shape
+    a = random_actions(E, N, seed)
+    return a
+
+
+def toward_objects_theta(xy):
+    """Initial headings: even bots face their nearest cfg4 object, odd bots keep a seeded random heading."""
+    d = xy[:, :, None, :] - CFG4_OBJECTS[None, None]
+    k = np.argmin((d ** 2).sum(-1), axis=-1)
+    tgt = CFG4_OBJECTS[k]
+    return np.arctan2(tgt[..., 1] - xy[..., 1], tgt[..., 0] - xy[..., 0])

@@ -46,7 +46,7 @@ def test_create_validates_and_reports(lib):
     assert lib.kb_set_block_threads(h, 100) == nat.KB_EINVAL
     lib.kb_destroy(h)
     for bad in (dict(num_bots=0), dict(num_bots=nat.MAX_BOTS + 1), dict(num_envs=0), dict(dt=0.0),
-                dict(num_objects=1), dict(ws_slots=0)):
+                dict(num_objects=9), dict(ws_slots=0)):
         cfg = nat.default_config(1, 16)
         for k, v in bad.items():
             setattr(cfg, k, v)

@@ -122,6 +122,31 @@ def test_acceleration_env_state_has_five_columns():
     assert len(env.kilobots[0].get_state()) == 5
 
 
+def test_env_with_pushable_circles():
+    class PushEnv(DirectControlKilobotsEnv):
+        def _configure_environment(self):
+            self._add_object(Circle(world=self.world, radius=0.075, position=(0.2, 0.0)))
+            self._add_object(Circle(world=self.world, radius=0.05, position=(-0.3, 0.2), orientation=0.5))
+            for i in range(5):
+                self._add_kilobot(SimpleVelocityControlKilobot(self.world, position=(0.02, 0.035 * (i - 2)), velocity=[0.0, 0.0]))
+
+        def get_reward(self, state, action, new_state):
+            return float(new_state['objects'][0, 0] - state['objects'][0, 0])
+
+    env = PushEnv(sim_factory=OracleBackend)
+    obs = env.reset()
+    assert obs['objects'].shape == (2, 3) and len(env.objects) == 2
+    np.testing.assert_allclose(obs['objects'][1], (-0.3, 0.2, 0.5), atol=1e-6)
+    total = 0.0
+    for _ in range(15):
+        obs, r, done, info = env.step(np.tile([0.01, 0.0], (5, 1)))
+        total += r
+    assert total > 0.01 and obs['objects'][0, 0] > 0.21          # the kilobots pushed the disc along +x
+    np.testing.assert_allclose(env.objects[0].get_pose(), obs['objects'][0], atol=1e-6)
+    assert env.objects[0].get_radius() == 0.075 and env.objects[0].width == 0.15
+    assert env.kilobots[2].collides_with(env.objects[0]) in (True, None)
+
+
 def test_unsupported_scenes_fail_loudly():
     class MixedEnv(KilobotsEnv):
         def _configure_environment(self):

@@ -86,3 +86,37 @@ def test_env_permutation_and_thread_count_do_not_matter():
     s2.step(10, threads=4)
     s2.step(10, threads=2)
     assert np.array_equal(s1.x[perm], s2.x) and np.array_equal(s1.y[perm], s2.y) and np.array_equal(s1.theta[perm], s2.theta)
+
+
+# ---- pushable circular objects (BASELINE config 4) ------------------------------------------------
+def test_bot_pushes_object_head_on():
+    sim = O.OracleSim(O.default_config(1, 1, num_objects=1))
+    sim.set_poses_m(np.array([[[-0.12, 0.0]]]), np.array([[0.0]]))
+    sim.set_objects_m(np.array([[[0.0, 0.0]]]))
+    sim.set_actions(np.array([[[0.01, 0.0]]], np.float32))
+    for _ in range(200):
+        sim.step(1)
+    bot, obj = sim.poses_m()[0, 0], sim.objects_m()[0, 0]
+    assert obj[0] > 0.02 and abs(obj[1]) < 1e-7 and obj[2] == 0.0          # pushed along +x, never spun
+    assert abs((obj[0] - bot[0]) - (R + 0.075 - SLOP_M)) < 0.6 * SLOP_M     # resting contact distance
+    # momentum bookkeeping of the steady state: the object moves slower than a free kilobot (0.01 / 1.08)
+    v_obj = sim.ovx[0, 0] / 25
+    assert 0.001 < v_obj < 0.01 / 1.08
+    assert sim.count_contacts(0, True) == (0, 0, 1)
+
+
+def test_object_is_stopped_by_the_wall_and_by_another_object():
+    sim = O.OracleSim(O.default_config(1, 6, num_objects=2))
+    xy = np.array([[[0.55, 0.02 * (i - 2.5)] for i in range(6)]])
+    sim.set_poses_m(xy, np.zeros((1, 6)))
+    sim.set_objects_m(np.array([[[0.66, 0.0], [0.83, 0.0]]]))
+    sim.set_actions(np.tile([0.01, 0.0], (1, 6, 1)).astype(np.float32))
+    for _ in range(400):
+        sim.step(1)
+    o = sim.objects_m()[0]
+    # the far object rests against the right wall (x = 1 - r - skin + slop), the near one against it
+    assert abs(o[1, 0] - (1.0 - 0.075 - 0.01 / 25 + SLOP_M)) < 1.2 * SLOP_M
+    assert abs((o[1, 0] - o[0, 0]) - (0.15 - SLOP_M)) < 1.2 * SLOP_M
+    nb, nw, no = sim.count_contacts(0, True)
+    assert no >= 2          # object-object and object-wall (the bots slide off the disc eventually)
+    assert int(sim.status.max()) == 0
