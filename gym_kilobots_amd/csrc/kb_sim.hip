@@ -89,7 +89,7 @@ struct Layout {  // byte offsets into dynamic LDS
     int wsOff, newOff, oldKey, oldAcc;
     int sPair, sInfo, sAcc, cbk, order;
     int bkStart, bkFill, bkMaxRank, bkList;
-    int next, cellOf;
+    int next, cellOf, cellXY;
     int wsCnt, wsCntNew, active, nList;
     int objF, objCnt, objList, owsOld, owsNew;
     int total;
@@ -108,7 +108,7 @@ struct Params {
 };
 
 Layout make_layout(int NP, int ncell, int capL) {
-    const int NB = NP + KB_MAX_OBJECTS;   // bodies: kilobots, then objects at index N + m
+    const int NB = NP + KB_MAX_OBJECTS + 4;   // bodies: kilobots, then objects at index N + m; last slot = scratch body
     Layout L;
     int o = 0;
     auto take = [&](int bytes) { int r = o; o += (bytes + 15) & ~15; return r; };
@@ -120,7 +120,7 @@ Layout make_layout(int NP, int ncell, int capL) {
     L.cbk = take(2 * capL); L.order = take(2 * capL);
     L.bkStart = take(4 * (MAX_BUCKETS + 1)); L.bkFill = take(4 * MAX_BUCKETS);
     L.bkMaxRank = take(4 * MAX_WAVES * NUM_CLS); L.bkList = take(2 * MAX_BUCKETS);
-    L.next = take(2 * NP); L.cellOf = take(2 * NP);
+    L.next = take(2 * NP); L.cellOf = take(2 * NP); L.cellXY = take(4 * NP);
     L.wsCnt = take(NP); L.wsCntNew = take(NP); L.active = take(2 * NB); L.nList = take(16);
     L.objF = take(4 * 2 * KB_MAX_OBJECTS); L.objCnt = take(4 * KB_MAX_OBJECTS); L.objList = take(2 * KB_MAX_OBJECTS * 32);
     L.owsOld = take(4 * KB_MAX_OBJECTS * 12); L.owsNew = take(4 * KB_MAX_OBJECTS * 12);
@@ -275,6 +275,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
     unsigned *bkMaxRank = (unsigned *)(smem + p.L.bkMaxRank);
     unsigned short *bkList = (unsigned short *)(smem + p.L.bkList);
     unsigned short *nextb = (unsigned short *)(smem + p.L.next), *cellOf = (unsigned short *)(smem + p.L.cellOf);
+    unsigned *cellXY = (unsigned *)(smem + p.L.cellXY);   // cx | cy << 16 (saves the div / mod by the grid width)
     unsigned char *wsCnt = smem + p.L.wsCnt, *wsCntNew = smem + p.L.wsCntNew;
     unsigned char *active = smem + p.L.active, *nList = smem + p.L.nList;
     float *objIm = (float *)(smem + p.L.objF), *objR = objIm + MAXOBJ;   // inverse mass / radius of object m
@@ -298,7 +299,8 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
     unsigned short *gCbk = reinterpret_cast<unsigned short *>(gAcc + p.cap), *gOrder = gCbk + p.cap;
 
 #ifdef KB_PROFILE
-    long long prof_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long prof_acc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    constexpr int M_PROF_DEPTH = 12;
     long long prof_t = clock64();
 #endif
 
@@ -446,6 +448,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
             cy = cy < 0 ? 0 : (cy >= p.gh ? p.gh - 1 : cy);
             const int cell = cy * p.gw + cx;
             cellOf[b] = (unsigned short)cell;
+            cellXY[b] = (unsigned)cx | ((unsigned)cy << 16);
             nextb[b] = (unsigned short)atomicExch(&head[cell], (unsigned)b);
         }
         if (tid < M) {   // b2Island::Solve damping of the objects; they keep their velocity between substeps
@@ -463,8 +466,8 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
         auto find_pass = [&](unsigned *sPair, unsigned *sInfo, int stageCap_) __attribute__((always_inline)) {
 #pragma unroll 1
             for (int a = tid; a < N; a += nt) {
-                const int cell = cellOf[a];
-                const int cx = cell % p.gw, cy = cell / p.gw;
+                const unsigned cxy = cellXY[a];
+                const int cx = cxy & 0xFFFF, cy = cxy >> 16;
                 const float ax = px[a], ay = py[a];
                 unsigned cnt = 0, mine = 0;
 #pragma unroll
@@ -667,7 +670,8 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                     const int a = pr & 0xFFFF;
                     const unsigned b = pr >> 16;
                     const int cell = cellOf[a];
-                    const int cx = cell % p.gw, cy = cell / p.gw;
+                    const unsigned cxy = cellXY[a];
+                    const int cx = cxy & 0xFFFF, cy = cxy >> 16;
                     const float ax = px[a], ay = py[a];
                     if (k == 0) cls = CLS_SAME;
                     else if (k == 1) cls = CLS_E + (cx & 1);
@@ -760,6 +764,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
         auto bucket_sort = [&](const unsigned *sPair, const unsigned *sInfo, unsigned short *cbk,
                                unsigned short *order) __attribute__((always_inline)) {
             const int W = coop ? 1 : nw;
+            for (int b = tid; b < N + M; b += nt) islCnt[b] = 0;   // reused as per-body dependency depth by the register solver
             for (int k = tid; k < W * BK_PER_WAVE; k += nt) { bkStart[k] = 0; bkFill[k] = 0; }
             for (int k = tid; k < W * NUM_CLS; k += nt) bkMaxRank[k] = 0;
             if (tid == 0) bkStart[W * BK_PER_WAVE] = 0;
@@ -804,15 +809,28 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
             }
             __syncthreads();
         };
-        if (big) bucket_sort(gPair, gInfo, gCbk, gOrder); else bucket_sort(lPair, lInfo, lCbk, lOrder);
+        if (reg) {
+            // register solver: it only needs each wave's contacts grouped together (any order inside a wave)
+            for (int b = tid; b < N + M; b += nt) islCnt[b] = 0;   // reused as per-body dependency depth
+            if (tid < nw * NUM_CLS) bkMaxRank[tid] = 0;
+            for (int c = tid; c < ncon; c += nt) {
+                const unsigned w = parent[lPair[c] >> 16] % (unsigned)nw;
+                unsigned base = 0;
+                for (unsigned w2 = 0; w2 < w; ++w2) base += misc[M_WCNT + w2];
+                lOrder[base + atomicAdd(&misc[M_WFILL + w], 1u)] = (unsigned short)c;
+            }
+            __syncthreads();
+        } else if (big) bucket_sort(gPair, gInfo, gCbk, gOrder);
+        else bucket_sort(lPair, lInfo, lCbk, lOrder);
         KB_STAMP(3);
 
         if (reg) {
             // =========================== register-resident solver ===========================
             // wave w owns the contacts of the islands with root % nw == w; lane l holds contacts l, l+64, ...
-            const unsigned mybase = bkStart[wave * BK_PER_WAVE];
-            const unsigned mycnt = bkStart[(wave + 1) * BK_PER_WAVE] - mybase;
-            int ra[KREG], rb[KREG], rkey[KREG], rrank[KREG], rslot[KREG], risl[KREG];
+            unsigned mybase = 0;
+            for (int w = 0; w < wave; ++w) mybase += misc[M_WCNT + w];
+            const unsigned mycnt = misc[M_WCNT + wave];
+            int ra[KREG], rb[KREG], rkey[KREG], rrank[KREG], rslot[KREG], risl[KREG], rc[KREG], rdepth[KREG];
             float racc[KREG], rnx[KREG], rny[KREG], rima[KREG], rimb[KREG], rra[KREG], rrb[KREG], rnm[KREG];
             bool rvalid[KREG], rflip[KREG];
             unsigned mlo = 0, mhi = 0;
@@ -824,19 +842,127 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
 #define R_RA(j) (OBJ ? rra[j] : (ra[j] < WALL_CODE ? p.r_bot : B2_POLYGON_RADIUS))
 #define R_RB(j) (OBJ ? rrb[j] : p.r_bot)
 #define R_NM(j) (OBJ ? rnm[j] : (ra[j] < WALL_CODE ? nm_bb : nm_wb))
+            // ---- light load: bodies and key of the contacts of this wave, in arrival order ----
 #pragma unroll
             for (int j = 0; j < KREG; ++j) {
                 const unsigned idx = lane + 64u * j;
                 rvalid[j] = idx < mycnt;
-                ra[j] = 0; rb[j] = 0; rkey[j] = 0; rrank[j] = 0; rslot[j] = 255; risl[j] = 0;
-                racc[j] = 0.0f; rnx[j] = 1.0f; rny[j] = 0.0f; rflip[j] = false;
-                rima[j] = 0.0f; rimb[j] = 0.0f; rra[j] = 0.0f; rrb[j] = 0.0f; rnm[j] = 0.0f;
+                ra[j] = 0; rb[j] = 0; rkey[j] = 0; rrank[j] = 0; rc[j] = 0; rdepth[j] = 0;
                 if (rvalid[j]) {
                     const int c = lOrder[mybase + idx];
                     const unsigned pr = lPair[c], inf = lInfo[c];
-                    const int a = pr & 0xFFFF, b = pr >> 16;
                     const int cls = inf & 0x7F, r = (inf >> 8) & 0xFF;
-                    ra[j] = a; rb[j] = b; rrank[j] = r; rslot[j] = (inf >> 16) & 0xFF; racc[j] = lAcc[c];
+                    rc[j] = c; ra[j] = pr & 0xFFFF; rb[j] = pr >> 16; rrank[j] = r;
+                    const int key = cls * RK + (r < RK - 1 ? r : RK - 1);
+                    rkey[j] = key;
+                    if (key < 32) mlo |= 1u << key; else mhi |= 1u << (key - 32);
+                    if (r >= RK - 1) atomicMax(&bkMaxRank[wave * NUM_CLS + cls], (unsigned)r);
+                }
+            }
+            // keys present in this wave (wave-uniform 52-bit mask)
+            for (int d = 32; d >= 1; d >>= 1) { mlo |= __shfl_xor(mlo, d); mhi |= __shfl_xor(mhi, d); }
+            mlo = __builtin_amdgcn_readfirstlane(mlo); mhi = __builtin_amdgcn_readfirstlane(mhi);
+            const unsigned long long keymask = ((unsigned long long)mhi << 32) | mlo;
+            wave_sync();   // bkMaxRank of this wave
+#ifdef KB_PROFILE
+            if (tid == 0) { prof_acc[8] += __popcll(keymask); prof_acc[11] += 1; }
+#endif
+
+#define KB_REG_KEY_ROUNDS(...)                                                                      \
+            for (unsigned long long m_ = keymask; m_; m_ &= m_ - 1) {                               \
+                const int key_ = __builtin_ctzll(m_);                                               \
+                if ((key_ % RK) < RK - 1) {                                                         \
+                    _Pragma("unroll") for (int j = 0; j < KREG; ++j)                                \
+                        if (rvalid[j] && rkey[j] == key_) { __VA_ARGS__ }                           \
+                    wave_sync();                                                                    \
+                } else {                                                                            \
+                    const int maxr_ = (int)bkMaxRank[wave * NUM_CLS + key_ / RK];                   \
+                    for (int r_ = RK - 1; r_ <= maxr_; ++r_) {                                      \
+                        _Pragma("unroll") for (int j = 0; j < KREG; ++j)                            \
+                            if (rvalid[j] && rkey[j] == key_ && rrank[j] == r_) { __VA_ARGS__ }     \
+                        wave_sync();                                                                \
+                    }                                                                               \
+                }                                                                                   \
+            }
+
+            // ---- dependency depth of every contact: 1 + the depth of the latest earlier contact (canonical key
+            // order) on either of its bodies.  Contacts of equal depth never share a body, and sweeping by
+            // increasing depth keeps the relative order of any two contacts that do -- so depth rounds give exactly
+            // the result of the key-by-key sweep, in (typically) a third of the rounds. ----
+            unsigned *bodyDepth = islCnt;   // zeroed before the wave sort
+            KB_REG_KEY_ROUNDS({
+                const int a = ra[j], b = rb[j];
+                unsigned d = bodyDepth[b];
+                if (a < WALL_CODE) d = max(d, bodyDepth[a]);
+                d += 1u;
+                bodyDepth[b] = d;
+                if (a < WALL_CODE) bodyDepth[a] = d;
+                rdepth[j] = (int)d;
+            })
+            int maxD = 0;
+#pragma unroll
+            for (int j = 0; j < KREG; ++j) maxD = max(maxD, rdepth[j]);
+            for (int dd = 32; dd >= 1; dd >>= 1) maxD = max(maxD, __shfl_xor(maxD, dd));
+            maxD = __builtin_amdgcn_readfirstlane(maxD);
+            // ---- re-deal the contacts to the lanes level by level (a level never straddles two register slots
+            // if it fits one), so that a round executes the body for ONE slot instead of all KREG ----
+            unsigned slotMask[KREG];     // bit d: register slot j holds contacts of depth d
+#pragma unroll
+            for (int j = 0; j < KREG; ++j) slotMask[j] = 0xFFFFFFFFu;
+            if (maxD >= 1 && maxD <= 31 && p.capL >= nw * 64 * KREG) {
+                unsigned *lvlCnt = bkStart + wave * BK_PER_WAVE;    // (the bucket arrays are idle on this path)
+                unsigned *lvlStart = bkFill + wave * BK_PER_WAVE;
+                unsigned short *deal = lCbk + wave * 64 * KREG;
+                if (lane < 32) lvlCnt[lane] = 0;
+#pragma unroll
+                for (int j = 0; j < KREG; ++j) deal[lane + 64 * j] = EMPTY16;
+                wave_sync();
+                unsigned posIn[KREG];
+#pragma unroll
+                for (int j = 0; j < KREG; ++j) posIn[j] = rvalid[j] ? atomicAdd(&lvlCnt[rdepth[j]], 1u) : 0u;
+                wave_sync();
+                unsigned run = 0, sm[KREG];
+#pragma unroll
+                for (int j = 0; j < KREG; ++j) sm[j] = 0;
+                for (int d = 1; d <= maxD; ++d) {      // wave-uniform
+                    const unsigned n = lvlCnt[d];
+                    if (n <= 64u && (run & 63u) + n > 64u) run = (run + 63u) & ~63u;
+                    if (lane == 0) lvlStart[d] = run;
+#pragma unroll
+                    for (int j = 0; j < KREG; ++j)
+                        if (n > 0 && run < 64u * (j + 1) && run + n > 64u * j) sm[j] |= 1u << d;
+                    run += n;
+                }
+                if (run <= 64u * KREG) {
+                    wave_sync();
+#pragma unroll
+                    for (int j = 0; j < KREG; ++j)
+                        if (rvalid[j]) {
+                            deal[lvlStart[rdepth[j]] + posIn[j]] = (unsigned short)rc[j];
+                            lInfo[rc[j]] = (lInfo[rc[j]] & 0x00FFFFFFu) | ((unsigned)rdepth[j] << 24);
+                        }
+                    wave_sync();
+#pragma unroll
+                    for (int j = 0; j < KREG; ++j) {
+                        const unsigned c = deal[lane + 64 * j];
+                        rvalid[j] = c != EMPTY16;
+                        rc[j] = rvalid[j] ? (int)c : 0;
+                        rdepth[j] = rvalid[j] ? (int)(lInfo[rc[j]] >> 24) : 0;
+                        slotMask[j] = __builtin_amdgcn_readfirstlane(sm[j]);
+                    }
+                }
+            }
+            // ---- full load of the (re-dealt) contacts ----
+#pragma unroll
+            for (int j = 0; j < KREG; ++j) {
+                ra[j] = 0; rb[j] = 0; rslot[j] = 255; risl[j] = 0;
+                racc[j] = 0.0f; rnx[j] = 1.0f; rny[j] = 0.0f; rflip[j] = false;
+                rima[j] = 0.0f; rimb[j] = 0.0f; rra[j] = 0.0f; rrb[j] = 0.0f; rnm[j] = 0.0f;
+                if (rvalid[j]) {
+                    const int c = rc[j];
+                    const unsigned pr = lPair[c], inf = lInfo[c];
+                    const int a = pr & 0xFFFF, b = pr >> 16;
+                    ra[j] = a; rb[j] = b; rslot[j] = (inf >> 16) & 0xFF; racc[j] = lAcc[c];
                     rflip[j] = (inf & 0x80) != 0;
                     risl[j] = (int)parent[b];
                     if (OBJ) {
@@ -844,9 +970,6 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                         const float k_ = rima[j] + rimb[j];
                         rnm[j] = k_ > 0.0f ? 1.0f / k_ : 0.0f;   // b2ContactSolver normalMass
                     }
-                    const int key = cls * RK + (r < RK - 1 ? r : RK - 1);
-                    rkey[j] = key;
-                    if (key < 32) mlo |= 1u << key; else mhi |= 1u << (key - 32);
                     // velocity-phase normal from the start-of-step positions (b2WorldManifold::Initialize)
                     if (a >= WALL_CODE) {
                         float dist, nx, ny;
@@ -864,29 +987,18 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                     }
                 }
             }
-            // keys present in this wave (wave-uniform 40-bit mask)
-            for (int d = 32; d >= 1; d >>= 1) { mlo |= __shfl_xor(mlo, d); mhi |= __shfl_xor(mhi, d); }
-            mlo = __builtin_amdgcn_readfirstlane(mlo); mhi = __builtin_amdgcn_readfirstlane(mhi);
-            const unsigned long long keymask = ((unsigned long long)mhi << 32) | mlo;
 #ifdef KB_PROFILE
-            if (tid == 0) { prof_acc[8] += __popcll(keymask); prof_acc[9] += mycnt; prof_acc[11] += 1; }
+            if (lane == 0) atomicMax(&misc[M_PROF], (unsigned)maxD);
+            if (tid == 0) prof_acc[M_PROF_DEPTH] += maxD;
+            KB_STAMP(7);     // register load + depth sweep of wave 0 (no barrier: wave-local time)
 #endif
-
 #define KB_REG_ROUNDS(...)                                                                          \
-            for (unsigned long long m_ = keymask; m_; m_ &= m_ - 1) {                               \
-                const int key_ = __builtin_ctzll(m_);                                               \
-                if ((key_ % RK) < RK - 1) {                                                         \
-                    _Pragma("unroll") for (int j = 0; j < KREG; ++j)                                \
-                        if (rvalid[j] && rkey[j] == key_) { __VA_ARGS__ }                           \
-                    wave_sync();                                                                    \
-                } else {                                                                            \
-                    const int maxr_ = (int)bkMaxRank[wave * NUM_CLS + key_ / RK];                   \
-                    for (int r_ = RK - 1; r_ <= maxr_; ++r_) {                                      \
-                        _Pragma("unroll") for (int j = 0; j < KREG; ++j)                            \
-                            if (rvalid[j] && rkey[j] == key_ && rrank[j] == r_) { __VA_ARGS__ }     \
-                        wave_sync();                                                                \
+            for (int d_ = 1; d_ <= maxD; ++d_) {                                                    \
+                _Pragma("unroll") for (int j = 0; j < KREG; ++j)                                    \
+                    if ((slotMask[j] >> (d_ & 31)) & 1u) {                                          \
+                        if (rvalid[j] && rdepth[j] == d_) { __VA_ARGS__ }                           \
                     }                                                                               \
-                }                                                                                   \
+                wave_sync();                                                                        \
             }
 
             // b2ContactSolver::WarmStart
@@ -896,29 +1008,54 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                 if (a < WALL_CODE) { vx[a] -= R_IMA(j) * Px; vy[a] -= R_IMA(j) * Py; }
                 vx[b] += R_IMB(j) * Px; vy[b] += R_IMB(j) * Py;
             })
-            // SolveVelocityConstraints: friction 0, restitution 0, one manifold point
+            // SolveVelocityConstraints: friction 0, restitution 0, one manifold point.
+            // Branch-free rounds: slots that are not part of the current depth level work on a scratch body, so
+            // the LDS reads of all KREG slots are issued together (one LDS round trip per round).
+            const int DUMMY = NB - 1;
+            int iaS[KREG], ibS[KREG];
+#pragma unroll
+            for (int j = 0; j < KREG; ++j) {
+                iaS[j] = (rvalid[j] && ra[j] < WALL_CODE) ? ra[j] : DUMMY;
+                ibS[j] = rvalid[j] ? rb[j] : DUMMY;
+            }
             for (int it = 0; it < p.vel_iters; ++it) {
-                KB_REG_ROUNDS({
-                    const int a = ra[j], b = rb[j];
-                    const float nx = rnx[j], ny = rny[j];
-                    float vax = 0.0f, vay = 0.0f;
-                    const float ima = R_IMA(j), imb = R_IMB(j);
-                    if (a < WALL_CODE) { vax = vx[a]; vay = vy[a]; }
-                    const float vbx = vx[b], vby = vy[b];
-                    const float dvx = vbx - vax, dvy = vby - vay;
-                    const float vn = dvx * nx + dvy * ny;
-                    float lambda = -(R_NM(j) * vn);
-                    const float accOld = racc[j];
-                    const float newimp = fmaxf(accOld + lambda, 0.0f);
-                    lambda = newimp - accOld;
-                    racc[j] = newimp;
-                    const float Px = lambda * nx, Py = lambda * ny;
-                    if (a < WALL_CODE) { vx[a] = vax - ima * Px; vy[a] = vay - ima * Py; }
-                    vx[b] = vbx + imb * Px; vy[b] = vby + imb * Py;
-                })
+                for (int d_ = 1; d_ <= maxD; ++d_) {
+                    int ia[KREG], ib[KREG];
+                    float vax[KREG], vay[KREG], vbx[KREG], vby[KREG];
+#pragma unroll
+                    for (int j = 0; j < KREG; ++j) {
+                        if (!((slotMask[j] >> (d_ & 31)) & 1u)) continue;      // wave-uniform
+                        const bool on = rdepth[j] == d_;
+                        ia[j] = on ? iaS[j] : DUMMY; ib[j] = on ? ibS[j] : DUMMY;
+                        vax[j] = vx[ia[j]]; vay[j] = vy[ia[j]]; vbx[j] = vx[ib[j]]; vby[j] = vy[ib[j]];
+                    }
+#pragma unroll
+                    for (int j = 0; j < KREG; ++j) {
+                        if (!((slotMask[j] >> (d_ & 31)) & 1u)) continue;
+                        const bool on = rdepth[j] == d_;
+                        const bool wallA = ra[j] >= WALL_CODE;
+                        const float nx = rnx[j], ny = rny[j];
+                        const float ima = R_IMA(j), imb = R_IMB(j);
+                        const float ax_ = wallA ? 0.0f : vax[j], ay_ = wallA ? 0.0f : vay[j];
+                        const float dvx = vbx[j] - ax_, dvy = vby[j] - ay_;
+                        const float vn = dvx * nx + dvy * ny;
+                        float lambda = -(R_NM(j) * vn);
+                        const float accOld = racc[j];
+                        const float newimp = fmaxf(accOld + lambda, 0.0f);
+                        lambda = newimp - accOld;
+                        racc[j] = on ? newimp : accOld;
+                        const float Px = lambda * nx, Py = lambda * ny;
+                        vx[ia[j]] = ax_ - ima * Px; vy[ia[j]] = ay_ - ima * Py;
+                        vx[ib[j]] = vbx[j] + imb * Px; vy[ib[j]] = vby[j] + imb * Py;
+                    }
+                    wave_sync();
+                }
             }
             __syncthreads();
             KB_STAMP(4);
+#ifdef KB_PROFILE
+            if (tid == 0) prof_acc[9] += misc[M_PROF];   // deepest wave of the env (replaces the contacts-per-wave slot)
+#endif
             // StoreImpulses -> packed warm-start list of the next substep (LDS image and/or global)
             const bool last = sub == p.n_substeps - 1;
 #pragma unroll
@@ -1017,6 +1154,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                 wave_sync();
             }
 #undef KB_REG_ROUNDS
+#undef KB_REG_KEY_ROUNDS
 #undef R_IMA
 #undef R_IMB
 #undef R_RA
@@ -1254,8 +1392,8 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
         if (misc[M_STATUS]) atomicOr(&g.status[e], (int)misc[M_STATUS]);
 #ifdef KB_PROFILE
         prof_acc[7] += clock64() - prof_t;
-        for (int k = 0; k < 8; ++k) g.status[p.E + 12 * e + k] += (int)(prof_acc[k] >> 4);   // units of 16 cycles
-        for (int k = 8; k < 12; ++k) g.status[p.E + 12 * e + k] += (int)prof_acc[k];
+        for (int k = 0; k < 8; ++k) g.status[p.E + 13 * e + k] += (int)(prof_acc[k] >> 4);   // units of 16 cycles
+        for (int k = 8; k < 13; ++k) g.status[p.E + 13 * e + k] += (int)prof_acc[k];
 #endif
     }
 }
@@ -1369,7 +1507,7 @@ int kb_create(const kb_config *cfg, kb_sim **out) {
     p.cap = (int)cap;
     p.capL = p.cap < CAP_LDS ? p.cap : CAP_LDS;
     p.NP = (p.N + 3) & ~3;
-    p.NB = p.NP + KB_MAX_OBJECTS;
+    p.NB = p.NP + KB_MAX_OBJECTS + 4;
     p.M = cfg->num_objects;
     for (int m = 0; m < KB_MAX_OBJECTS; ++m) {
         p.r_obj[m] = cfg->obj_radius[m] * WORLD_SCALE;
