@@ -1,51 +1,72 @@
 """Build libkilobots_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
 
     python -m gym_kilobots_amd.build [--force]
+
+The kernel template is instantiated per drive law in separate translation units
+(csrc/kb_inst_d*.hip), compiled in parallel and linked with the C-ABI unit (csrc/kb_abi.hip).
 """
+import glob
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SRC = [os.path.join(HERE, 'csrc', 'kb_sim.hip')]
+CSRC = os.path.join(HERE, 'csrc')
 INC = os.path.join(ROOT, 'include')
 LIB = os.path.join(HERE, 'libkilobots_hip.so')
+PROF_LIB = os.path.join(HERE, 'libkilobots_hip_prof.so')
 
 # -ffp-contract=off: the step is specified as a sequence of individually rounded fp32 operations
 # (DESIGN.md); fused multiply-adds would make results depend on compiler scheduling.
-FLAGS = ['--offload-arch=gfx950', '-O3', '-ffp-contract=off', '-fno-fast-math', '-fPIC', '-shared', '-std=c++17']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-ffp-contract=off', '-fno-fast-math', '-fPIC', '-std=c++17']
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, '*.hip')))
+
+
+def needs_build(lib=LIB):
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
-    deps = SRC + [os.path.join(INC, 'kilobots_hip.h')]
+    t = os.path.getmtime(lib)
+    deps = sources() + glob.glob(os.path.join(CSRC, '*.h')) + [os.path.join(INC, 'kilobots_hip.h')]
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(args):
+    src, obj, extra, verbose = args
+    cmd = [os.environ.get('HIPCC', 'hipcc')] + FLAGS + extra + ['-I', INC, '-I', CSRC, '-c', src, '-o', obj]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    return obj
+
+
+def _build(lib, extra, tag, verbose):
+    objdir = os.path.join(HERE, '_obj', tag)
+    os.makedirs(objdir, exist_ok=True)
+    jobs = [(s, os.path.join(objdir, os.path.basename(s)[:-4] + '.o'), extra, verbose) for s in sources()]
+    with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
+        objs = list(ex.map(_compile, jobs))
+    cmd = [os.environ.get('HIPCC', 'hipcc'), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + objs
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    return lib
 
 
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
-    hipcc = os.environ.get('HIPCC', 'hipcc')
-    cmd = [hipcc] + FLAGS + ['-I', INC, '-o', LIB] + SRC
-    if verbose:
-        print(' '.join(cmd))
-    subprocess.check_call(cmd)
-    return LIB
+    return _build(LIB, [], 'rel', verbose)
 
 
 def build_profile(verbose=False):
     """Diagnostic build with in-kernel cycle stamps per phase (tools/phase_profile.py); never shipped
     as the product library: it writes its stamps behind the status buffer."""
-    hipcc = os.environ.get('HIPCC', 'hipcc')
-    out = os.path.join(HERE, 'libkilobots_hip_prof.so')
-    cmd = [hipcc] + FLAGS + ['-DKB_PROFILE', '-I', INC, '-o', out] + SRC
-    if verbose:
-        print(' '.join(cmd))
-    subprocess.check_call(cmd)
-    return out
+    return _build(PROF_LIB, ['-DKB_PROFILE'], 'prof', verbose)
 
 
 if __name__ == '__main__':

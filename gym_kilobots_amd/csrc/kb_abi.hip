@@ -1,0 +1,266 @@
+// kb_abi.hip -- batched Kilobot world step for MI355X (gfx950 / CDNA4) + its C ABI.
+//
+// One workgroup owns one env for the whole launch: positions are loaded once from HBM into LDS,
+// `n_substeps` iterations of the reference substep loop
+// (gym_kilobots/envs/kilobots_env.py:168-190) run out of LDS / registers, poses are written back once.
+// Per substep:
+//   drive law (kilobot.py:86-127,191-203,253-258,294-300,318-333) + light (light.py:59-75,176-189)
+//   -> broadphase: uniform grid of per-cell linked lists in LDS (one atomic exchange per bot)
+//   -> narrowphase: circle-circle / circle-wall (Box2D b2CollideCircles, b2CollideEdgeAndCircle),
+//      5-cell half stencil, warm-start impulses matched from the previous substep
+//   -> islands: lock-free union-find in LDS
+//   -> solver (b2ContactSolver semantics): warm start + 10 sequential-impulse velocity sweeps,
+//      symplectic Euler, <= 10 position sweeps with Box2D's per-island early out.
+// Gauss-Seidel order.  Every contact gets a key (class, rank): class from the relative grid position
+// of the two bodies and the parity of the base cell, rank from its position inside its cell-pair
+// group.  Two contacts with the same key never share a body, so all contacts of one key can be
+// solved concurrently and the result equals the sequential sweep in (class, group, A, B) order that
+// DESIGN.md specifies.  Islands are independent, so each island is bound to ONE wavefront
+// (root id mod #waves): a wave walks its own contacts key by key with no workgroup barrier at all
+// (LDS operations of one wave execute in order).  Only when one island is very large does the whole
+// workgroup cooperate on the sweep with s_barrier between keys.
+// No MFMA anywhere: this is LDS/latency- and HBM-bound integer/float work.
+//
+// Arithmetic: fp32, compiled with -ffp-contract=off; every expression is written in the operation
+// order of the specification so results do not depend on launch fusion, workgroup size or sharding.
+#include <new>
+
+#include "kb_common.h"
+
+using namespace kb;
+
+namespace {
+
+// set_action alone (kilobot.py:235-241, 283-289)
+__global__ void kb_set_actions_kernel(const Params p) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t T = (size_t)p.E * p.N;
+    if (i >= T) return;
+    float a0 = 0.0f, a1 = 0.0f;
+    if (p.actions) { const float2 a = reinterpret_cast<const float2 *>(p.actions)[i]; a0 = a.x; a1 = a.y; }
+    if (p.drive_mode == KB_DRIVE_VELOCITY) {
+        const float mw = 0.5f * 3.14159265358979323846f;
+        p.buf.v[i] = fmaxf(fminf(a0, 0.01f), 0.0f);
+        p.buf.w[i] = fmaxf(fminf(a1, mw), -mw);
+    } else {
+        const float aw = 0.2f * 3.14159265358979323846f;
+        p.buf.acc_v[i] = fmaxf(fminf(a0, 0.005f), -0.005f);
+        p.buf.acc_w[i] = fmaxf(fminf(a1, aw), -aw);
+    }
+}
+
+// Body.get_pose for every kilobot (body.py:63-65): metres, radians
+__global__ void kb_get_poses_kernel(const float *x, const float *y, const float *th, float *out, size_t T) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T) return;
+    out[3 * i + 0] = x[i] / WORLD_SCALE;
+    out[3 * i + 1] = y[i] / WORLD_SCALE;
+    out[3 * i + 2] = th[i];
+}
+
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, const char *detail = "") {
+    snprintf(g_err, sizeof(g_err), fmt, detail);
+    return code;
+}
+
+
+}  // namespace
+
+struct kb_sim {
+    kb_config cfg;
+    Params p;
+    bool bound;
+    bool attr_set;
+    int threads;
+};
+
+extern "C" {
+
+const char *kb_last_error(void) { return g_err; }
+const char *kb_version(void) { return "kilobots_hip 0.1 (gfx950)"; }
+
+int kb_create(const kb_config *cfg, kb_sim **out) {
+    if (!cfg || !out) return fail(KB_EINVAL, "kb_create: NULL argument");
+    if (cfg->num_envs < 1 || cfg->num_bots < 1 || cfg->num_bots > KB_MAX_BOTS)
+        return fail(KB_EINVAL, "kb_create: num_envs >= 1 and 1 <= num_bots <= 1024 required");
+    if (cfg->num_objects < 0 || cfg->num_objects > KB_MAX_OBJECTS) return fail(KB_EINVAL, "kb_create: 0 <= num_objects <= 8 required");
+    for (int m = 0; m < cfg->num_objects; ++m)
+        if (!(cfg->obj_radius[m] > 0.0f)) return fail(KB_EINVAL, "kb_create: obj_radius must be positive");
+    if (cfg->num_objects > 0 && !(cfg->obj_density > 0.0f)) return fail(KB_EINVAL, "kb_create: obj_density must be positive");
+    if (cfg->drive_mode < 0 || cfg->drive_mode > KB_DRIVE_PHOTOTAXIS) return fail(KB_EINVAL, "kb_create: bad drive_mode");
+    if (cfg->light_type != KB_LIGHT_NONE && cfg->light_type != KB_LIGHT_CIRCULAR)
+        return fail(KB_EINVAL, "kb_create: unsupported light_type");
+    if ((cfg->drive_mode == KB_DRIVE_SIMPLE_PHOTOTAXIS || cfg->drive_mode == KB_DRIVE_PHOTOTAXIS) &&
+        cfg->light_type == KB_LIGHT_NONE)
+        return fail(KB_EINVAL, "kb_create: phototaxis drive modes need a light");
+    if (cfg->ws_slots < 1 || cfg->ws_slots > 64) return fail(KB_EINVAL, "kb_create: 1 <= ws_slots <= 64 required");
+    if (cfg->solver_mode < 0 || cfg->solver_mode > 4) return fail(KB_EINVAL, "kb_create: solver_mode must be 0..4");
+    if (!(cfg->dt > 0.0f) || cfg->vel_iters < 0 || cfg->pos_iters < 0 || !(cfg->world_width > 0.0f) ||
+        !(cfg->world_height > 0.0f) || !(cfg->bot_radius > 0.0f) || !(cfg->bot_density > 0.0f))
+        return fail(KB_EINVAL, "kb_create: non-positive dt / size / radius / density");
+    kb_sim *s = new (std::nothrow) kb_sim();
+    if (!s) return fail(KB_EINVAL, "kb_create: out of host memory");
+    s->cfg = *cfg;
+    s->bound = false;
+    s->attr_set = false;
+    Params &p = s->p;
+    memset(&p, 0, sizeof(p));
+    p.N = cfg->num_bots; p.E = cfg->num_envs; p.S = cfg->ws_slots;
+    p.drive_mode = cfg->drive_mode; p.light_type = cfg->light_type;
+    p.vel_iters = cfg->vel_iters; p.pos_iters = cfg->pos_iters;
+    const float W = cfg->world_width * WORLD_SCALE, H = cfg->world_height * WORLD_SCALE;
+    p.xmin = -0.5f * W; p.xmax = 0.5f * W; p.ymin = -0.5f * H; p.ymax = 0.5f * H;
+    float cell = CELL_SIZE;
+    const float dmin = 2.0f * cfg->bot_radius * WORLD_SCALE;
+    while (cell < dmin) cell *= 2.0f;
+    for (;;) {
+        p.inv_cell = 1.0f / cell;
+        p.gw = (int)ceilf(W * p.inv_cell); if (p.gw < 1) p.gw = 1;
+        p.gh = (int)ceilf(H * p.inv_cell); if (p.gh < 1) p.gh = 1;
+        if ((long)p.gw * p.gh <= MAX_CELLS) break;
+        cell *= 2.0f;
+    }
+    p.ncell = p.gw * p.gh;
+    p.h = cfg->dt;
+    p.r_bot = cfg->bot_radius * WORLD_SCALE;
+    const float m = cfg->bot_density * B2_PI * p.r_bot * p.r_bot;  // b2CircleShape::ComputeMass
+    p.im_bot = m > 0.0f ? 1.0f / m : 0.0f;
+    p.kl_bot = 1.0f / (1.0f + p.h * cfg->bot_linear_damping);
+    p.ka_bot = 1.0f / (1.0f + p.h * cfg->bot_angular_damping);
+    p.light_radius = cfg->light_radius;
+    for (int i = 0; i < 2; ++i) {
+        p.light_lo[i] = cfg->light_lo[i]; p.light_hi[i] = cfg->light_hi[i];
+        p.act_lo[i] = cfg->light_act_lo[i]; p.act_hi[i] = cfg->light_act_hi[i];
+    }
+    long cap = (long)p.N * (p.N - 1) / 2 + 4L * p.N;
+    if (cap > 2304) cap = 2304;
+    if (cap < 4L * p.N + 64) cap = 4L * p.N + 64;
+    cap += 40L * cfg->num_objects;
+    p.cap = (int)cap;
+    p.capL = p.cap < CAP_LDS ? p.cap : CAP_LDS;
+    p.NP = (p.N + 3) & ~3;
+    p.NB = p.NP + KB_MAX_OBJECTS + 4;
+    p.M = cfg->num_objects;
+    for (int m = 0; m < KB_MAX_OBJECTS; ++m) {
+        p.r_obj[m] = cfg->obj_radius[m] * WORLD_SCALE;
+        const float mo = cfg->obj_density * B2_PI * p.r_obj[m] * p.r_obj[m];   // b2CircleShape::ComputeMass
+        p.im_obj[m] = mo > 0.0f ? 1.0f / mo : 0.0f;
+    }
+    p.kl_obj = 1.0f / (1.0f + p.h * cfg->obj_linear_damping);
+    p.ka_obj = 1.0f / (1.0f + p.h * cfg->obj_angular_damping);
+    p.solver_mode = cfg->solver_mode;
+    p.L = make_layout(p.NP, p.ncell, p.capL);
+    if (p.L.total > 160 * 1024) {
+        delete s;
+        return fail(KB_ELDS, "kb_create: configuration needs more than 160 KiB of LDS per env");
+    }
+    s->threads = ((p.N + BPT - 1) / BPT + 63) & ~63;   // N <= BPT * threads
+    if (s->threads < 64) s->threads = 64;
+    if (s->threads > 64 * MAX_WAVES) { delete s; return fail(KB_EINVAL, "kb_create: num_bots exceeds bots-per-thread x workgroup size of this build"); }
+    *out = s;
+    return KB_OK;
+}
+
+void kb_destroy(kb_sim *sim) { delete sim; }
+
+int kb_bind(kb_sim *sim, const kb_buffers *b) {
+    if (!sim || !b) return fail(KB_EINVAL, "kb_bind: NULL argument");
+    if (!b->x || !b->y || !b->theta || !b->ws_key || !b->ws_acc || !b->ws_cnt || !b->status || !b->scratch)
+        return fail(KB_ENOTBOUND, "kb_bind: x, y, theta, ws_key, ws_acc, ws_cnt, status and scratch are required");
+    const int m = sim->cfg.drive_mode;
+    if ((m == KB_DRIVE_VELOCITY || m == KB_DRIVE_ACCEL) && (!b->v || !b->w))
+        return fail(KB_ENOTBOUND, "kb_bind: v and w are required in the velocity / acceleration modes");
+    if (m == KB_DRIVE_ACCEL && (!b->acc_v || !b->acc_w)) return fail(KB_ENOTBOUND, "kb_bind: acc_v, acc_w required");
+    if ((m == KB_DRIVE_MOTORS || m == KB_DRIVE_PHOTOTAXIS) && (!b->motor_l || !b->motor_r))
+        return fail(KB_ENOTBOUND, "kb_bind: motor_l, motor_r required");
+    if (m == KB_DRIVE_PHOTOTAXIS && (!b->pt_threshold || !b->pt_update || !b->pt_nochange || !b->pt_dir))
+        return fail(KB_ENOTBOUND, "kb_bind: pt_* buffers required in the phototaxis mode");
+    if (sim->cfg.num_objects > 0 && (!b->ox || !b->oy || !b->otheta || !b->ovx || !b->ovy || !b->ow || !b->ows_acc))
+        return fail(KB_ENOTBOUND, "kb_bind: ox, oy, otheta, ovx, ovy, ow and ows_acc are required when num_objects > 0");
+    if (sim->cfg.light_type != KB_LIGHT_NONE && (!b->light_x || !b->light_y))
+        return fail(KB_ENOTBOUND, "kb_bind: light_x, light_y required when a light is configured");
+    if ((b->light_value != nullptr) != (b->light_gx != nullptr) || (b->light_value != nullptr) != (b->light_gy != nullptr))
+        return fail(KB_EINVAL, "kb_bind: light_value, light_gx, light_gy must be given together");
+    if ((b->cmd_vx != nullptr) != (b->cmd_vy != nullptr) || (b->cmd_vx != nullptr) != (b->cmd_w != nullptr))
+        return fail(KB_EINVAL, "kb_bind: cmd_vx, cmd_vy, cmd_w must be given together");
+    sim->p.buf = *b;
+    sim->bound = true;
+    return KB_OK;
+}
+
+int kb_set_actions(kb_sim *sim, const float *d_actions, void *stream) {
+    if (!sim) return fail(KB_EINVAL, "kb_set_actions: NULL handle");
+    if (!sim->bound) return fail(KB_ENOTBOUND, "kb_set_actions: kb_bind() first");
+    if (sim->cfg.drive_mode != KB_DRIVE_VELOCITY && sim->cfg.drive_mode != KB_DRIVE_ACCEL)
+        return fail(KB_EINVAL, "kb_set_actions: only the velocity / acceleration drive modes take actions");
+    Params p = sim->p;
+    p.actions = d_actions;
+    const size_t T = (size_t)p.E * p.N;
+    hipLaunchKernelGGL(kb_set_actions_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return fail(KB_EHIP, "kb_set_actions: %s", hipGetErrorString(err));
+    return KB_OK;
+}
+
+int kb_step(kb_sim *sim, const float *d_actions, const float *d_light_action, int n_substeps, int flags, void *stream) {
+    if (!sim) return fail(KB_EINVAL, "kb_step: NULL handle");
+    if (!sim->bound) return fail(KB_ENOTBOUND, "kb_step: kb_bind() first");
+    if (n_substeps < 0) return fail(KB_EINVAL, "kb_step: n_substeps < 0");
+    if (d_actions && sim->cfg.drive_mode != KB_DRIVE_VELOCITY && sim->cfg.drive_mode != KB_DRIVE_ACCEL)
+        return fail(KB_EINVAL, "kb_step: only the velocity / acceleration drive modes take actions");
+    if (n_substeps == 0 && !d_actions) return KB_OK;
+    Params p = sim->p;
+    p.actions = d_actions;
+    p.light_action = d_light_action;
+    p.n_substeps = n_substeps;
+    p.flags = flags;
+    const bool obj = p.M > 0;
+    kb_step_fn fn = nullptr;
+    switch (p.drive_mode) {
+    case KB_DRIVE_VELOCITY: fn = kb_pick_velocity(p.light_type, obj); break;
+    case KB_DRIVE_ACCEL: fn = kb_pick_accel(p.light_type, obj); break;
+    case KB_DRIVE_MOTORS: fn = kb_pick_motors(p.light_type, obj); break;
+    case KB_DRIVE_SIMPLE_PHOTOTAXIS: fn = kb_pick_simple_phototaxis(p.light_type, obj); break;
+    case KB_DRIVE_PHOTOTAXIS: fn = kb_pick_phototaxis(p.light_type, obj); break;
+    default: break;
+    }
+    if (!fn) return fail(KB_EINVAL, "kb_step: no kernel for this drive mode / light type");
+    if (p.L.total > 64 * 1024 && !sim->attr_set) {
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, p.L.total);
+        if (e2 != hipSuccess) return fail(KB_EHIP, "kb_step: hipFuncSetAttribute: %s", hipGetErrorString(e2));
+        sim->attr_set = true;
+    }
+    hipLaunchKernelGGL(fn, dim3((unsigned)p.E), dim3((unsigned)sim->threads), (size_t)p.L.total,
+                       (hipStream_t)stream, p);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return fail(KB_EHIP, "kb_step: %s", hipGetErrorString(err));
+    return KB_OK;
+}
+
+int kb_get_poses(kb_sim *sim, float *d_out, void *stream) {
+    if (!sim || !d_out) return fail(KB_EINVAL, "kb_get_poses: NULL argument");
+    if (!sim->bound) return fail(KB_ENOTBOUND, "kb_get_poses: kb_bind() first");
+    const size_t T = (size_t)sim->p.E * sim->p.N;
+    hipLaunchKernelGGL(kb_get_poses_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       sim->p.buf.x, sim->p.buf.y, sim->p.buf.theta, d_out, T);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return fail(KB_EHIP, "kb_get_poses: %s", hipGetErrorString(err));
+    return KB_OK;
+}
+
+int kb_lds_bytes(const kb_sim *sim) { return sim ? sim->p.L.total : KB_EINVAL; }
+size_t kb_scratch_bytes(const kb_sim *sim) { return sim ? (size_t)sim->p.E * (size_t)sim->p.cap * 16u : 0; }
+int kb_contact_capacity(const kb_sim *sim) { return sim ? sim->p.cap : KB_EINVAL; }
+int kb_block_threads(const kb_sim *sim) { return sim ? sim->threads : KB_EINVAL; }
+int kb_set_block_threads(kb_sim *sim, int threads) {
+    if (!sim || threads < 64 || threads > 64 * MAX_WAVES || (threads & 63)) return fail(KB_EINVAL, "kb_set_block_threads: multiple of 64 up to the build maximum");
+    if (sim->p.N > BPT * threads) return fail(KB_EINVAL, "kb_set_block_threads: need num_bots <= bots-per-thread x threads");
+    sim->threads = threads;
+    return KB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,261 @@
+// kb_sim.hip -- batched Kilobot world step for MI355X (gfx950 / CDNA4) + its C ABI.
+//
+// One workgroup owns one env for the whole launch: positions are loaded once from HBM into LDS,
+// `n_substeps` iterations of the reference substep loop
+// (gym_kilobots/envs/kilobots_env.py:168-190) run out of LDS / registers, poses are written back once.
+// Per substep:
+//   drive law (kilobot.py:86-127,191-203,253-258,294-300,318-333) + light (light.py:59-75,176-189)
+//   -> broadphase: uniform grid of per-cell linked lists in LDS (one atomic exchange per bot)
+//   -> narrowphase: circle-circle / circle-wall (Box2D b2CollideCircles, b2CollideEdgeAndCircle),
+//      5-cell half stencil, warm-start impulses matched from the previous substep
+//   -> islands: lock-free union-find in LDS
+//   -> solver (b2ContactSolver semantics): warm start + 10 sequential-impulse velocity sweeps,
+//      symplectic Euler, <= 10 position sweeps with Box2D's per-island early out.
+// Gauss-Seidel order.  Every contact gets a key (class, rank): class from the relative grid position
+// of the two bodies and the parity of the base cell, rank from its position inside its cell-pair
+// group.  Two contacts with the same key never share a body, so all contacts of one key can be
+// solved concurrently and the result equals the sequential sweep in (class, group, A, B) order that
+// DESIGN.md specifies.  Islands are independent, so each island is bound to ONE wavefront
+// (root id mod #waves): a wave walks its own contacts key by key with no workgroup barrier at all
+// (LDS operations of one wave execute in order).  Only when one island is very large does the whole
+// workgroup cooperate on the sweep with s_barrier between keys.
+// No MFMA anywhere: this is LDS/latency- and HBM-bound integer/float work.
+//
+// Arithmetic: fp32, compiled with -ffp-contract=off; every expression is written in the operation
+// order of the specification so results do not depend on launch fusion, workgroup size or sharding.
+// kb_common.h -- constants, kernel parameters, LDS layout and device helpers shared by the translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "kilobots_hip.h"
+
+namespace kb {
+
+// ---- Box2D 2.3.1 constants (b2Settings.h) ---------------------------------------------------
+constexpr float B2_PI = 3.14159265359f;
+constexpr float B2_LINEAR_SLOP = 0.005f;
+constexpr float B2_POLYGON_RADIUS = 2.0f * B2_LINEAR_SLOP;
+constexpr float B2_BAUMGARTE = 0.2f;
+constexpr float B2_MAX_LINEAR_CORRECTION = 0.2f;
+constexpr float B2_MAX_TRANSLATION = 2.0f;
+constexpr float B2_MAX_TRANSLATION_SQ = B2_MAX_TRANSLATION * B2_MAX_TRANSLATION;
+constexpr float B2_MAX_ROTATION = 0.5f * B2_PI;
+constexpr float B2_MAX_ROTATION_SQ = B2_MAX_ROTATION * B2_MAX_ROTATION;
+constexpr float B2_EPSILON = 1.19209290e-07f;
+constexpr float WORLD_SCALE = 25.0f;  // body.py:7
+
+constexpr float CELL_SIZE = 0.875f;   // world units, >= 2 * bot radius
+constexpr int MAX_CELLS = 8192;
+
+constexpr unsigned KEY_WALL = 0x10000u, KEY_OBJ = 0x20000u;
+constexpr int WALL_CODE = 0xFFF0;     // body id of wall w is WALL_CODE + w
+constexpr int OBJ_CODE = 0xFFE0;      // 16-bit warm-start key of object m (its body id is N + m)
+constexpr int MAXOBJ = KB_MAX_OBJECTS, OWS = 12, OBJ_LIST = 32;
+constexpr unsigned EMPTY32 = 0xFFFFFFFFu;
+constexpr unsigned short EMPTY16 = 0xFFFFu;
+
+// contact classes in canonical order; +1 on E/N/NE/NW for odd base-cell parity
+constexpr int CLS_SAME = 0, CLS_E = 1, CLS_N = 3, CLS_NE = 5, CLS_NW = 7, CLS_WALL = 9,
+              CLS_BOT_OBJ = 10, CLS_OBJ_OBJ = 11, CLS_OBJ_WALL = 12, NUM_CLS = 13;
+constexpr int RK = 4;                 // rank buckets per class; the last one holds every rank >= RK-1
+#ifndef KB_MAX_WAVES
+#define KB_MAX_WAVES 8
+#endif
+#ifndef KB_BPT
+#define KB_BPT 2
+#endif
+#ifndef KB_KREG
+#define KB_KREG 2
+#endif
+#ifndef KB_MIN_WAVES_PER_SIMD
+#define KB_MIN_WAVES_PER_SIMD 4
+#endif
+constexpr int MAX_WAVES = KB_MAX_WAVES;   // waves per workgroup
+constexpr int BK_PER_WAVE = NUM_CLS * RK;
+constexpr int MAX_BUCKETS = MAX_WAVES * BK_PER_WAVE;
+constexpr int BPT = KB_BPT;                // bots per thread (max): N <= BPT * blockDim.x
+constexpr int GIANT_ISLAND = 256;     // contacts; larger islands are swept by the whole workgroup
+constexpr int KREG = KB_KREG;               // contacts a lane can keep in registers (register-resident solver)
+constexpr int CAP_LDS = 1024;         // contacts staged in LDS; denser envs stage in the global scratch slice
+
+enum { M_NCON = 0, M_TOTAL = 1, M_ANY = 2, M_STATUS = 3, M_MAXISL = 4, M_PROF = 5, M_WCNT = 8, M_WFILL = 8 + MAX_WAVES, M_COUNT = 8 + 2 * MAX_WAVES };
+
+struct Layout {  // byte offsets into dynamic LDS
+    int px, py, vx, vy;
+    int head, dirCnt, parent, misc, wsum;
+    int wsOff, newOff, oldKey, oldAcc;
+    int sPair, sInfo, sAcc, cbk, order;
+    int bkStart, bkFill, bkMaxRank, bkList;
+    int next, cellOf, cellXY;
+    int wsCnt, wsCntNew, active, nList;
+    int objF, objCnt, objList, owsOld, owsNew;
+    int total;
+};
+
+struct Params {
+    kb_buffers buf;
+    const float *actions;
+    const float *light_action;
+    int N, NP, NB, M, E, S, gw, gh, ncell, cap, capL, n_substeps, flags, drive_mode, light_type, vel_iters, pos_iters;
+    int solver_mode;
+    float xmin, ymin, xmax, ymax, inv_cell, r_bot, im_bot, kl_bot, ka_bot, h;
+    float light_radius, light_lo[2], light_hi[2], act_lo[2], act_hi[2];
+    float r_obj[KB_MAX_OBJECTS], im_obj[KB_MAX_OBJECTS], kl_obj, ka_obj;
+    Layout L;
+};
+
+inline Layout make_layout(int NP, int ncell, int capL) {
+    const int NB = NP + KB_MAX_OBJECTS + 4;   // bodies: kilobots, then objects at index N + m; last slot = scratch body
+    Layout L;
+    int o = 0;
+    auto take = [&](int bytes) { int r = o; o += (bytes + 15) & ~15; return r; };
+    L.px = take(4 * NB); L.py = take(4 * NB); L.vx = take(4 * NB); L.vy = take(4 * NB);
+    L.head = take(4 * ncell); L.dirCnt = take(4 * NB); L.parent = take(4 * NB);
+    L.misc = take(4 * M_COUNT); L.wsum = take(4 * 16);
+    L.wsOff = take(2 * NP); L.newOff = take(2 * NP); L.oldKey = take(2 * capL); L.oldAcc = take(4 * capL);
+    L.sPair = take(4 * capL); L.sInfo = take(4 * capL); L.sAcc = take(4 * capL);
+    L.cbk = take(2 * capL); L.order = take(2 * capL);
+    L.bkStart = take(4 * (MAX_BUCKETS + 1)); L.bkFill = take(4 * MAX_BUCKETS);
+    L.bkMaxRank = take(4 * MAX_WAVES * NUM_CLS); L.bkList = take(2 * MAX_BUCKETS);
+    L.next = take(2 * NP); L.cellOf = take(2 * NP); L.cellXY = take(4 * NP);
+    L.wsCnt = take(NP); L.wsCntNew = take(NP); L.active = take(2 * NB); L.nList = take(16);
+    L.objF = take(4 * 2 * KB_MAX_OBJECTS); L.objCnt = take(4 * KB_MAX_OBJECTS); L.objList = take(2 * KB_MAX_OBJECTS * 32);
+    L.owsOld = take(4 * KB_MAX_OBJECTS * 12); L.owsNew = take(4 * KB_MAX_OBJECTS * 12);
+    L.total = o;
+    return L;
+}
+
+// ---- device math ----------------------------------------------------------------------------
+// sin/cos: Cephes single-precision algorithm (argument reduction by pi/4 in three parts, degree-3
+// minimax polynomials in x^2).  Own implementation so that results are identical wherever the
+// same specification is evaluated in IEEE fp32.
+__device__ __forceinline__ void kb_sincosf(float xx, float &sn, float &cs) {
+    const float DP1 = 0.78515625f, DP2 = 2.4187564849853515625e-4f, DP3 = 3.77489497744594108e-8f;
+    const float FOPI = 1.27323954473516f;
+    float x = fabsf(xx);
+    int j = (int)(FOPI * x);
+    float y = (float)j;
+    if (j & 1) { j += 1; y += 1.0f; }
+    j &= 7;
+    float ssign = xx < 0.0f ? -1.0f : 1.0f, csign = 1.0f;
+    if (j > 3) { ssign = -ssign; csign = -csign; j -= 4; }
+    if (j > 1) csign = -csign;
+    x = ((x - y * DP1) - y * DP2) - y * DP3;
+    float z = x * x;
+    float pc = ((2.443315711809948E-005f * z - 1.388731625493765E-003f) * z + 4.166664568298827E-002f) * z * z
+               - 0.5f * z + 1.0f;
+    float ps = ((-1.9515295891E-4f * z + 8.3321608736E-3f) * z - 1.6666654611E-1f) * z * x + x;
+    if (j == 1 || j == 2) { sn = ssign * pc; cs = csign * ps; }
+    else { sn = ssign * ps; cs = csign * pc; }
+}
+
+// CircularGradientLight.value_and_gradients, light.py:176-189 (zero gradient instead of NaN at distance 0)
+__device__ __forceinline__ void kb_light_circular(float sx, float sy, float lx, float ly, float R,
+                                                  float &val, float &gx, float &gy) {
+    float dx = -1.0f * (sx - lx), dy = -1.0f * (sy - ly);
+    float n = sqrtf(dx * dx + dy * dy);
+    float v = 1.0f - n / R;
+    v = fmaxf(fminf(v, 1.0f), 0.0f);
+    val = v * 255.0f;
+    if (n > 0.0f) { dx = dx / n; dy = dy / n; }
+    else { dx = 0.0f; dy = 0.0f; }
+    if (n > R) { dx *= 0.0f; dy *= 0.0f; }
+    gx = dx; gy = dy;
+}
+
+// Kilobot.step motor law, kilobot.py:86-127; body velocity in world units
+__device__ __forceinline__ void kb_motor_law(int ml, int mr, float th, float h, float &vx, float &vy, float &w) {
+    const float max_lin = 0.01f, max_ang = 0.5f * 3.14159265358979323846f;
+    float s, c;
+    kb_sincosf(th, s, c);
+    if (ml && mr) {  // kilobot.py:97-101 (intended meaning; the reference raises TypeError at :127)
+        float lin = (float)(mr + ml) / 510.0f * max_lin;
+        vx = (s * lin) * WORLD_SCALE; vy = (c * lin) * WORLD_SCALE;
+        w = (float)(mr - ml) / 510.0f * max_ang;
+    } else if (mr || ml) {  // kilobot.py:103-121: pivot about the opposite leg
+        float av, lx, ly = -0.009f;
+        if (mr) { av = (float)mr / 255.0f * max_ang; lx = -0.013f; }
+        else { av = -(float)ml / 255.0f * max_ang; lx = 0.013f; }
+        float ds, dc;
+        kb_sincosf(av * h, ds, dc);
+        float tx = lx - (dc * lx - ds * ly), ty = ly - (ds * lx + dc * ly);
+        tx *= WORLD_SCALE; ty *= WORLD_SCALE;
+        float wx = c * tx - s * ty, wy = s * tx + c * ty;  // b2Body::GetWorldVector
+        wx = wx / WORLD_SCALE / h; wy = wy / WORLD_SCALE / h;
+        vx = wx * WORLD_SCALE; vy = wy * WORLD_SCALE; w = av;
+    } else {
+        vx = 0.0f; vy = 0.0f; w = 0.0f;
+    }
+}
+
+__device__ __forceinline__ float kb_clampf(float a, float lo, float hi) { return fmaxf(lo, fminf(a, hi)); }
+
+// LDS operations of one wave execute in program order; this only stops the compiler from moving
+// LDS accesses across the point where other lanes' results are consumed.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ void wall_geom(const Params &p, int wl, float x, float y, float &dist, float &nx, float &ny) {
+    switch (wl) {
+    case 0: nx = 1.0f; ny = 0.0f; dist = x - p.xmin; break;
+    case 1: nx = 0.0f; ny = 1.0f; dist = y - p.ymin; break;
+    case 2: nx = -1.0f; ny = 0.0f; dist = p.xmax - x; break;
+    default: nx = 0.0f; ny = -1.0f; dist = p.ymax - y; break;
+    }
+}
+
+#ifdef KB_PROFILE
+// diagnostic build: thread 0 accumulates shader cycles per phase into g.status[E + 8*e + phase]
+#define KB_STAMP(ph) do { if (tid == 0) { long long t_ = clock64(); prof_acc[ph] += t_ - prof_t; prof_t = t_; } } while (0)
+#else
+#define KB_STAMP(ph) do { } while (0)
+#endif
+
+__device__ __forceinline__ int dir_dx(int k) { return (k == 1 || k == 3) ? 1 : (k == 4 ? -1 : 0); }
+__device__ __forceinline__ int dir_dy(int k) { return (k >= 2) ? 1 : 0; }
+
+// exclusive scan of NP (multiple of 4, <= 4 * blockDim.x) u8 counts into u16 offsets; returns the total.
+// All threads must call; contains two workgroup barriers.
+__device__ __forceinline__ unsigned block_scan_u8(const unsigned char *cnt, unsigned short *off, int NP, unsigned *wsum) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    const bool in = 4 * tid < NP;
+    const unsigned c4 = in ? *reinterpret_cast<const unsigned *>(cnt + 4 * tid) : 0u;
+    const unsigned c0 = c4 & 255u, c1 = (c4 >> 8) & 255u, c2 = (c4 >> 16) & 255u, c3 = c4 >> 24;
+    const unsigned sum = c0 + c1 + c2 + c3;
+    unsigned incl = sum;
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    unsigned base = 0, total = 0;
+    for (int w = 0; w < nw; ++w) { const unsigned s = wsum[w]; if (w < wave) base += s; total += s; }
+    if (in) {
+        const unsigned r0 = base + incl - sum, r1 = r0 + c0, r2 = r1 + c1, r3 = r2 + c2;
+        reinterpret_cast<unsigned *>(off + 4 * tid)[0] = r0 | (r1 << 16);
+        reinterpret_cast<unsigned *>(off + 4 * tid)[1] = r2 | (r3 << 16);
+    }
+    __syncthreads();
+    return total;
+}
+
+#define KB_NEXT(b) (nextb[b] == EMPTY16 ? EMPTY32 : (unsigned)nextb[b])
+
+
+typedef void (*kb_step_fn)(const Params);
+// one translation unit per drive law (kb_inst_d*.hip) instantiates its kernels and hands out the right one
+kb_step_fn kb_pick_velocity(int light_type, bool objects);
+kb_step_fn kb_pick_accel(int light_type, bool objects);
+kb_step_fn kb_pick_motors(int light_type, bool objects);
+kb_step_fn kb_pick_simple_phototaxis(int light_type, bool objects);
+kb_step_fn kb_pick_phototaxis(int light_type, bool objects);
+
+}  // namespace kb

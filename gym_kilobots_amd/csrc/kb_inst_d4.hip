@@ -1,0 +1,9 @@
+// kernel instantiations for drive law KB_DRIVE_PHOTOTAXIS
+#include "kb_step_kernel.h"
+
+namespace kb {
+kb_step_fn kb_pick_phototaxis(int light_type, bool objects) {
+    if (light_type == KB_LIGHT_CIRCULAR) return objects ? kb_step_kernel<KB_DRIVE_PHOTOTAXIS, KB_LIGHT_CIRCULAR, true> : kb_step_kernel<KB_DRIVE_PHOTOTAXIS, KB_LIGHT_CIRCULAR, false>;
+    return nullptr;
+}
+}  // namespace kb

@@ -1,252 +1,8 @@
-// kb_sim.hip -- batched Kilobot world step for MI355X (gfx950 / CDNA4) + its C ABI.
-//
-// One workgroup owns one env for the whole launch: positions are loaded once from HBM into LDS,
-// `n_substeps` iterations of the reference substep loop
-// (gym_kilobots/envs/kilobots_env.py:168-190) run out of LDS / registers, poses are written back once.
-// Per substep:
-//   drive law (kilobot.py:86-127,191-203,253-258,294-300,318-333) + light (light.py:59-75,176-189)
-//   -> broadphase: uniform grid of per-cell linked lists in LDS (one atomic exchange per bot)
-//   -> narrowphase: circle-circle / circle-wall (Box2D b2CollideCircles, b2CollideEdgeAndCircle),
-//      5-cell half stencil, warm-start impulses matched from the previous substep
-//   -> islands: lock-free union-find in LDS
-//   -> solver (b2ContactSolver semantics): warm start + 10 sequential-impulse velocity sweeps,
-//      symplectic Euler, <= 10 position sweeps with Box2D's per-island early out.
-// Gauss-Seidel order.  Every contact gets a key (class, rank): class from the relative grid position
-// of the two bodies and the parity of the base cell, rank from its position inside its cell-pair
-// group.  Two contacts with the same key never share a body, so all contacts of one key can be
-// solved concurrently and the result equals the sequential sweep in (class, group, A, B) order that
-// DESIGN.md specifies.  Islands are independent, so each island is bound to ONE wavefront
-// (root id mod #waves): a wave walks its own contacts key by key with no workgroup barrier at all
-// (LDS operations of one wave execute in order).  Only when one island is very large does the whole
-// workgroup cooperate on the sweep with s_barrier between keys.
-// No MFMA anywhere: this is LDS/latency- and HBM-bound integer/float work.
-//
-// Arithmetic: fp32, compiled with -ffp-contract=off; every expression is written in the operation
-// order of the specification so results do not depend on launch fusion, workgroup size or sharding.
-#include <hip/hip_runtime.h>
+// kb_step_kernel.h -- the world-step kernel template (see kb_common.h for the overview).
+#pragma once
+#include "kb_common.h"
 
-#include <cmath>
-#include <cstdio>
-#include <cstring>
-#include <new>
-
-#include "kilobots_hip.h"
-
-namespace {
-
-// ---- Box2D 2.3.1 constants (b2Settings.h) ---------------------------------------------------
-constexpr float B2_PI = 3.14159265359f;
-constexpr float B2_LINEAR_SLOP = 0.005f;
-constexpr float B2_POLYGON_RADIUS = 2.0f * B2_LINEAR_SLOP;
-constexpr float B2_BAUMGARTE = 0.2f;
-constexpr float B2_MAX_LINEAR_CORRECTION = 0.2f;
-constexpr float B2_MAX_TRANSLATION = 2.0f;
-constexpr float B2_MAX_TRANSLATION_SQ = B2_MAX_TRANSLATION * B2_MAX_TRANSLATION;
-constexpr float B2_MAX_ROTATION = 0.5f * B2_PI;
-constexpr float B2_MAX_ROTATION_SQ = B2_MAX_ROTATION * B2_MAX_ROTATION;
-constexpr float B2_EPSILON = 1.19209290e-07f;
-constexpr float WORLD_SCALE = 25.0f;  // body.py:7
-
-constexpr float CELL_SIZE = 0.875f;   // world units, >= 2 * bot radius
-constexpr int MAX_CELLS = 8192;
-
-constexpr unsigned KEY_WALL = 0x10000u, KEY_OBJ = 0x20000u;
-constexpr int WALL_CODE = 0xFFF0;     // body id of wall w is WALL_CODE + w
-constexpr int OBJ_CODE = 0xFFE0;      // 16-bit warm-start key of object m (its body id is N + m)
-constexpr int MAXOBJ = KB_MAX_OBJECTS, OWS = 12, OBJ_LIST = 32;
-constexpr unsigned EMPTY32 = 0xFFFFFFFFu;
-constexpr unsigned short EMPTY16 = 0xFFFFu;
-
-// contact classes in canonical order; +1 on E/N/NE/NW for odd base-cell parity
-constexpr int CLS_SAME = 0, CLS_E = 1, CLS_N = 3, CLS_NE = 5, CLS_NW = 7, CLS_WALL = 9,
-              CLS_BOT_OBJ = 10, CLS_OBJ_OBJ = 11, CLS_OBJ_WALL = 12, NUM_CLS = 13;
-constexpr int RK = 4;                 // rank buckets per class; the last one holds every rank >= RK-1
-#ifndef KB_MAX_WAVES
-#define KB_MAX_WAVES 8
-#endif
-#ifndef KB_BPT
-#define KB_BPT 2
-#endif
-#ifndef KB_KREG
-#define KB_KREG 2
-#endif
-#ifndef KB_MIN_WAVES_PER_SIMD
-#define KB_MIN_WAVES_PER_SIMD 4
-#endif
-constexpr int MAX_WAVES = KB_MAX_WAVES;   // waves per workgroup
-constexpr int BK_PER_WAVE = NUM_CLS * RK;
-constexpr int MAX_BUCKETS = MAX_WAVES * BK_PER_WAVE;
-constexpr int BPT = KB_BPT;                // bots per thread (max): N <= BPT * blockDim.x
-constexpr int GIANT_ISLAND = 256;     // contacts; larger islands are swept by the whole workgroup
-constexpr int KREG = KB_KREG;               // contacts a lane can keep in registers (register-resident solver)
-constexpr int CAP_LDS = 1024;         // contacts staged in LDS; denser envs stage in the global scratch slice
-
-enum { M_NCON = 0, M_TOTAL = 1, M_ANY = 2, M_STATUS = 3, M_MAXISL = 4, M_PROF = 5, M_WCNT = 8, M_WFILL = 8 + MAX_WAVES, M_COUNT = 8 + 2 * MAX_WAVES };
-
-struct Layout {  // byte offsets into dynamic LDS
-    int px, py, vx, vy;
-    int head, dirCnt, parent, misc, wsum;
-    int wsOff, newOff, oldKey, oldAcc;
-    int sPair, sInfo, sAcc, cbk, order;
-    int bkStart, bkFill, bkMaxRank, bkList;
-    int next, cellOf, cellXY;
-    int wsCnt, wsCntNew, active, nList;
-    int objF, objCnt, objList, owsOld, owsNew;
-    int total;
-};
-
-struct Params {
-    kb_buffers buf;
-    const float *actions;
-    const float *light_action;
-    int N, NP, NB, M, E, S, gw, gh, ncell, cap, capL, n_substeps, flags, drive_mode, light_type, vel_iters, pos_iters;
-    int solver_mode;
-    float xmin, ymin, xmax, ymax, inv_cell, r_bot, im_bot, kl_bot, ka_bot, h;
-    float light_radius, light_lo[2], light_hi[2], act_lo[2], act_hi[2];
-    float r_obj[KB_MAX_OBJECTS], im_obj[KB_MAX_OBJECTS], kl_obj, ka_obj;
-    Layout L;
-};
-
-Layout make_layout(int NP, int ncell, int capL) {
-    const int NB = NP + KB_MAX_OBJECTS + 4;   // bodies: kilobots, then objects at index N + m; last slot = scratch body
-    Layout L;
-    int o = 0;
-    auto take = [&](int bytes) { int r = o; o += (bytes + 15) & ~15; return r; };
-    L.px = take(4 * NB); L.py = take(4 * NB); L.vx = take(4 * NB); L.vy = take(4 * NB);
-    L.head = take(4 * ncell); L.dirCnt = take(4 * NB); L.parent = take(4 * NB);
-    L.misc = take(4 * M_COUNT); L.wsum = take(4 * 16);
-    L.wsOff = take(2 * NP); L.newOff = take(2 * NP); L.oldKey = take(2 * capL); L.oldAcc = take(4 * capL);
-    L.sPair = take(4 * capL); L.sInfo = take(4 * capL); L.sAcc = take(4 * capL);
-    L.cbk = take(2 * capL); L.order = take(2 * capL);
-    L.bkStart = take(4 * (MAX_BUCKETS + 1)); L.bkFill = take(4 * MAX_BUCKETS);
-    L.bkMaxRank = take(4 * MAX_WAVES * NUM_CLS); L.bkList = take(2 * MAX_BUCKETS);
-    L.next = take(2 * NP); L.cellOf = take(2 * NP); L.cellXY = take(4 * NP);
-    L.wsCnt = take(NP); L.wsCntNew = take(NP); L.active = take(2 * NB); L.nList = take(16);
-    L.objF = take(4 * 2 * KB_MAX_OBJECTS); L.objCnt = take(4 * KB_MAX_OBJECTS); L.objList = take(2 * KB_MAX_OBJECTS * 32);
-    L.owsOld = take(4 * KB_MAX_OBJECTS * 12); L.owsNew = take(4 * KB_MAX_OBJECTS * 12);
-    L.total = o;
-    return L;
-}
-
-// ---- device math ----------------------------------------------------------------------------
-// sin/cos: Cephes single-precision algorithm (argument reduction by pi/4 in three parts, degree-3
-// minimax polynomials in x^2).  Own implementation so that results are identical wherever the
-// same specification is evaluated in IEEE fp32.
-__device__ __forceinline__ void kb_sincosf(float xx, float &sn, float &cs) {
-    const float DP1 = 0.78515625f, DP2 = 2.4187564849853515625e-4f, DP3 = 3.77489497744594108e-8f;
-    const float FOPI = 1.27323954473516f;
-    float x = fabsf(xx);
-    int j = (int)(FOPI * x);
-    float y = (float)j;
-    if (j & 1) { j += 1; y += 1.0f; }
-    j &= 7;
-    float ssign = xx < 0.0f ? -1.0f : 1.0f, csign = 1.0f;
-    if (j > 3) { ssign = -ssign; csign = -csign; j -= 4; }
-    if (j > 1) csign = -csign;
-    x = ((x - y * DP1) - y * DP2) - y * DP3;
-    float z = x * x;
-    float pc = ((2.443315711809948E-005f * z - 1.388731625493765E-003f) * z + 4.166664568298827E-002f) * z * z
-               - 0.5f * z + 1.0f;
-    float ps = ((-1.9515295891E-4f * z + 8.3321608736E-3f) * z - 1.6666654611E-1f) * z * x + x;
-    if (j == 1 || j == 2) { sn = ssign * pc; cs = csign * ps; }
-    else { sn = ssign * ps; cs = csign * pc; }
-}
-
-// CircularGradientLight.value_and_gradients, light.py:176-189 (zero gradient instead of NaN at distance 0)
-__device__ __forceinline__ void kb_light_circular(float sx, float sy, float lx, float ly, float R,
-                                                  float &val, float &gx, float &gy) {
-    float dx = -1.0f * (sx - lx), dy = -1.0f * (sy - ly);
-    float n = sqrtf(dx * dx + dy * dy);
-    float v = 1.0f - n / R;
-    v = fmaxf(fminf(v, 1.0f), 0.0f);
-    val = v * 255.0f;
-    if (n > 0.0f) { dx = dx / n; dy = dy / n; }
-    else { dx = 0.0f; dy = 0.0f; }
-    if (n > R) { dx *= 0.0f; dy *= 0.0f; }
-    gx = dx; gy = dy;
-}
-
-// Kilobot.step motor law, kilobot.py:86-127; body velocity in world units
-__device__ __forceinline__ void kb_motor_law(int ml, int mr, float th, float h, float &vx, float &vy, float &w) {
-    const float max_lin = 0.01f, max_ang = 0.5f * 3.14159265358979323846f;
-    float s, c;
-    kb_sincosf(th, s, c);
-    if (ml && mr) {  // kilobot.py:97-101 (intended meaning; the reference raises TypeError at :127)
-        float lin = (float)(mr + ml) / 510.0f * max_lin;
-        vx = (s * lin) * WORLD_SCALE; vy = (c * lin) * WORLD_SCALE;
-        w = (float)(mr - ml) / 510.0f * max_ang;
-    } else if (mr || ml) {  // kilobot.py:103-121: pivot about the opposite leg
-        float av, lx, ly = -0.009f;
-        if (mr) { av = (float)mr / 255.0f * max_ang; lx = -0.013f; }
-        else { av = -(float)ml / 255.0f * max_ang; lx = 0.013f; }
-        float ds, dc;
-        kb_sincosf(av * h, ds, dc);
-        float tx = lx - (dc * lx - ds * ly), ty = ly - (ds * lx + dc * ly);
-        tx *= WORLD_SCALE; ty *= WORLD_SCALE;
-        float wx = c * tx - s * ty, wy = s * tx + c * ty;  // b2Body::GetWorldVector
-        wx = wx / WORLD_SCALE / h; wy = wy / WORLD_SCALE / h;
-        vx = wx * WORLD_SCALE; vy = wy * WORLD_SCALE; w = av;
-    } else {
-        vx = 0.0f; vy = 0.0f; w = 0.0f;
-    }
-}
-
-__device__ __forceinline__ float kb_clampf(float a, float lo, float hi) { return fmaxf(lo, fminf(a, hi)); }
-
-// LDS operations of one wave execute in program order; this only stops the compiler from moving
-// LDS accesses across the point where other lanes' results are consumed.
-__device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-__device__ __forceinline__ void wall_geom(const Params &p, int wl, float x, float y, float &dist, float &nx, float &ny) {
-    switch (wl) {
-    case 0: nx = 1.0f; ny = 0.0f; dist = x - p.xmin; break;
-    case 1: nx = 0.0f; ny = 1.0f; dist = y - p.ymin; break;
-    case 2: nx = -1.0f; ny = 0.0f; dist = p.xmax - x; break;
-    default: nx = 0.0f; ny = -1.0f; dist = p.ymax - y; break;
-    }
-}
-
-#ifdef KB_PROFILE
-// diagnostic build: thread 0 accumulates shader cycles per phase into g.status[E + 8*e + phase]
-#define KB_STAMP(ph) do { if (tid == 0) { long long t_ = clock64(); prof_acc[ph] += t_ - prof_t; prof_t = t_; } } while (0)
-#else
-#define KB_STAMP(ph) do { } while (0)
-#endif
-
-__device__ __forceinline__ int dir_dx(int k) { return (k == 1 || k == 3) ? 1 : (k == 4 ? -1 : 0); }
-__device__ __forceinline__ int dir_dy(int k) { return (k >= 2) ? 1 : 0; }
-
-// exclusive scan of NP (multiple of 4, <= 4 * blockDim.x) u8 counts into u16 offsets; returns the total.
-// All threads must call; contains two workgroup barriers.
-__device__ __forceinline__ unsigned block_scan_u8(const unsigned char *cnt, unsigned short *off, int NP, unsigned *wsum) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-    const bool in = 4 * tid < NP;
-    const unsigned c4 = in ? *reinterpret_cast<const unsigned *>(cnt + 4 * tid) : 0u;
-    const unsigned c0 = c4 & 255u, c1 = (c4 >> 8) & 255u, c2 = (c4 >> 16) & 255u, c3 = c4 >> 24;
-    const unsigned sum = c0 + c1 + c2 + c3;
-    unsigned incl = sum;
-    for (int d = 1; d < 64; d <<= 1) {
-        const unsigned t = __shfl_up(incl, d);
-        if (lane >= d) incl += t;
-    }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    unsigned base = 0, total = 0;
-    for (int w = 0; w < nw; ++w) { const unsigned s = wsum[w]; if (w < wave) base += s; total += s; }
-    if (in) {
-        const unsigned r0 = base + incl - sum, r1 = r0 + c0, r2 = r1 + c1, r3 = r2 + c2;
-        reinterpret_cast<unsigned *>(off + 4 * tid)[0] = r0 | (r1 << 16);
-        reinterpret_cast<unsigned *>(off + 4 * tid)[1] = r2 | (r3 << 16);
-    }
-    __syncthreads();
-    return total;
-}
-
-#define KB_NEXT(b) (nextb[b] == EMPTY16 ? EMPTY32 : (unsigned)nextb[b])
+namespace kb {
 
 // One instantiation per (drive law, light model): keeps only that law's code (and registers) in the kernel.
 template <int DRIVE_MODE, int LIGHT_TYPE, bool OBJ>
@@ -1398,237 +1154,5 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
     }
 }
 
-// set_action alone (kilobot.py:235-241, 283-289)
-__global__ void kb_set_actions_kernel(const Params p) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t T = (size_t)p.E * p.N;
-    if (i >= T) return;
-    float a0 = 0.0f, a1 = 0.0f;
-    if (p.actions) { const float2 a = reinterpret_cast<const float2 *>(p.actions)[i]; a0 = a.x; a1 = a.y; }
-    if (p.drive_mode == KB_DRIVE_VELOCITY) {
-        const float mw = 0.5f * 3.14159265358979323846f;
-        p.buf.v[i] = fmaxf(fminf(a0, 0.01f), 0.0f);
-        p.buf.w[i] = fmaxf(fminf(a1, mw), -mw);
-    } else {
-        const float aw = 0.2f * 3.14159265358979323846f;
-        p.buf.acc_v[i] = fmaxf(fminf(a0, 0.005f), -0.005f);
-        p.buf.acc_w[i] = fmaxf(fminf(a1, aw), -aw);
-    }
-}
 
-// Body.get_pose for every kilobot (body.py:63-65): metres, radians
-__global__ void kb_get_poses_kernel(const float *x, const float *y, const float *th, float *out, size_t T) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= T) return;
-    out[3 * i + 0] = x[i] / WORLD_SCALE;
-    out[3 * i + 1] = y[i] / WORLD_SCALE;
-    out[3 * i + 2] = th[i];
-}
-
-thread_local char g_err[512] = "";
-
-int fail(int code, const char *fmt, const char *detail = "") {
-    snprintf(g_err, sizeof(g_err), fmt, detail);
-    return code;
-}
-
-}  // namespace
-
-struct kb_sim {
-    kb_config cfg;
-    Params p;
-    bool bound;
-    bool attr_set;
-    int threads;
-};
-
-extern "C" {
-
-const char *kb_last_error(void) { return g_err; }
-const char *kb_version(void) { return "kilobots_hip 0.1 (gfx950)"; }
-
-int kb_create(const kb_config *cfg, kb_sim **out) {
-    if (!cfg || !out) return fail(KB_EINVAL, "kb_create: NULL argument");
-    if (cfg->num_envs < 1 || cfg->num_bots < 1 || cfg->num_bots > KB_MAX_BOTS)
-        return fail(KB_EINVAL, "kb_create: num_envs >= 1 and 1 <= num_bots <= 1024 required");
-    if (cfg->num_objects < 0 || cfg->num_objects > KB_MAX_OBJECTS) return fail(KB_EINVAL, "kb_create: 0 <= num_objects <= 8 required");
-    for (int m = 0; m < cfg->num_objects; ++m)
-        if (!(cfg->obj_radius[m] > 0.0f)) return fail(KB_EINVAL, "kb_create: obj_radius must be positive");
-    if (cfg->num_objects > 0 && !(cfg->obj_density > 0.0f)) return fail(KB_EINVAL, "kb_create: obj_density must be positive");
-    if (cfg->drive_mode < 0 || cfg->drive_mode > KB_DRIVE_PHOTOTAXIS) return fail(KB_EINVAL, "kb_create: bad drive_mode");
-    if (cfg->light_type != KB_LIGHT_NONE && cfg->light_type != KB_LIGHT_CIRCULAR)
-        return fail(KB_EINVAL, "kb_create: unsupported light_type");
-    if ((cfg->drive_mode == KB_DRIVE_SIMPLE_PHOTOTAXIS || cfg->drive_mode == KB_DRIVE_PHOTOTAXIS) &&
-        cfg->light_type == KB_LIGHT_NONE)
-        return fail(KB_EINVAL, "kb_create: phototaxis drive modes need a light");
-    if (cfg->ws_slots < 1 || cfg->ws_slots > 64) return fail(KB_EINVAL, "kb_create: 1 <= ws_slots <= 64 required");
-    if (cfg->solver_mode < 0 || cfg->solver_mode > 4) return fail(KB_EINVAL, "kb_create: solver_mode must be 0..4");
-    if (!(cfg->dt > 0.0f) || cfg->vel_iters < 0 || cfg->pos_iters < 0 || !(cfg->world_width > 0.0f) ||
-        !(cfg->world_height > 0.0f) || !(cfg->bot_radius > 0.0f) || !(cfg->bot_density > 0.0f))
-        return fail(KB_EINVAL, "kb_create: non-positive dt / size / radius / density");
-    kb_sim *s = new (std::nothrow) kb_sim();
-    if (!s) return fail(KB_EINVAL, "kb_create: out of host memory");
-    s->cfg = *cfg;
-    s->bound = false;
-    s->attr_set = false;
-    Params &p = s->p;
-    memset(&p, 0, sizeof(p));
-    p.N = cfg->num_bots; p.E = cfg->num_envs; p.S = cfg->ws_slots;
-    p.drive_mode = cfg->drive_mode; p.light_type = cfg->light_type;
-    p.vel_iters = cfg->vel_iters; p.pos_iters = cfg->pos_iters;
-    const float W = cfg->world_width * WORLD_SCALE, H = cfg->world_height * WORLD_SCALE;
-    p.xmin = -0.5f * W; p.xmax = 0.5f * W; p.ymin = -0.5f * H; p.ymax = 0.5f * H;
-    float cell = CELL_SIZE;
-    const float dmin = 2.0f * cfg->bot_radius * WORLD_SCALE;
-    while (cell < dmin) cell *= 2.0f;
-    for (;;) {
-        p.inv_cell = 1.0f / cell;
-        p.gw = (int)ceilf(W * p.inv_cell); if (p.gw < 1) p.gw = 1;
-        p.gh = (int)ceilf(H * p.inv_cell); if (p.gh < 1) p.gh = 1;
-        if ((long)p.gw * p.gh <= MAX_CELLS) break;
-        cell *= 2.0f;
-    }
-    p.ncell = p.gw * p.gh;
-    p.h = cfg->dt;
-    p.r_bot = cfg->bot_radius * WORLD_SCALE;
-    const float m = cfg->bot_density * B2_PI * p.r_bot * p.r_bot;  // b2CircleShape::ComputeMass
-    p.im_bot = m > 0.0f ? 1.0f / m : 0.0f;
-    p.kl_bot = 1.0f / (1.0f + p.h * cfg->bot_linear_damping);
-    p.ka_bot = 1.0f / (1.0f + p.h * cfg->bot_angular_damping);
-    p.light_radius = cfg->light_radius;
-    for (int i = 0; i < 2; ++i) {
-        p.light_lo[i] = cfg->light_lo[i]; p.light_hi[i] = cfg->light_hi[i];
-        p.act_lo[i] = cfg->light_act_lo[i]; p.act_hi[i] = cfg->light_act_hi[i];
-    }
-    long cap = (long)p.N * (p.N - 1) / 2 + 4L * p.N;
-    if (cap > 2304) cap = 2304;
-    if (cap < 4L * p.N + 64) cap = 4L * p.N + 64;
-    cap += 40L * cfg->num_objects;
-    p.cap = (int)cap;
-    p.capL = p.cap < CAP_LDS ? p.cap : CAP_LDS;
-    p.NP = (p.N + 3) & ~3;
-    p.NB = p.NP + KB_MAX_OBJECTS + 4;
-    p.M = cfg->num_objects;
-    for (int m = 0; m < KB_MAX_OBJECTS; ++m) {
-        p.r_obj[m] = cfg->obj_radius[m] * WORLD_SCALE;
-        const float mo = cfg->obj_density * B2_PI * p.r_obj[m] * p.r_obj[m];   // b2CircleShape::ComputeMass
-        p.im_obj[m] = mo > 0.0f ? 1.0f / mo : 0.0f;
-    }
-    p.kl_obj = 1.0f / (1.0f + p.h * cfg->obj_linear_damping);
-    p.ka_obj = 1.0f / (1.0f + p.h * cfg->obj_angular_damping);
-    p.solver_mode = cfg->solver_mode;
-    p.L = make_layout(p.NP, p.ncell, p.capL);
-    if (p.L.total > 160 * 1024) {
-        delete s;
-        return fail(KB_ELDS, "kb_create: configuration needs more than 160 KiB of LDS per env");
-    }
-    s->threads = ((p.N + BPT - 1) / BPT + 63) & ~63;   // N <= BPT * threads
-    if (s->threads < 64) s->threads = 64;
-    if (s->threads > 64 * MAX_WAVES) { delete s; return fail(KB_EINVAL, "kb_create: num_bots exceeds bots-per-thread x workgroup size of this build"); }
-    *out = s;
-    return KB_OK;
-}
-
-void kb_destroy(kb_sim *sim) { delete sim; }
-
-int kb_bind(kb_sim *sim, const kb_buffers *b) {
-    if (!sim || !b) return fail(KB_EINVAL, "kb_bind: NULL argument");
-    if (!b->x || !b->y || !b->theta || !b->ws_key || !b->ws_acc || !b->ws_cnt || !b->status || !b->scratch)
-        return fail(KB_ENOTBOUND, "kb_bind: x, y, theta, ws_key, ws_acc, ws_cnt, status and scratch are required");
-    const int m = sim->cfg.drive_mode;
-    if ((m == KB_DRIVE_VELOCITY || m == KB_DRIVE_ACCEL) && (!b->v || !b->w))
-        return fail(KB_ENOTBOUND, "kb_bind: v and w are required in the velocity / acceleration modes");
-    if (m == KB_DRIVE_ACCEL && (!b->acc_v || !b->acc_w)) return fail(KB_ENOTBOUND, "kb_bind: acc_v, acc_w required");
-    if ((m == KB_DRIVE_MOTORS || m == KB_DRIVE_PHOTOTAXIS) && (!b->motor_l || !b->motor_r))
-        return fail(KB_ENOTBOUND, "kb_bind: motor_l, motor_r required");
-    if (m == KB_DRIVE_PHOTOTAXIS && (!b->pt_threshold || !b->pt_update || !b->pt_nochange || !b->pt_dir))
-        return fail(KB_ENOTBOUND, "kb_bind: pt_* buffers required in the phototaxis mode");
-    if (sim->cfg.num_objects > 0 && (!b->ox || !b->oy || !b->otheta || !b->ovx || !b->ovy || !b->ow || !b->ows_acc))
-        return fail(KB_ENOTBOUND, "kb_bind: ox, oy, otheta, ovx, ovy, ow and ows_acc are required when num_objects > 0");
-    if (sim->cfg.light_type != KB_LIGHT_NONE && (!b->light_x || !b->light_y))
-        return fail(KB_ENOTBOUND, "kb_bind: light_x, light_y required when a light is configured");
-    if ((b->light_value != nullptr) != (b->light_gx != nullptr) || (b->light_value != nullptr) != (b->light_gy != nullptr))
-        return fail(KB_EINVAL, "kb_bind: light_value, light_gx, light_gy must be given together");
-    if ((b->cmd_vx != nullptr) != (b->cmd_vy != nullptr) || (b->cmd_vx != nullptr) != (b->cmd_w != nullptr))
-        return fail(KB_EINVAL, "kb_bind: cmd_vx, cmd_vy, cmd_w must be given together");
-    sim->p.buf = *b;
-    sim->bound = true;
-    return KB_OK;
-}
-
-int kb_set_actions(kb_sim *sim, const float *d_actions, void *stream) {
-    if (!sim) return fail(KB_EINVAL, "kb_set_actions: NULL handle");
-    if (!sim->bound) return fail(KB_ENOTBOUND, "kb_set_actions: kb_bind() first");
-    if (sim->cfg.drive_mode != KB_DRIVE_VELOCITY && sim->cfg.drive_mode != KB_DRIVE_ACCEL)
-        return fail(KB_EINVAL, "kb_set_actions: only the velocity / acceleration drive modes take actions");
-    Params p = sim->p;
-    p.actions = d_actions;
-    const size_t T = (size_t)p.E * p.N;
-    hipLaunchKernelGGL(kb_set_actions_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
-    hipError_t err = hipGetLastError();
-    if (err != hipSuccess) return fail(KB_EHIP, "kb_set_actions: %s", hipGetErrorString(err));
-    return KB_OK;
-}
-
-int kb_step(kb_sim *sim, const float *d_actions, const float *d_light_action, int n_substeps, int flags, void *stream) {
-    if (!sim) return fail(KB_EINVAL, "kb_step: NULL handle");
-    if (!sim->bound) return fail(KB_ENOTBOUND, "kb_step: kb_bind() first");
-    if (n_substeps < 0) return fail(KB_EINVAL, "kb_step: n_substeps < 0");
-    if (d_actions && sim->cfg.drive_mode != KB_DRIVE_VELOCITY && sim->cfg.drive_mode != KB_DRIVE_ACCEL)
-        return fail(KB_EINVAL, "kb_step: only the velocity / acceleration drive modes take actions");
-    if (n_substeps == 0 && !d_actions) return KB_OK;
-    Params p = sim->p;
-    p.actions = d_actions;
-    p.light_action = d_light_action;
-    p.n_substeps = n_substeps;
-    p.flags = flags;
-    typedef void (*step_fn)(const Params);
-    step_fn fn = nullptr;
-    const bool lit = p.light_type == KB_LIGHT_CIRCULAR;
-    const bool obj = p.M > 0;
-#define KB_PICK(D, L) (obj ? kb_step_kernel<D, L, true> : kb_step_kernel<D, L, false>)
-    switch (p.drive_mode) {
-    case KB_DRIVE_VELOCITY: fn = lit ? KB_PICK(KB_DRIVE_VELOCITY, KB_LIGHT_CIRCULAR) : KB_PICK(KB_DRIVE_VELOCITY, KB_LIGHT_NONE); break;
-    case KB_DRIVE_ACCEL: fn = lit ? KB_PICK(KB_DRIVE_ACCEL, KB_LIGHT_CIRCULAR) : KB_PICK(KB_DRIVE_ACCEL, KB_LIGHT_NONE); break;
-    case KB_DRIVE_MOTORS: fn = lit ? KB_PICK(KB_DRIVE_MOTORS, KB_LIGHT_CIRCULAR) : KB_PICK(KB_DRIVE_MOTORS, KB_LIGHT_NONE); break;
-    case KB_DRIVE_SIMPLE_PHOTOTAXIS: fn = KB_PICK(KB_DRIVE_SIMPLE_PHOTOTAXIS, KB_LIGHT_CIRCULAR); break;
-    case KB_DRIVE_PHOTOTAXIS: fn = KB_PICK(KB_DRIVE_PHOTOTAXIS, KB_LIGHT_CIRCULAR); break;
-    default: return fail(KB_EINVAL, "kb_step: bad drive mode");
-    }
-#undef KB_PICK
-    if (p.L.total > 64 * 1024 && !sim->attr_set) {
-        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, p.L.total);
-        if (e2 != hipSuccess) return fail(KB_EHIP, "kb_step: hipFuncSetAttribute: %s", hipGetErrorString(e2));
-        sim->attr_set = true;
-    }
-    hipLaunchKernelGGL(fn, dim3((unsigned)p.E), dim3((unsigned)sim->threads), (size_t)p.L.total,
-                       (hipStream_t)stream, p);
-    hipError_t err = hipGetLastError();
-    if (err != hipSuccess) return fail(KB_EHIP, "kb_step: %s", hipGetErrorString(err));
-    return KB_OK;
-}
-
-int kb_get_poses(kb_sim *sim, float *d_out, void *stream) {
-    if (!sim || !d_out) return fail(KB_EINVAL, "kb_get_poses: NULL argument");
-    if (!sim->bound) return fail(KB_ENOTBOUND, "kb_get_poses: kb_bind() first");
-    const size_t T = (size_t)sim->p.E * sim->p.N;
-    hipLaunchKernelGGL(kb_get_poses_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       sim->p.buf.x, sim->p.buf.y, sim->p.buf.theta, d_out, T);
-    hipError_t err = hipGetLastError();
-    if (err != hipSuccess) return fail(KB_EHIP, "kb_get_poses: %s", hipGetErrorString(err));
-    return KB_OK;
-}
-
-int kb_lds_bytes(const kb_sim *sim) { return sim ? sim->p.L.total : KB_EINVAL; }
-size_t kb_scratch_bytes(const kb_sim *sim) { return sim ? (size_t)sim->p.E * (size_t)sim->p.cap * 16u : 0; }
-int kb_contact_capacity(const kb_sim *sim) { return sim ? sim->p.cap : KB_EINVAL; }
-int kb_block_threads(const kb_sim *sim) { return sim ? sim->threads : KB_EINVAL; }
-int kb_set_block_threads(kb_sim *sim, int threads) {
-    if (!sim || threads < 64 || threads > 64 * MAX_WAVES || (threads & 63)) return fail(KB_EINVAL, "kb_set_block_threads: multiple of 64 up to the build maximum");
-    if (sim->p.N > BPT * threads) return fail(KB_EINVAL, "kb_set_block_threads: need num_bots <= bots-per-thread x threads");
-    sim->threads = threads;
-    return KB_OK;
-}
-
-}  // extern "C"
+}  // namespace kb
