@@ -11,7 +11,8 @@ LIB_PATH = os.environ.get('KB_HIP_LIB', os.path.join(HERE, 'libkilobots_hip.so')
 
 KB_OK, KB_EINVAL, KB_ENOTBOUND, KB_EHIP, KB_ELDS = 0, -1, -2, -3, -4
 DRIVE_VELOCITY, DRIVE_ACCEL, DRIVE_MOTORS, DRIVE_SIMPLE_PHOTOTAXIS, DRIVE_PHOTOTAXIS = range(5)
-LIGHT_NONE, LIGHT_CIRCULAR = 0, 1
+LIGHT_NONE, LIGHT_CIRCULAR, LIGHT_GRADIENT, LIGHT_MOMENTUM, LIGHT_COMPOSITE = range(5)
+MAX_LIGHTS = 4
 STEP_NO_DRIVE = 1
 MAX_OBJECTS = 8
 MAX_BOTS = 1024
@@ -36,6 +37,10 @@ class KbConfig(C.Structure):
         ('obj_linear_damping', C.c_float), ('obj_angular_damping', C.c_float),
         ('toi_walls', C.c_int32),
         ('solver_mode', C.c_int32),
+        ('light_count', C.c_int32), ('light_kind', C.c_int32 * MAX_LIGHTS),
+        ('lightc_radius', C.c_float * MAX_LIGHTS), ('lightc_max_velocity', C.c_float * MAX_LIGHTS),
+        ('lightc_lo', (C.c_float * 2) * MAX_LIGHTS), ('lightc_hi', (C.c_float * 2) * MAX_LIGHTS),
+        ('lightc_act_lo', (C.c_float * 2) * MAX_LIGHTS), ('lightc_act_hi', (C.c_float * 2) * MAX_LIGHTS),
     ]
 
 
@@ -54,7 +59,7 @@ class KbBuffers(C.Structure):
 
 
 EXPORTS = ['kb_create', 'kb_destroy', 'kb_bind', 'kb_set_actions', 'kb_step', 'kb_get_poses',
-           'kb_lds_bytes', 'kb_contact_capacity', 'kb_scratch_bytes', 'kb_block_threads', 'kb_set_block_threads',
+           'kb_lds_bytes', 'kb_contact_capacity', 'kb_scratch_bytes', 'kb_light_action_dim', 'kb_light_count', 'kb_block_threads', 'kb_set_block_threads',
            'kb_last_error', 'kb_version']
 
 _lib = None
@@ -86,7 +91,7 @@ def load():
     lib.kb_step.restype = C.c_int
     lib.kb_get_poses.argtypes = [_P, _P, _P]
     lib.kb_get_poses.restype = C.c_int
-    for name in ('kb_lds_bytes', 'kb_contact_capacity', 'kb_block_threads'):
+    for name in ('kb_lds_bytes', 'kb_contact_capacity', 'kb_block_threads', 'kb_light_action_dim', 'kb_light_count'):
         getattr(lib, name).argtypes = [_P]
         getattr(lib, name).restype = C.c_int
     lib.kb_scratch_bytes.argtypes = [_P]
@@ -131,11 +136,27 @@ def default_config(num_envs, num_bots, drive_mode=DRIVE_VELOCITY, light_type=LIG
     c.obj_linear_damping = c.obj_angular_damping = 0.8
     c.toi_walls = 0
     c.solver_mode = 0
+    c.light_count = 1
+    for i in range(MAX_LIGHTS):
+        c.light_kind[i] = LIGHT_CIRCULAR
+        c.lightc_radius[i] = 0.2
+        c.lightc_max_velocity[i] = inf
+        for k in range(2):
+            c.lightc_lo[i][k], c.lightc_hi[i][k] = -inf, inf
+            c.lightc_act_lo[i][k], c.lightc_act_hi[i][k] = -0.01, 0.01
     for k, v in kw.items():
-        cur = getattr(c, k)
-        if hasattr(cur, '__len__'):
-            for i, vi in enumerate(v):
-                cur[i] = vi
-        else:
-            setattr(c, k, v)
+        _assign(c, k, v)
     return c
+
+
+def _assign(c, k, v):
+    cur = getattr(c, k)
+    if hasattr(cur, '__len__'):
+        for i, vi in enumerate(v):
+            if hasattr(cur[i], '__len__'):
+                for j, vij in enumerate(vi):
+                    cur[i][j] = vij
+            else:
+                cur[i] = vi
+    else:
+        setattr(c, k, v)

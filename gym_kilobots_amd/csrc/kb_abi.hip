@@ -91,8 +91,14 @@ int kb_create(const kb_config *cfg, kb_sim **out) {
         if (!(cfg->obj_radius[m] > 0.0f)) return fail(KB_EINVAL, "kb_create: obj_radius must be positive");
     if (cfg->num_objects > 0 && !(cfg->obj_density > 0.0f)) return fail(KB_EINVAL, "kb_create: obj_density must be positive");
     if (cfg->drive_mode < 0 || cfg->drive_mode > KB_DRIVE_PHOTOTAXIS) return fail(KB_EINVAL, "kb_create: bad drive_mode");
-    if (cfg->light_type != KB_LIGHT_NONE && cfg->light_type != KB_LIGHT_CIRCULAR)
+    if (cfg->light_type < KB_LIGHT_NONE || cfg->light_type > KB_LIGHT_COMPOSITE)
         return fail(KB_EINVAL, "kb_create: unsupported light_type");
+    if (cfg->light_type == KB_LIGHT_COMPOSITE) {
+        if (cfg->light_count < 1 || cfg->light_count > KB_MAX_LIGHTS) return fail(KB_EINVAL, "kb_create: 1 <= light_count <= 4 required");
+        for (int i = 0; i < cfg->light_count; ++i)
+            if (cfg->light_kind[i] != KB_LIGHT_CIRCULAR && cfg->light_kind[i] != KB_LIGHT_MOMENTUM)
+                return fail(KB_EINVAL, "kb_create: composite components must be circular or momentum lights");
+    }
     if ((cfg->drive_mode == KB_DRIVE_SIMPLE_PHOTOTAXIS || cfg->drive_mode == KB_DRIVE_PHOTOTAXIS) &&
         cfg->light_type == KB_LIGHT_NONE)
         return fail(KB_EINVAL, "kb_create: phototaxis drive modes need a light");
@@ -131,6 +137,20 @@ int kb_create(const kb_config *cfg, kb_sim **out) {
     p.kl_bot = 1.0f / (1.0f + p.h * cfg->bot_linear_damping);
     p.ka_bot = 1.0f / (1.0f + p.h * cfg->bot_angular_damping);
     p.light_radius = cfg->light_radius;
+    p.lcount = cfg->light_type == KB_LIGHT_COMPOSITE ? cfg->light_count : 1;
+    p.ladim = cfg->light_type == KB_LIGHT_NONE ? 0 : (cfg->light_type == KB_LIGHT_GRADIENT ? 1 : 2 * p.lcount);
+    for (int i = 0; i < KB_MAX_LIGHTS; ++i) {
+        const bool comp = cfg->light_type == KB_LIGHT_COMPOSITE;
+        p.lkind[i] = comp ? cfg->light_kind[i] : cfg->light_type;
+        p.lradius[i] = comp ? cfg->lightc_radius[i] : cfg->light_radius;
+        p.lmaxv[i] = comp ? cfg->lightc_max_velocity[i] : cfg->light_max_velocity;
+        for (int k = 0; k < 2; ++k) {
+            p.llo[i][k] = comp ? cfg->lightc_lo[i][k] : cfg->light_lo[k];
+            p.lhi[i][k] = comp ? cfg->lightc_hi[i][k] : cfg->light_hi[k];
+            p.lalo[i][k] = comp ? cfg->lightc_act_lo[i][k] : cfg->light_act_lo[k];
+            p.lahi[i][k] = comp ? cfg->lightc_act_hi[i][k] : cfg->light_act_hi[k];
+        }
+    }
     for (int i = 0; i < 2; ++i) {
         p.light_lo[i] = cfg->light_lo[i]; p.light_hi[i] = cfg->light_hi[i];
         p.act_lo[i] = cfg->light_act_lo[i]; p.act_hi[i] = cfg->light_act_hi[i];
@@ -180,8 +200,14 @@ int kb_bind(kb_sim *sim, const kb_buffers *b) {
         return fail(KB_ENOTBOUND, "kb_bind: pt_* buffers required in the phototaxis mode");
     if (sim->cfg.num_objects > 0 && (!b->ox || !b->oy || !b->otheta || !b->ovx || !b->ovy || !b->ow || !b->ows_acc))
         return fail(KB_ENOTBOUND, "kb_bind: ox, oy, otheta, ovx, ovy, ow and ows_acc are required when num_objects > 0");
-    if (sim->cfg.light_type != KB_LIGHT_NONE && (!b->light_x || !b->light_y))
+    if (sim->cfg.light_type != KB_LIGHT_NONE && (!b->light_x || (!b->light_y && sim->cfg.light_type != KB_LIGHT_GRADIENT)))
         return fail(KB_ENOTBOUND, "kb_bind: light_x, light_y required when a light is configured");
+    {
+        bool momentum = sim->cfg.light_type == KB_LIGHT_MOMENTUM;
+        if (sim->cfg.light_type == KB_LIGHT_COMPOSITE)
+            for (int i = 0; i < sim->cfg.light_count; ++i) momentum |= sim->cfg.light_kind[i] == KB_LIGHT_MOMENTUM;
+        if (momentum && (!b->light_vx || !b->light_vy)) return fail(KB_ENOTBOUND, "kb_bind: light_vx, light_vy required by a MomentumLight");
+    }
     if ((b->light_value != nullptr) != (b->light_gx != nullptr) || (b->light_value != nullptr) != (b->light_gy != nullptr))
         return fail(KB_EINVAL, "kb_bind: light_value, light_gx, light_gy must be given together");
     if ((b->cmd_vx != nullptr) != (b->cmd_vy != nullptr) || (b->cmd_vx != nullptr) != (b->cmd_w != nullptr))
@@ -253,6 +279,8 @@ int kb_get_poses(kb_sim *sim, float *d_out, void *stream) {
 }
 
 int kb_lds_bytes(const kb_sim *sim) { return sim ? sim->p.L.total : KB_EINVAL; }
+int kb_light_action_dim(const kb_sim *sim) { return sim ? sim->p.ladim : KB_EINVAL; }
+int kb_light_count(const kb_sim *sim) { return sim ? (sim->cfg.light_type == KB_LIGHT_NONE ? 0 : sim->p.lcount) : KB_EINVAL; }
 size_t kb_scratch_bytes(const kb_sim *sim) { return sim ? (size_t)sim->p.E * (size_t)sim->p.cap * 16u : 0; }
 int kb_contact_capacity(const kb_sim *sim) { return sim ? sim->p.cap : KB_EINVAL; }
 int kb_block_threads(const kb_sim *sim) { return sim ? sim->threads : KB_EINVAL; }

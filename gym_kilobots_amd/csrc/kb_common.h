@@ -78,6 +78,7 @@ constexpr int MAX_WAVES = KB_MAX_WAVES;   // waves per workgroup
 constexpr int BK_PER_WAVE = NUM_CLS * RK;
 constexpr int MAX_BUCKETS = MAX_WAVES * BK_PER_WAVE;
 constexpr int BPT = KB_BPT;                // bots per thread (max): N <= BPT * blockDim.x
+constexpr int KB_LIGHT_GENERAL = 99;   // kernel template value: any light model other than NONE / single CIRCULAR
 constexpr int GIANT_ISLAND = 256;     // contacts; larger islands are swept by the whole workgroup
 constexpr int KREG = KB_KREG;               // contacts a lane can keep in registers (register-resident solver)
 constexpr int CAP_LDS = 1024;         // contacts staged in LDS; denser envs stage in the global scratch slice
@@ -104,6 +105,10 @@ struct Params {
     int solver_mode;
     float xmin, ymin, xmax, ymax, inv_cell, r_bot, im_bot, kl_bot, ka_bot, h;
     float light_radius, light_lo[2], light_hi[2], act_lo[2], act_hi[2];
+    // general light model (GradientLight / MomentumLight / CompositeLight): per component
+    int lcount, ladim, lkind[KB_MAX_LIGHTS];
+    float lradius[KB_MAX_LIGHTS], lmaxv[KB_MAX_LIGHTS];
+    float llo[KB_MAX_LIGHTS][2], lhi[KB_MAX_LIGHTS][2], lalo[KB_MAX_LIGHTS][2], lahi[KB_MAX_LIGHTS][2];
     float r_obj[KB_MAX_OBJECTS], im_obj[KB_MAX_OBJECTS], kl_obj, ka_obj;
     Layout L;
 };

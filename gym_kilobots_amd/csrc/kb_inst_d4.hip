@@ -4,6 +4,7 @@
 namespace kb {
 kb_step_fn kb_pick_phototaxis(int light_type, bool objects) {
     if (light_type == KB_LIGHT_CIRCULAR) return objects ? kb_step_kernel<KB_DRIVE_PHOTOTAXIS, KB_LIGHT_CIRCULAR, true> : kb_step_kernel<KB_DRIVE_PHOTOTAXIS, KB_LIGHT_CIRCULAR, false>;
-    return nullptr;
+    // GradientLight, MomentumLight, CompositeLight: one general kernel
+    return objects ? kb_step_kernel<KB_DRIVE_PHOTOTAXIS, KB_LIGHT_GENERAL, true> : kb_step_kernel<KB_DRIVE_PHOTOTAXIS, KB_LIGHT_GENERAL, false>;
 }
 }  // namespace kb

@@ -102,6 +102,38 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
     if (tid == 0) misc[M_STATUS] = 0;
     float lx = 0.0f, ly = 0.0f;
     if (LIGHT_TYPE == KB_LIGHT_CIRCULAR) { lx = g.light_x[e]; ly = g.light_y[e]; }
+    // general light model: state of every component in registers (wave-uniform values)
+    constexpr bool LGEN = LIGHT_TYPE == KB_LIGHT_GENERAL;
+    float glx[KB_MAX_LIGHTS], gly[KB_MAX_LIGHTS], glvx[KB_MAX_LIGHTS], glvy[KB_MAX_LIGHTS];
+#pragma unroll
+    for (int i = 0; i < KB_MAX_LIGHTS; ++i) {
+        glx[i] = 0.0f; gly[i] = 0.0f; glvx[i] = 0.0f; glvy[i] = 0.0f;
+        if (LGEN && i < p.lcount) {
+            glx[i] = g.light_x[(size_t)e * p.lcount + i];
+            if (p.light_type != KB_LIGHT_GRADIENT) gly[i] = g.light_y[(size_t)e * p.lcount + i];
+            if (p.lkind[i] == KB_LIGHT_MOMENTUM) { glvx[i] = g.light_vx[(size_t)e * p.lcount + i]; glvy[i] = g.light_vy[(size_t)e * p.lcount + i]; }
+        }
+    }
+    // value_and_gradients of the general model at one sensor position (metres): light.py:176-189, 137-141;
+    // GradientLight: projection on the gradient direction (intent of light.py:255-260)
+    auto sense_general = [&](float sx, float sy, float &val, float &gx, float &gy) __attribute__((always_inline)) {
+        if (p.light_type == KB_LIGHT_GRADIENT) {
+            float s_, c_;
+            kb_sincosf(glx[0], s_, c_);
+            val = c_ * sx + s_ * sy; gx = c_; gy = s_;
+            return;
+        }
+        float vsum = 0.0f, vbest = 0.0f, bgx = 0.0f, bgy = 0.0f;
+#pragma unroll
+        for (int i = 0; i < KB_MAX_LIGHTS; ++i) {
+            if (i >= p.lcount) break;
+            float v, x, y;
+            kb_light_circular(sx, sy, glx[i], gly[i], p.lradius[i], v, x, y);
+            vsum = i == 0 ? v : vsum + v;
+            if (i == 0 || v > vbest) { vbest = v; bgx = x; bgy = y; }   // np.argmax: first maximum
+        }
+        val = vsum; gx = bgx; gy = bgy;
+    };
     const bool drive = !(p.flags & KB_STEP_NO_DRIVE);
     const float rr = p.r_bot + p.r_bot, rr2 = rr * rr;
     const float rw = B2_POLYGON_RADIUS + p.r_bot, rw2 = rw * rw;
@@ -120,6 +152,36 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
 
     for (int sub = 0; sub < p.n_substeps; ++sub) {
         // ---- light.step: SinglePositionLight.step, light.py:59-75 (uniform per env) ----
+        if (p.light_action && LGEN && drive) {
+            // Light.step of every component: light.py:59-75 (positional), 300-316 (momentum), 237-253 (gradient)
+            const float *la = p.light_action + (size_t)e * p.ladim;
+            if (p.light_type == KB_LIGHT_GRADIENT) {
+                const float pi = 3.14159265358979323846f;
+                float ang = fminf(fmaxf(la[0], -2.0f * pi), 2.0f * pi);
+                if (ang < -pi) ang += 2.0f * pi;
+                if (ang > pi) ang -= 2.0f * pi;
+                glx[0] = ang;
+            } else {
+#pragma unroll
+                for (int i = 0; i < KB_MAX_LIGHTS; ++i) {
+                    if (i >= p.lcount) break;
+                    const float ax = fminf(fmaxf(la[2 * i + 0], p.lalo[i][0]), p.lahi[i][0]);
+                    const float ay = fminf(fmaxf(la[2 * i + 1], p.lalo[i][1]), p.lahi[i][1]);
+                    float nlx, nly;
+                    if (p.lkind[i] == KB_LIGHT_MOMENTUM) {
+                        float mvx = glvx[i] + ax * h, mvy = glvy[i] + ay * h;
+                        const float nv = sqrtf(mvx * mvx + mvy * mvy);
+                        if (nv > p.lmaxv[i]) { const float sc = p.lmaxv[i] / nv; mvx *= sc; mvy *= sc; }
+                        glvx[i] = mvx; glvy[i] = mvy;
+                        nlx = glx[i] + mvx * h; nly = gly[i] + mvy * h;
+                    } else {
+                        nlx = glx[i] + ax * h; nly = gly[i] + ay * h;
+                    }
+                    glx[i] = fminf(fmaxf(nlx, p.llo[i][0]), p.lhi[i][0]);
+                    gly[i] = fminf(fmaxf(nly, p.llo[i][1]), p.lhi[i][1]);
+                }
+            }
+        }
         if (p.light_action && LIGHT_TYPE == KB_LIGHT_CIRCULAR && drive) {
             float ax = fminf(fmaxf(p.light_action[2 * e + 0], p.act_lo[0]), p.act_hi[0]);
             float ay = fminf(fmaxf(p.light_action[2 * e + 1], p.act_lo[1]), p.act_hi[1]);
@@ -137,7 +199,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
             if (drive) {
                 const float t = th[q];
                 float lval = 0.0f, lgx = 0.0f, lgy = 0.0f;
-                if (LIGHT_TYPE == KB_LIGHT_CIRCULAR) {
+                if (LIGHT_TYPE != KB_LIGHT_NONE) {
                     float sx = bx, sy = by;
                     if (DRIVE_MODE != KB_DRIVE_SIMPLE_PHOTOTAXIS) {  // kilobot.py:54-55: world point of (0, -r)
                         float s, c;
@@ -146,7 +208,8 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                         sx = (c * lx0 - s * ly0) + bx;
                         sy = (s * lx0 + c * ly0) + by;
                     }
-                    kb_light_circular(sx / WORLD_SCALE, sy / WORLD_SCALE, lx, ly, p.light_radius, lval, lgx, lgy);
+                    if (LGEN) sense_general(sx / WORLD_SCALE, sy / WORLD_SCALE, lval, lgx, lgy);
+                    else kb_light_circular(sx / WORLD_SCALE, sy / WORLD_SCALE, lx, ly, p.light_radius, lval, lgx, lgy);
                     if (g.light_value) { g.light_value[o + b] = lval; g.light_gx[o + b] = lgx; g.light_gy[o + b] = lgy; }
                 }
                 switch (DRIVE_MODE) {
@@ -1145,6 +1208,15 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
     if (p.n_substeps > 0) for (int k = tid; k < M * OWS; k += nt) g.ows_acc[(size_t)e * MAXOBJ * OWS + k] = owsOld[k];
     if (tid == 0) {
         if (LIGHT_TYPE == KB_LIGHT_CIRCULAR && p.light_action && drive) { g.light_x[e] = lx; g.light_y[e] = ly; }
+        if (LGEN && p.light_action && drive) {
+#pragma unroll
+            for (int i = 0; i < KB_MAX_LIGHTS; ++i) {
+                if (i >= p.lcount) break;
+                g.light_x[(size_t)e * p.lcount + i] = glx[i];
+                if (p.light_type != KB_LIGHT_GRADIENT) g.light_y[(size_t)e * p.lcount + i] = gly[i];
+                if (p.lkind[i] == KB_LIGHT_MOMENTUM) { g.light_vx[(size_t)e * p.lcount + i] = glvx[i]; g.light_vy[(size_t)e * p.lcount + i] = glvy[i]; }
+            }
+        }
         if (misc[M_STATUS]) atomicOr(&g.status[e], (int)misc[M_STATUS]);
 #ifdef KB_PROFILE
         prof_acc[7] += clock64() - prof_t;

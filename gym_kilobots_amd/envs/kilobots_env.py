@@ -21,7 +21,7 @@ import torch
 from .. import _native as nat
 from ..lib.body import World, Body, _world_scale  # noqa: F401
 from ..lib.kilobot import Kilobot
-from ..lib.light import Light, CircularGradientLight
+from ..lib.light import Light, CircularGradientLight, GradientLight, MomentumLight, CompositeLight
 
 
 class UnknownObjectException(Exception):
@@ -148,8 +148,14 @@ class KilobotsEnv(object):
             kb = np.concatenate([kb, vw[0] if self.num_envs == 1 else vw], -1)
         light = None
         if self._light is not None:
-            l = torch.stack([self._sim.light_x, self._sim.light_y], -1).double().cpu().numpy()
-            light = l[0] if self.num_envs == 1 else l
+            if self.num_envs == 1:
+                light = np.asarray(self._light.get_state(), dtype=np.float64)
+            elif isinstance(self._light, GradientLight):
+                light = self._sim.light_x.double().cpu().numpy()[:, None]
+            else:
+                parts = [self._sim.light_x, self._sim.light_y]
+                l = torch.stack([p_.reshape(self.num_envs, -1) for p_ in parts], -1).double().cpu().numpy()
+                light = l.reshape(self.num_envs, -1)
         objs = np.array([o.get_state() for o in self._objects])
         if self._objects:
             op = self._sim.object_poses().double().cpu().numpy()
@@ -220,14 +226,33 @@ class KilobotsEnv(object):
                              obj_friction=float(ob0._friction), obj_linear_damping=float(ob0._linear_damping),
                              obj_angular_damping=float(ob0._angular_damping))
         if self._light is not None:
-            if not isinstance(self._light, CircularGradientLight):
-                raise UnknownLightTypeException('only CircularGradientLight runs on the device in this version')
-            light_type = nat.LIGHT_CIRCULAR
-            overrides.update(light_radius=float(self._light._radius),
-                             light_lo=[float(v) for v in self._light._bounds[0]],
-                             light_hi=[float(v) for v in self._light._bounds[1]],
-                             light_act_lo=[float(v) for v in self._light._action_bounds[0]],
-                             light_act_hi=[float(v) for v in self._light._action_bounds[1]])
+            lt = self._light
+            if isinstance(lt, CompositeLight):
+                comps = lt.lights
+                if not (1 <= len(comps) <= nat.MAX_LIGHTS) or not all(isinstance(c, CircularGradientLight) for c in comps):
+                    raise UnknownLightTypeException('a CompositeLight on the device holds 1..4 circular / momentum lights')
+                pad = nat.MAX_LIGHTS - len(comps)
+                light_type = nat.LIGHT_COMPOSITE
+                overrides.update(
+                    light_count=len(comps),
+                    light_kind=[nat.LIGHT_MOMENTUM if isinstance(c, MomentumLight) else nat.LIGHT_CIRCULAR for c in comps] + [nat.LIGHT_CIRCULAR] * pad,
+                    lightc_radius=[float(c._radius) for c in comps] + [0.2] * pad,
+                    lightc_max_velocity=[float(getattr(c, 'max_velocity', np.inf)) for c in comps] + [np.inf] * pad,
+                    lightc_lo=[[float(v) for v in c._bounds[0]] for c in comps] + [[0.0, 0.0]] * pad,
+                    lightc_hi=[[float(v) for v in c._bounds[1]] for c in comps] + [[0.0, 0.0]] * pad,
+                    lightc_act_lo=[[float(v) for v in c._action_bounds[0]] for c in comps] + [[0.0, 0.0]] * pad,
+                    lightc_act_hi=[[float(v) for v in c._action_bounds[1]] for c in comps] + [[0.0, 0.0]] * pad)
+            elif isinstance(lt, GradientLight):
+                light_type = nat.LIGHT_GRADIENT
+            elif isinstance(lt, CircularGradientLight):
+                light_type = nat.LIGHT_MOMENTUM if isinstance(lt, MomentumLight) else nat.LIGHT_CIRCULAR
+                overrides.update(light_radius=float(lt._radius),
+                                 light_lo=[float(v) for v in lt._bounds[0]], light_hi=[float(v) for v in lt._bounds[1]],
+                                 light_act_lo=[float(v) for v in lt._action_bounds[0]],
+                                 light_act_hi=[float(v) for v in lt._action_bounds[1]],
+                                 light_max_velocity=float(getattr(lt, 'max_velocity', np.inf)))
+            else:
+                raise UnknownLightTypeException('light model %s does not run on the device' % type(lt).__name__)
         N = len(kbs)
         sig = (self.num_envs, N, mode, light_type, tuple(sorted((k, str(v)) for k, v in overrides.items())))
         if self._sim is None or sig != self._sim_signature:
@@ -266,10 +291,22 @@ class KilobotsEnv(object):
             sim.pt_nochange.zero_()
             sim.pt_dir.zero_()
         if self._light is not None:
-            p = self._light._position
-            sim.light_x.fill_(float(p[0]))
-            sim.light_y.fill_(float(p[1]))
-            self._light._world = self.world
+            lt = self._light
+            comps = lt.lights if isinstance(lt, CompositeLight) else (lt,)
+            for i, c in enumerate(comps):
+                c._world = self.world
+                c._slot = i if isinstance(lt, CompositeLight) else None
+            if isinstance(lt, GradientLight):
+                sim.light_x.fill_(float(lt._gradient_angle[0]))
+            else:
+                lx = torch.tensor([[float(c._position[0]) for c in comps]], dtype=torch.float32).expand(self.num_envs, -1)
+                ly = torch.tensor([[float(c._position[1]) for c in comps]], dtype=torch.float32).expand(self.num_envs, -1)
+                lvx = torch.tensor([[float(getattr(c, '_velocity', (0.0, 0.0))[0]) for c in comps]], dtype=torch.float32).expand(self.num_envs, -1)
+                lvy = torch.tensor([[float(getattr(c, '_velocity', (0.0, 0.0))[1]) for c in comps]], dtype=torch.float32).expand(self.num_envs, -1)
+                for name, val in (('light_x', lx), ('light_y', ly), ('light_vx', lvx), ('light_vy', lvy)):
+                    dst = getattr(sim, name)
+                    dst.copy_(val.reshape(dst.shape).to(dst.device))
+            lt._world = self.world
         self.world.backend = sim
         self.world.env_index = 0
 
@@ -284,12 +321,13 @@ class KilobotsEnv(object):
         return self.get_observation()
 
     def _light_action_tensor(self, action):
-        a = torch.as_tensor(np.asarray(action, dtype=np.float32).reshape(-1, 2) if not torch.is_tensor(action) else action,
-                            dtype=torch.float32, device=self._sim.x.device)
-        if a.dim() == 1:
-            a = a.reshape(1, 2)
+        adim = self._light.action_space.shape[0]
+        if torch.is_tensor(action):
+            a = action.to(device=self._sim.x.device, dtype=torch.float32).reshape(-1, adim)
+        else:
+            a = torch.as_tensor(np.asarray(action, dtype=np.float32).reshape(-1, adim), device=self._sim.x.device)
         if a.shape[0] == 1 and self.num_envs > 1:
-            a = a.expand(self.num_envs, 2)
+            a = a.expand(self.num_envs, adim)
         return a.contiguous()
 
     def step(self, action):

@@ -54,8 +54,11 @@ class KilobotSim:
             self.pt_update = torch.zeros(E, N, dtype=torch.int32, device=dev)
             self.pt_nochange = torch.zeros(E, N, dtype=torch.int32, device=dev)
             self.pt_dir = torch.zeros(E, N, dtype=torch.uint8, device=dev)
+        self.light_vx = self.light_vy = None
         if light_type != LIGHT_NONE:
-            self.light_x, self.light_y = f(E), f(E)
+            LC = self._lib.kb_light_count(self._h)
+            shape = (E,) if LC == 1 else (E, LC)
+            self.light_x, self.light_y, self.light_vx, self.light_vy = f(*shape), f(*shape), f(*shape), f(*shape)
         cap = self._lib.kb_contact_capacity(self._h)
         self.ws_key = torch.zeros(E, cap, dtype=torch.int32, device=dev)
         self.ws_acc = f(E, cap)
@@ -169,5 +172,5 @@ class KilobotSim:
     def step(self, n_substeps=1, actions=None, light_action=None, flags=0):
         """n_substeps iterations of the reference substep loop in one kernel launch (asynchronous)."""
         pa = self._ptr(actions, (self.num_envs, self.num_bots, 2), 'actions')
-        pl = self._ptr(light_action, (self.num_envs, 2), 'light_action')
+        pl = self._ptr(light_action, (self.num_envs, self._lib.kb_light_action_dim(self._h)), 'light_action')
         nat.check(self._lib.kb_step(self._h, pa, pl, int(n_substeps), int(flags), self._stream()), 'kb_step')

@@ -53,8 +53,12 @@ enum kb_drive_mode {
 
 enum kb_light_type {
     KB_LIGHT_NONE = 0,
-    KB_LIGHT_CIRCULAR = 1           /* CircularGradientLight             light.py:151-195   */
+    KB_LIGHT_CIRCULAR = 1,          /* CircularGradientLight             light.py:151-195   */
+    KB_LIGHT_GRADIENT = 2,          /* GradientLight                     light.py:218-271   */
+    KB_LIGHT_MOMENTUM = 3,          /* MomentumLight                     light.py:274-319   */
+    KB_LIGHT_COMPOSITE = 4          /* CompositeLight of <= 4 circular / momentum lights, light.py:99-148 */
 };
+#define KB_MAX_LIGHTS 4
 
 /* kb_step flags */
 #define KB_STEP_NO_DRIVE 1          /* world.Step only, kilobot body velocities = 0:
@@ -76,7 +80,7 @@ typedef struct kb_config {
     float light_radius;                         /* metres [0.2]        light.py:152 */
     float light_lo[2], light_hi[2];             /* light position bounds, light.py:44-46 */
     float light_act_lo[2], light_act_hi[2];     /* [-0.01, 0.01]       light.py:49-54 */
-    float light_max_velocity;                   /* reserved (MomentumLight) */
+    float light_max_velocity;                   /* MomentumLight.max_velocity, light.py:289-292 */
     int32_t ws_slots;                           /* warm-start slots per bot [8] */
     float obj_radius[KB_MAX_OBJECTS];           /* metres; Circle(radius=...), body.py:181-192 */
     float obj_density, obj_friction;            /* [2, 0.01] body.py:11-12; friction is not modelled */
@@ -85,6 +89,12 @@ typedef struct kb_config {
     int32_t solver_mode;                        /* 0 = automatic.  Test knobs (results are identical in every mode):
                                                    1 list solver, one wave per island set; 2 list solver, whole
                                                    workgroup per sweep; 3 / 4 = 1 / 2 with contacts staged in `scratch` */
+    /* KB_LIGHT_COMPOSITE only: the component lights (the fields above then are unused) */
+    int32_t light_count;                        /* 1..KB_MAX_LIGHTS */
+    int32_t light_kind[KB_MAX_LIGHTS];          /* KB_LIGHT_CIRCULAR or KB_LIGHT_MOMENTUM */
+    float lightc_radius[KB_MAX_LIGHTS], lightc_max_velocity[KB_MAX_LIGHTS];
+    float lightc_lo[KB_MAX_LIGHTS][2], lightc_hi[KB_MAX_LIGHTS][2];
+    float lightc_act_lo[KB_MAX_LIGHTS][2], lightc_act_hi[KB_MAX_LIGHTS][2];
 } kb_config;
 
 /* Device buffers of one handle.  NULL is allowed for buffers the configuration never touches
@@ -99,8 +109,8 @@ typedef struct kb_buffers {
     float *pt_threshold;                /* PHOTOTAXIS mode */
     int32_t *pt_update, *pt_nochange;   /* PHOTOTAXIS mode */
     uint8_t *pt_dir;                    /* PHOTOTAXIS mode: 0 = 'left', 1 = 'right' */
-    float *light_x, *light_y;           /* [num_envs], metres; required when light_type != NONE */
-    float *light_vx, *light_vy;         /* reserved */
+    float *light_x, *light_y;           /* [num_envs][kb_light_count()], metres; GradientLight: its angle in light_x */
+    float *light_vx, *light_vy;         /* [num_envs][kb_light_count()] MomentumLight velocity (light.py:284-287) */
     float *ox, *oy, *otheta, *ovx, *ovy, *ow; /* objects: [num_envs][num_objects] pose (world units, radians) and body velocity */
     /* warm-start store (Box2D keeps the accumulated normal impulse in each b2Contact): per env a packed
      * list of kb_contact_capacity() entries, owner bots ascending, ws_cnt[bot] entries per owner */
@@ -134,7 +144,8 @@ int kb_set_actions(kb_sim *sim, const float *d_actions, void *stream);
 
 /* n_substeps iterations of the KilobotsEnv.step loop body (kilobots_env.py:168-190) in ONE launch.
  * d_actions (optional): kilobot actions applied first, as kb_set_actions.
- * d_light_action (optional): [num_envs][2] light action, applied every substep (kilobots_env.py:171-172);
+ * d_light_action (optional): [num_envs][kb_light_action_dim()] light action (2 per positional light in
+ * component order, 1 for a GradientLight), applied every substep (kilobots_env.py:171-172);
  * NULL = action None. */
 int kb_step(kb_sim *sim, const float *d_actions, const float *d_light_action, int n_substeps, int flags,
             void *stream);
@@ -145,6 +156,8 @@ int kb_get_poses(kb_sim *sim, float *d_out, void *stream);
 
 /* Introspection */
 int kb_lds_bytes(const kb_sim *sim);            /* dynamic LDS per workgroup (one env per workgroup) */
+int kb_light_action_dim(const kb_sim *sim);     /* floats per env in d_light_action */
+int kb_light_count(const kb_sim *sim);          /* light components per env (0 without a light) */
 int kb_contact_capacity(const kb_sim *sim);     /* contacts (and warm-start entries) per env */
 size_t kb_scratch_bytes(const kb_sim *sim);     /* size of kb_buffers.scratch */
 int kb_block_threads(const kb_sim *sim);

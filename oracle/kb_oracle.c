@@ -149,6 +149,90 @@ static void light_circular(float sx, float sy, float lx, float ly, float R, floa
     *gx = dx; *gy = dy;
 }
 
+/* ---- light models on top of light_circular ------------------------------------------------------
+ * per-env light state: light_x/y/vx/vy [num_envs][count]; GradientLight keeps its angle in light_x. */
+typedef struct { int kind; float radius, maxv, lo[2], hi[2], alo[2], ahi[2]; } lightc_t;
+
+static int light_components(const kbo_config *c, lightc_t *L) {
+    int n = c->light_type == KBO_LIGHT_COMPOSITE ? c->light_count : 1;
+    for (int i = 0; i < n; ++i) {
+        if (c->light_type == KBO_LIGHT_COMPOSITE) {
+            L[i].kind = c->light_kind[i]; L[i].radius = c->lightc_radius[i]; L[i].maxv = c->lightc_max_velocity[i];
+            for (int k = 0; k < 2; ++k) {
+                L[i].lo[k] = c->lightc_lo[i][k]; L[i].hi[k] = c->lightc_hi[i][k];
+                L[i].alo[k] = c->lightc_act_lo[i][k]; L[i].ahi[k] = c->lightc_act_hi[i][k];
+            }
+        } else {
+            L[i].kind = c->light_type; L[i].radius = c->light_radius; L[i].maxv = c->light_max_velocity;
+            for (int k = 0; k < 2; ++k) {
+                L[i].lo[k] = c->light_lo[k]; L[i].hi[k] = c->light_hi[k];
+                L[i].alo[k] = c->light_act_lo[k]; L[i].ahi[k] = c->light_act_hi[k];
+            }
+        }
+    }
+    return n;
+}
+
+int kbo_light_action_dim(const kbo_config *c) {
+    if (c->light_type == KBO_LIGHT_NONE) return 0;
+    if (c->light_type == KBO_LIGHT_GRADIENT) return 1;
+    return 2 * (c->light_type == KBO_LIGHT_COMPOSITE ? c->light_count : 1);
+}
+
+/* Light.step of every component (light.py:59-75, 237-253, 300-316, 122-127) */
+static void light_step_env(const kbo_config *cfg, kbo_state *st, int e, const float *action, float h) {
+    lightc_t L[KBO_MAX_LIGHTS];
+    const int n = light_components(cfg, L);
+    const int adim = kbo_light_action_dim(cfg);
+    const float *a = action + (size_t)e * adim;
+    if (cfg->light_type == KBO_LIGHT_GRADIENT) {
+        /* GradientLight.step: absolute angle action clamped to +-2 pi, wrapped once into [-pi, pi] */
+        const float pi = 3.14159265358979323846f;
+        float ang = fminf(fmaxf(a[0], -2.0f * pi), 2.0f * pi);
+        if (ang < -pi) ang += 2.0f * pi;
+        if (ang > pi) ang -= 2.0f * pi;
+        st->light_x[e] = ang;
+        return;
+    }
+    for (int i = 0; i < n; ++i) {
+        const size_t li = (size_t)e * n + i;
+        float ax = fminf(fmaxf(a[2 * i + 0], L[i].alo[0]), L[i].ahi[0]);
+        float ay = fminf(fmaxf(a[2 * i + 1], L[i].alo[1]), L[i].ahi[1]);
+        float lx, ly;
+        if (L[i].kind == KBO_LIGHT_MOMENTUM) {
+            float vx = st->light_vx[li] + ax * h, vy = st->light_vy[li] + ay * h;
+            float nv = sqrtf(vx * vx + vy * vy);
+            if (nv > L[i].maxv) { float sc = L[i].maxv / nv; vx *= sc; vy *= sc; }
+            st->light_vx[li] = vx; st->light_vy[li] = vy;
+            lx = st->light_x[li] + vx * h; ly = st->light_y[li] + vy * h;
+        } else {
+            lx = st->light_x[li] + ax * h; ly = st->light_y[li] + ay * h;
+        }
+        st->light_x[li] = fminf(fmaxf(lx, L[i].lo[0]), L[i].hi[0]);
+        st->light_y[li] = fminf(fmaxf(ly, L[i].lo[1]), L[i].hi[1]);
+    }
+}
+
+/* value_and_gradients at one sensor position (metres): light.py:176-189, 137-141; GradientLight: the evident
+ * intent of light.py:255-260 (projection on the gradient direction; the reference's dot() only runs for N == 2) */
+static void light_sense(const kbo_config *cfg, const kbo_state *st, int e, float sx, float sy, float *val, float *gx, float *gy) {
+    lightc_t L[KBO_MAX_LIGHTS];
+    const int n = light_components(cfg, L);
+    if (cfg->light_type == KBO_LIGHT_GRADIENT) {
+        float s, c; kbo_sincosf(st->light_x[e], &s, &c);
+        *val = c * sx + s * sy; *gx = c; *gy = s;
+        return;
+    }
+    float vsum = 0.0f, vbest = 0.0f, bgx = 0.0f, bgy = 0.0f;
+    for (int i = 0; i < n; ++i) {
+        float v, x, y;
+        light_circular(sx, sy, st->light_x[(size_t)e * n + i], st->light_y[(size_t)e * n + i], L[i].radius, &v, &x, &y);
+        vsum = i == 0 ? v : vsum + v;
+        if (i == 0 || v > vbest) { vbest = v; bgx = x; bgy = y; }     /* np.argmax: first maximum */
+    }
+    *val = vsum; *gx = bgx; *gy = bgy;
+}
+
 /* ---- Kilobot.step motor law, kilobot.py:86-127 (world-unit body velocity out) ---------------- */
 static void motor_law(int ml, int mr, float th, float h, float *vx, float *vy, float *w) {
     const float max_lin = 0.01f, max_ang = 0.5f * 3.14159265358979323846f;
@@ -507,21 +591,15 @@ static void substep_env(const kbo_config *cfg, const derived_t *d, kbo_state *st
     const size_t o = (size_t)e * N;
     const float h = d->h;
     /* light.step, kilobots_env.py:171-172 */
-    if (light_action && cfg->light_type == KBO_LIGHT_CIRCULAR && !(flags & KBO_STEP_NO_DRIVE)) {
-        /* SinglePositionLight.step, light.py:59-75 (relative actions) */
-        float ax = fminf(fmaxf(light_action[2 * e + 0], cfg->light_act_lo[0]), cfg->light_act_hi[0]);
-        float ay = fminf(fmaxf(light_action[2 * e + 1], cfg->light_act_lo[1]), cfg->light_act_hi[1]);
-        float lx = st->light_x[e] + ax * h, ly = st->light_y[e] + ay * h;
-        st->light_x[e] = fminf(fmaxf(lx, cfg->light_lo[0]), cfg->light_hi[0]);
-        st->light_y[e] = fminf(fmaxf(ly, cfg->light_lo[1]), cfg->light_hi[1]);
-    }
+    if (light_action && cfg->light_type != KBO_LIGHT_NONE && !(flags & KBO_STEP_NO_DRIVE))
+        light_step_env(cfg, st, e, light_action, h);
     for (int b = 0; b < N; ++b) {
         float th = st->theta[o + b];
         float bvx = 0.0f, bvy = 0.0f, bw = 0.0f;
         w->px[b] = st->x[o + b]; w->py[b] = st->y[o + b];
         if (!(flags & KBO_STEP_NO_DRIVE)) {
             float lval = 0.0f, lgx = 0.0f, lgy = 0.0f;
-            if (cfg->light_type == KBO_LIGHT_CIRCULAR) {
+            if (cfg->light_type != KBO_LIGHT_NONE) {
                 /* kilobots_env.py:174-180; sensor position kilobot.py:54-55 / :188-189 */
                 float sx = w->px[b], sy = w->py[b];
                 if (cfg->drive_mode != KBO_DRIVE_SIMPLE_PHOTOTAXIS) {
@@ -530,8 +608,7 @@ static void substep_env(const kbo_config *cfg, const derived_t *d, kbo_state *st
                     sx = (c * lx0 - s * ly0) + w->px[b];
                     sy = (s * lx0 + c * ly0) + w->py[b];
                 }
-                light_circular(sx / WORLD_SCALE, sy / WORLD_SCALE, st->light_x[e], st->light_y[e],
-                               cfg->light_radius, &lval, &lgx, &lgy);
+                light_sense(cfg, st, e, sx / WORLD_SCALE, sy / WORLD_SCALE, &lval, &lgx, &lgy);
                 if (st->light_value) { st->light_value[o + b] = lval; st->light_gx[o + b] = lgx; st->light_gy[o + b] = lgy; }
             }
             switch (cfg->drive_mode) {

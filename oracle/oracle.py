@@ -13,7 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, 'libkb_oracle.so')
 
 DRIVE_VELOCITY, DRIVE_ACCEL, DRIVE_MOTORS, DRIVE_SIMPLE_PHOTOTAXIS, DRIVE_PHOTOTAXIS = range(5)
-LIGHT_NONE, LIGHT_CIRCULAR, LIGHT_GRADIENT, LIGHT_MOMENTUM = range(4)
+LIGHT_NONE, LIGHT_CIRCULAR, LIGHT_GRADIENT, LIGHT_MOMENTUM, LIGHT_COMPOSITE = range(5)
+MAX_LIGHTS = 4
 STEP_NO_DRIVE = 1
 MAX_OBJECTS = 8
 WORLD_SCALE = 25.0
@@ -37,6 +38,10 @@ class Config(C.Structure):
         ('obj_linear_damping', C.c_float), ('obj_angular_damping', C.c_float),
         ('toi_walls', C.c_int32),
         ('solver_mode', C.c_int32),
+        ('light_count', C.c_int32), ('light_kind', C.c_int32 * MAX_LIGHTS),
+        ('lightc_radius', C.c_float * MAX_LIGHTS), ('lightc_max_velocity', C.c_float * MAX_LIGHTS),
+        ('lightc_lo', (C.c_float * 2) * MAX_LIGHTS), ('lightc_hi', (C.c_float * 2) * MAX_LIGHTS),
+        ('lightc_act_lo', (C.c_float * 2) * MAX_LIGHTS), ('lightc_act_hi', (C.c_float * 2) * MAX_LIGHTS),
     ]
 
 
@@ -113,14 +118,30 @@ def default_config(num_envs, num_bots, drive_mode=DRIVE_VELOCITY, light_type=LIG
     c.obj_density, c.obj_friction = 2.0, 0.01
     c.obj_linear_damping = c.obj_angular_damping = 0.8
     c.toi_walls = 0
+    c.light_count = 1
+    for i in range(MAX_LIGHTS):
+        c.light_kind[i] = LIGHT_CIRCULAR
+        c.lightc_radius[i] = 0.2
+        c.lightc_max_velocity[i] = np.inf
+        for k in range(2):
+            c.lightc_lo[i][k], c.lightc_hi[i][k] = -np.inf, np.inf
+            c.lightc_act_lo[i][k], c.lightc_act_hi[i][k] = -0.01, 0.01
     for k, v in kw.items():
-        cur = getattr(c, k)
-        if hasattr(cur, '__len__'):
-            for i, vi in enumerate(v):
-                cur[i] = vi
-        else:
-            setattr(c, k, v)
+        _assign(c, k, v)
     return c
+
+
+def _assign(c, k, v):
+    cur = getattr(c, k)
+    if hasattr(cur, '__len__'):
+        for i, vi in enumerate(v):
+            if hasattr(cur[i], '__len__'):
+                for j, vij in enumerate(vi):
+                    cur[i][j] = vij
+            else:
+                cur[i] = vi
+    else:
+        setattr(c, k, v)
 
 
 class OracleSim:
@@ -139,7 +160,11 @@ class OracleSim:
         self.pt_update = np.zeros((E, N), np.int32)
         self.pt_nochange = np.zeros((E, N), np.int32)
         self.pt_dir = np.zeros((E, N), np.uint8)
-        self.light_x, self.light_y, self.light_vx, self.light_vy = f(E), f(E), f(E), f(E)
+        LC = cfg.light_count if cfg.light_type == LIGHT_COMPOSITE else 1
+        self.light_x, self.light_y, self.light_vx, self.light_vy = f(E, LC), f(E, LC), f(E, LC), f(E, LC)
+        if LC == 1:
+            self.light_x, self.light_y = self.light_x.reshape(E), self.light_y.reshape(E)
+            self.light_vx, self.light_vy = self.light_vx.reshape(E), self.light_vy.reshape(E)
         self.ws_key = np.full((E, self.cap), 0xFFFFFFFF, np.uint32)
         self.ws_acc = f(E, self.cap)
         self.ws_cnt = np.zeros((E, N), np.uint8)

@@ -15,7 +15,7 @@ class OracleBackend:
         self.num_envs, self.num_bots = num_envs, num_bots
         self.drive_mode, self.light_type = drive_mode, light_type
         for name in ('x', 'y', 'theta', 'v', 'w', 'acc_v', 'acc_w', 'motor_l', 'motor_r', 'pt_threshold',
-                     'pt_update', 'pt_nochange', 'pt_dir', 'light_x', 'light_y', 'ws_cnt', 'status',
+                     'pt_update', 'pt_nochange', 'pt_dir', 'light_x', 'light_y', 'light_vx', 'light_vy', 'ws_cnt', 'status',
                      'light_value', 'light_gx', 'light_gy', 'cmd_vx', 'cmd_vy', 'cmd_w',
                      'ox', 'oy', 'otheta', 'ovx', 'ovy', 'ow'):
             setattr(self, name, torch.from_numpy(getattr(self.o, name)))     # shares memory

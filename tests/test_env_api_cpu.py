@@ -197,3 +197,41 @@ def test_env_shard_partition():
         assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         kdist.env_shard(8, 8, 8)
+
+
+def test_other_lights_through_the_env_api():
+    from gym_kilobots_amd.lib import GradientLight, MomentumLight, CompositeLight, SimplePhototaxisKilobot as SPK
+    bounds = (np.array([-1.1, -0.825]), np.array([1.1, 0.825]))
+
+    def make(light_factory):
+        class E(KilobotsEnv):
+            def _configure_environment(self):
+                self._light = light_factory()
+                for i in range(4):
+                    self._add_kilobot(SPK(self.world, position=(0.05 * i, 0.1), light=self._light))
+
+            def get_reward(self, *a):
+                return 0.
+        env = E(sim_factory=OracleBackend)
+        env.reset()
+        return env
+
+    env = make(lambda: GradientLight(angle=0.0))
+    assert env.action_space.shape == (1,)
+    p0 = env.get_state()['kilobots'][:, :2]
+    obs, *_ = env.step(np.array([np.pi / 2]))            # gradient now points along +y: kilobots climb it at 1 cm/s
+    np.testing.assert_allclose(obs['light'], [np.pi / 2], atol=1e-6)
+    np.testing.assert_allclose(obs['kilobots'][:, :2] - p0, np.tile([0.0, 0.01], (4, 1)), atol=2e-6)
+
+    env = make(lambda: MomentumLight(position=np.array([0.0, 0.0]), velocity=np.array([0.006, 0.008]), max_velocity=0.01,
+                                     radius=0.3, bounds=bounds))
+    assert env.observation_space is NotImplemented and env.action_space.shape == (2,)
+    obs, *_ = env.step(np.array([0.0, 0.0]))
+    np.testing.assert_allclose(obs['light'], [0.006, 0.008, 0.006, 0.008], atol=1e-7)      # 10 substeps of 0.1 s
+
+    env = make(lambda: CompositeLight([CircularGradientLight(position=np.array([-0.3, 0.1]), radius=0.3, bounds=bounds),
+                                       MomentumLight(position=np.array([0.4, 0.1]), max_velocity=0.01, radius=0.3, bounds=bounds)]))
+    assert env.action_space.shape == (4,)
+    obs, *_ = env.step(np.array([0.01, 0.0, 0.0, 0.01]))
+    np.testing.assert_allclose(obs['light'][:2], [-0.29, 0.1], atol=1e-6)
+    assert obs['light'].shape == (6,) and obs['light'][3] > 0.1           # the momentum component picked up speed along +y

@@ -169,3 +169,49 @@ def test_kat_simple_phototaxis_moves_1mm_per_substep():
     for k in range(1, 6):
         sim.step(1)
         np.testing.assert_allclose(sim.poses_m()[0, 0, :2], (0.15 - 0.001 * k, 0.0), atol=2e-7)
+
+
+# ---- the other light models: GradientLight, MomentumLight, CompositeLight ---------------
+def test_f2_momentum_light_steps(golden):
+    g = golden['a7_light']['momentum']
+    sim = one_bot(O.DRIVE_MOTORS, O.LIGHT_MOMENTUM, light_lo=g['bounds'][0], light_hi=g['bounds'][1],
+                  light_max_velocity=g['max_velocity'])
+    sim.light_x[...], sim.light_y[...] = g['start'][0], g['start'][1]
+    sim.light_vx[...], sim.light_vy[...] = g['start'][2], g['start'][3]
+    for st in g['steps']:
+        sim.step(1, light_action=np.array([st['action']]))
+        got = [sim.light_x[0], sim.light_y[0], sim.light_vx[0], sim.light_vy[0]]
+        np.testing.assert_allclose(got, st['state'], rtol=2e-6, atol=1e-9)
+
+
+def test_f2_gradient_light_steps(golden):
+    g = golden['a7_light']['gradient']
+    sim = one_bot(O.DRIVE_SIMPLE_PHOTOTAXIS, O.LIGHT_GRADIENT, pos=(0.2, -0.1))
+    sim.light_x[...] = g['start_angle']
+    for st in g['steps']:
+        sim.step(1, light_action=np.array([[st['action']]]))
+        np.testing.assert_allclose(sim.light_x[0], st['angle'], atol=3e-7)
+        np.testing.assert_allclose([sim.light_gx[0, 0], sim.light_gy[0, 0]], st['gradient'], atol=3e-7)
+        # value = projection of the sensor position on the gradient direction (intent of light.py:255-257)
+        np.testing.assert_allclose(sim.light_value[0, 0], 0.2 * st['gradient'][0] - 0.1 * st['gradient'][1], atol=1e-5)
+        sim.set_poses_m(np.array([[(0.2, -0.1)]]), np.array([[0.0]]))
+    assert golden['a7_light']['single_position']['n24_error'] == 'ValueError'   # reference bug recorded, not reproduced
+
+
+def test_f2_composite_light(golden):
+    g = golden['a7_light']['composite']
+    pts = np.array(g['points'])
+    n = len(g['lights'])
+    sim = O.OracleSim(O.default_config(1, len(pts), O.DRIVE_SIMPLE_PHOTOTAXIS, O.LIGHT_COMPOSITE, light_count=n,
+                                       light_kind=[O.LIGHT_CIRCULAR] * n,
+                                       lightc_radius=[l['radius'] for l in g['lights']]))
+    sim.set_poses_m(pts[None], np.zeros((1, len(pts))))
+    for i, l in enumerate(g['lights']):
+        sim.light_x[0, i], sim.light_y[0, i] = l['position']
+    sim.step(1)
+    np.testing.assert_allclose(sim.light_value[0], g['values'], rtol=1e-5, atol=3e-4)
+    np.testing.assert_allclose(np.stack([sim.light_gx[0], sim.light_gy[0]], -1), g['gradients'], atol=3e-6)
+    # composite action = concatenated component actions (light.py:122-127)
+    sim.step(1, light_action=np.array([[0.01, 0.0, 0.0, -0.02]]))
+    np.testing.assert_allclose(sim.light_x[0], [g['lights'][0]['position'][0] + 0.001, g['lights'][1]['position'][0]], atol=1e-7)
+    np.testing.assert_allclose(sim.light_y[0], [g['lights'][0]['position'][1], g['lights'][1]['position'][1] - 0.001], atol=1e-7)

@@ -230,6 +230,44 @@ def test_light_driven_modes(mode):
     assert int(cpu(gsim.status).max()) == 0
 
 
+@pytest.mark.parametrize('light', ['gradient', 'momentum', 'composite'])
+def test_other_light_models(light):
+    """GradientLight, MomentumLight, CompositeLight evaluated and stepped on the device."""
+    E, N = 6, 40
+    xy, th = scenes.gaussian_spawn(E, N, sigma=0.15, seed=19)
+    rng = np.random.RandomState(23)
+    b = dict(light_lo=(-1.1, -0.825), light_hi=(1.1, 0.825))
+    if light == 'gradient':
+        kw, lt, adim = {}, O.LIGHT_GRADIENT, 1
+    elif light == 'momentum':
+        kw, lt, adim = dict(light_radius=0.5, light_max_velocity=0.01, **b), O.LIGHT_MOMENTUM, 2
+    else:
+        kw = dict(light_count=3, light_kind=[O.LIGHT_CIRCULAR, O.LIGHT_MOMENTUM, O.LIGHT_CIRCULAR],
+                  lightc_radius=[0.3, 0.4, 0.25], lightc_max_velocity=[np.inf, 0.008, np.inf],
+                  lightc_lo=[b['light_lo']] * 3 + [(0, 0)], lightc_hi=[b['light_hi']] * 3 + [(0, 0)])
+        lt, adim = O.LIGHT_COMPOSITE, 6
+    for mode in (O.DRIVE_SIMPLE_PHOTOTAXIS, O.DRIVE_PHOTOTAXIS):
+        osim, gsim = make_pair(E, N, mode, lt, xy=xy, th=th, **kw)
+        l0 = rng.uniform(-0.4, 0.4, size=osim.light_x.shape).astype(np.float32)
+        l1 = rng.uniform(-0.4, 0.4, size=osim.light_x.shape).astype(np.float32)
+        v0 = rng.uniform(-0.005, 0.005, size=osim.light_x.shape).astype(np.float32)
+        for name, val in (('light_x', l0), ('light_y', l1), ('light_vx', v0), ('light_vy', -v0)):
+            getattr(osim, name)[...] = val
+            getattr(gsim, name).copy_(dev(val))
+        fields = ('x', 'y', 'theta', 'light_x', 'light_y', 'light_vx', 'light_vy', 'light_value', 'light_gx', 'light_gy')
+        for k in range(5):
+            la = rng.uniform(-7.0 if light == 'gradient' else -0.02, 7.0 if light == 'gradient' else 0.02,
+                             size=(E, adim)).astype(np.float32)
+            if k == 2:
+                osim.step(10)
+                gsim.step(10)
+            else:
+                osim.step(10, light_action=la)
+                gsim.step(10, light_action=dev(la))
+            assert_same(osim, gsim, '%s light mode %d step %d' % (light, mode, k), fields)
+        assert int(cpu(gsim.status).max()) == 0
+
+
 def test_reset_step_resolves_overlaps_without_drive():
     """KilobotsEnv.reset: one world.Step with zero velocities pushes overlapping bodies apart
     (kilobots_env.py:156-157); heavy initial overlap like kilobots_test_envs.py:53-82."""
