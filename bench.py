@@ -37,6 +37,7 @@ def main():
     ap.add_argument('--bots', type=int, default=1024)
     ap.add_argument('--threads', type=int, default=0, help='workgroup size override')
     ap.add_argument('--objects', type=int, default=0, help='cfg4: 4 pushable discs per env (not the headline workload)')
+    ap.add_argument('--no-toi', action='store_true', help='disable the continuous step against the walls (A/B only)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-envs', type=int, default=64)
     ap.add_argument('--traffic-json', default=os.path.join(ROOT, 'profiles', 'traffic_latest.json'))
@@ -66,7 +67,7 @@ def main():
     reps = (E + base - 1) // base
     xy = np.tile(xy1, (reps, 1, 1))[:E]
     th = np.tile(th1, (reps, 1))[:E]
-    sim = KilobotSim(E, N, device=dev, num_objects=args.objects)
+    sim = KilobotSim(E, N, device=dev, num_objects=args.objects, toi_walls=0 if args.no_toi else 1)
     if args.threads:
         sim.block_threads = args.threads
     sim.set_poses_m(xy, th)

@@ -134,7 +134,7 @@ def default_config(num_envs, num_bots, drive_mode=DRIVE_VELOCITY, light_type=LIG
     c.ws_slots = 8
     c.obj_density, c.obj_friction = 2.0, 0.01
     c.obj_linear_damping = c.obj_angular_damping = 0.8
-    c.toi_walls = 0
+    c.toi_walls = 1      # b2World continuousPhysics defaults to true
     c.solver_mode = 0
     c.light_count = 1
     for i in range(MAX_LIGHTS):

@@ -172,6 +172,7 @@ int kb_create(const kb_config *cfg, kb_sim **out) {
     p.kl_obj = 1.0f / (1.0f + p.h * cfg->obj_linear_damping);
     p.ka_obj = 1.0f / (1.0f + p.h * cfg->obj_angular_damping);
     p.solver_mode = cfg->solver_mode;
+    p.toi_walls = cfg->toi_walls;
     p.L = make_layout(p.NP, p.ncell, p.capL);
     if (p.L.total > 160 * 1024) {
         delete s;

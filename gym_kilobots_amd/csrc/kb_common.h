@@ -46,6 +46,8 @@ constexpr float B2_MAX_TRANSLATION_SQ = B2_MAX_TRANSLATION * B2_MAX_TRANSLATION;
 constexpr float B2_MAX_ROTATION = 0.5f * B2_PI;
 constexpr float B2_MAX_ROTATION_SQ = B2_MAX_ROTATION * B2_MAX_ROTATION;
 constexpr float B2_EPSILON = 1.19209290e-07f;
+constexpr float B2_TOI_BAUMGARTE = 0.75f;
+constexpr int B2_MAX_SUBSTEPS = 8;     // b2World::SolveTOI k_maxSubSteps
 constexpr float WORLD_SCALE = 25.0f;  // body.py:7
 
 constexpr float CELL_SIZE = 0.875f;   // world units, >= 2 * bot radius
@@ -91,7 +93,7 @@ struct Layout {  // byte offsets into dynamic LDS
     int wsOff, newOff, oldKey, oldAcc;
     int sPair, sInfo, sAcc, cbk, order;
     int bkStart, bkFill, bkMaxRank, bkList;
-    int next, cellOf, cellXY;
+    int next, cellOf, x0, y0;
     int wsCnt, wsCntNew, active, nList;
     int objF, objCnt, objList, owsOld, owsNew;
     int total;
@@ -102,7 +104,7 @@ struct Params {
     const float *actions;
     const float *light_action;
     int N, NP, NB, M, E, S, gw, gh, ncell, cap, capL, n_substeps, flags, drive_mode, light_type, vel_iters, pos_iters;
-    int solver_mode;
+    int solver_mode, toi_walls;
     float xmin, ymin, xmax, ymax, inv_cell, r_bot, im_bot, kl_bot, ka_bot, h;
     float light_radius, light_lo[2], light_hi[2], act_lo[2], act_hi[2];
     // general light model (GradientLight / MomentumLight / CompositeLight): per component
@@ -119,14 +121,14 @@ inline Layout make_layout(int NP, int ncell, int capL) {
     int o = 0;
     auto take = [&](int bytes) { int r = o; o += (bytes + 15) & ~15; return r; };
     L.px = take(4 * NB); L.py = take(4 * NB); L.vx = take(4 * NB); L.vy = take(4 * NB);
-    L.head = take(4 * ncell); L.dirCnt = take(4 * NB); L.parent = take(4 * NB);
+    L.head = take(2 * ncell + 4); L.dirCnt = take(4 * NB); L.parent = take(4 * NB);   // head: u16 pairs
     L.misc = take(4 * M_COUNT); L.wsum = take(4 * 16);
     L.wsOff = take(2 * NP); L.newOff = take(2 * NP); L.oldKey = take(2 * capL); L.oldAcc = take(4 * capL);
     L.sPair = take(4 * capL); L.sInfo = take(4 * capL); L.sAcc = take(4 * capL);
     L.cbk = take(2 * capL); L.order = take(2 * capL);
     L.bkStart = take(4 * (MAX_BUCKETS + 1)); L.bkFill = take(4 * MAX_BUCKETS);
     L.bkMaxRank = take(4 * MAX_WAVES * NUM_CLS); L.bkList = take(2 * MAX_BUCKETS);
-    L.next = take(2 * NP); L.cellOf = take(2 * NP); L.cellXY = take(4 * NP);
+    L.next = take(2 * NP); L.cellOf = take(2 * NP); L.x0 = take(4 * NB); L.y0 = take(4 * NB);
     L.wsCnt = take(NP); L.wsCntNew = take(NP); L.active = take(2 * NB); L.nList = take(16);
     L.objF = take(4 * 2 * KB_MAX_OBJECTS); L.objCnt = take(4 * KB_MAX_OBJECTS); L.objList = take(2 * KB_MAX_OBJECTS * 32);
     L.owsOld = take(4 * KB_MAX_OBJECTS * 12); L.owsNew = take(4 * KB_MAX_OBJECTS * 12);
@@ -223,6 +225,142 @@ __device__ __forceinline__ void wall_geom(const Params &p, int wl, float x, floa
 #define KB_STAMP(ph) do { } while (0)
 #endif
 
+// b2TimeOfImpact for a circle (radius R) whose centre moves linearly from (x0,y0) to (x1,y1) against wall wl:
+// Box2D's control flow (conservative advancement + bisection / secant root finder) on the closed-form distance of
+// the centre to an axis-aligned wall.  True and t in [0,1] when the state is e_touching.
+__device__ __forceinline__ bool kb_toi_wall(const Params &p, int wl, float R, float x0, float y0, float x1, float y1, float &tout) {
+    const float total = R + B2_POLYGON_RADIUS;
+    const float target = fmaxf(B2_LINEAR_SLOP, total - 3.0f * B2_LINEAR_SLOP);
+    const float tol = 0.25f * B2_LINEAR_SLOP;
+    float nx, ny;
+    auto dist_at = [&](float t) __attribute__((always_inline)) -> float {
+        float dv;
+        wall_geom(p, wl, (1.0f - t) * x0 + t * x1, (1.0f - t) * y0 + t * y1, dv, nx, ny);
+        return dv;
+    };
+    float t1 = 0.0f;
+    for (int iter = 0; iter < 20; ++iter) {
+        const float dist = dist_at(t1);
+        if (fabsf(dist) <= 0.0f) return false;                        // overlapped
+        if (fabsf(dist) < target + tol) { tout = t1; return true; }   // touching
+        float t2 = 1.0f;
+        for (int push = 0; push < 8; ++push) {
+            float s2 = dist_at(t2);
+            if (s2 > target + tol) return false;                      // separated at the end of the step
+            if (s2 > target - tol) { t1 = t2; break; }
+            float s1 = dist_at(t1);
+            if (s1 < target - tol) return false;                      // failed
+            if (s1 <= target + tol) { tout = t1; return true; }
+            float a1 = t1, a2 = t2;
+            for (int root = 0; root < 50; ++root) {                   // bisection / secant alternating
+                const float t = (root & 1) ? a1 + (target - s1) * (a2 - a1) / (s2 - s1) : 0.5f * (a1 + a2);
+                const float sv = dist_at(t);
+                if (fabsf(sv - target) < tol) { t2 = t; break; }
+                if (sv > target) { a1 = t; s1 = sv; } else { a2 = t; s2 = sv; }
+            }
+        }
+    }
+    return false;                                                     // failed (iteration cap)
+}
+
+// b2World::SolveTOI + b2Island::SolveTOI for one circular body against the arena walls (the only TOI events Box2D
+// computes for non-bullet bodies).  (x0,y0,a0): pose at the start of the step; (x,y,a): pose after b2Island::Solve;
+// (vx,vy,w): velocity after the solve; updated in place.
+__device__ __forceinline__ void kb_toi_walls_body(const Params &p, float R, float im, float x0, float y0, float a0,
+                                                  float &x, float &y, float &a, float &vx, float &vy, float &w) {
+    const float h = p.h;
+    const float total = R + B2_POLYGON_RADIUS;
+    // quick reject: a body that stays clear of every wall by more than its contact radius has no TOI event
+    {
+        const float m0 = fminf(fminf(x0 - p.xmin, p.xmax - x0), fminf(y0 - p.ymin, p.ymax - y0));
+        const float m1 = fminf(fminf(x - p.xmin, p.xmax - x), fminf(y - p.ymin, p.ymax - y));
+        if (m0 > total && m1 > total) return;
+    }
+    float alpha0 = 0.0f;
+    float c0x = x0, c0y = y0, ca0 = a0, cx = x, cy = y, ca = a;
+    for (int ev = 0; ev < B2_MAX_SUBSTEPS; ++ev) {
+        float minAlpha = 1.0f;
+#pragma unroll
+        for (int wl = 0; wl < 4; ++wl) {
+            float t;
+            float alpha = 1.0f;
+            if (kb_toi_wall(p, wl, R, c0x, c0y, cx, cy, t)) alpha = fminf(alpha0 + (1.0f - alpha0) * t, 1.0f);
+            if (alpha < minAlpha) minAlpha = alpha;
+        }
+        if (1.0f - 10.0f * B2_EPSILON < minAlpha) break;
+        const float beta = (minAlpha - alpha0) / (1.0f - alpha0);      // b2Body::Advance
+        c0x += beta * (cx - c0x); c0y += beta * (cy - c0y); ca0 += beta * (ca - ca0);
+        alpha0 = minAlpha;
+        cx = c0x; cy = c0y; ca = ca0;
+        bool touch[4];
+        float wnx[4], wny[4];
+#pragma unroll
+        for (int wl = 0; wl < 4; ++wl) {                               // manifolds of the static contacts at the TOI pose
+            float dist;
+            wall_geom(p, wl, cx, cy, dist, wnx[wl], wny[wl]);
+            touch[wl] = !(dist * dist > total * total);
+            if (dist < 0.0f) { wnx[wl] = -wnx[wl]; wny[wl] = -wny[wl]; }
+        }
+        for (int it = 0; it < 20; ++it) {                              // SolveTOIPositionConstraints
+            float minSep = 0.0f;
+#pragma unroll
+            for (int wl = 0; wl < 4; ++wl) {
+                if (!touch[wl]) continue;
+                float dist, bx, by;
+                wall_geom(p, wl, cx, cy, dist, bx, by);
+                const float along = (wnx[wl] == bx && wny[wl] == by) ? dist : -dist;
+                const float sep = along - B2_POLYGON_RADIUS - R;
+                minSep = fminf(minSep, sep);
+                const float C = kb_clampf(B2_TOI_BAUMGARTE * (sep + B2_LINEAR_SLOP), -B2_MAX_LINEAR_CORRECTION, 0.0f);
+                const float K = 0.0f + im;
+                const float imp = K > 0.0f ? -C / K : 0.0f;
+                cx += im * (imp * wnx[wl]); cy += im * (imp * wny[wl]);
+            }
+            if (minSep >= -1.5f * B2_LINEAR_SLOP) break;
+        }
+        c0x = cx; c0y = cy; ca0 = ca;                                   // leap of faith to the new safe state
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int it = 0; it < p.vel_iters; ++it) {                      // velocity constraints, no warm starting
+#pragma unroll
+            for (int wl = 0; wl < 4; ++wl) {
+                if (!touch[wl]) continue;
+                const float vn = vx * wnx[wl] + vy * wny[wl];
+                const float k = 0.0f + im;
+                const float nm = k > 0.0f ? 1.0f / k : 0.0f;
+                float lambda = -(nm * vn);
+                const float newimp = fmaxf(acc[wl] + lambda, 0.0f);
+                lambda = newimp - acc[wl];
+                acc[wl] = newimp;
+                vx += im * (lambda * wnx[wl]); vy += im * (lambda * wny[wl]);
+            }
+        }
+        const float hh = (1.0f - minAlpha) * h;                         // integrate the rest of the step
+        const float tx = hh * vx, ty = hh * vy;
+        if (tx * tx + ty * ty > B2_MAX_TRANSLATION_SQ) {
+            const float ratio = B2_MAX_TRANSLATION / sqrtf(tx * tx + ty * ty);
+            vx *= ratio; vy *= ratio;
+        }
+        const float rot = hh * w;
+        if (rot * rot > B2_MAX_ROTATION_SQ) w *= B2_MAX_ROTATION / fabsf(rot);
+        cx += hh * vx; cy += hh * vy; ca += hh * w;
+    }
+    x = cx; y = cy; a = ca;
+}
+
+// atomic exchange on a 16-bit LDS cell (LDS atomics are 32-bit: compare-and-swap on the containing word)
+__device__ __forceinline__ unsigned kb_exch16(unsigned short *base, int idx, unsigned val) {
+    unsigned *word = reinterpret_cast<unsigned *>(base) + (idx >> 1);
+    const int sh = (idx & 1) * 16;
+    unsigned old = *reinterpret_cast<volatile unsigned *>(word);
+    for (;;) {
+        const unsigned want = (old & ~(0xFFFFu << sh)) | (val << sh);
+        const unsigned seen = atomicCAS(word, old, want);
+        if (seen == old) break;
+        old = seen;
+    }
+    return (old >> sh) & 0xFFFFu;
+}
+
 __device__ __forceinline__ int dir_dx(int k) { return (k == 1 || k == 3) ? 1 : (k == 4 ? -1 : 0); }
 __device__ __forceinline__ int dir_dy(int k) { return (k >= 2) ? 1 : 0; }
 
@@ -253,6 +391,7 @@ __device__ __forceinline__ unsigned block_scan_u8(const unsigned char *cnt, unsi
 }
 
 #define KB_NEXT(b) (nextb[b] == EMPTY16 ? EMPTY32 : (unsigned)nextb[b])
+#define KB_HEAD(c) (head[c] == EMPTY16 ? EMPTY32 : (unsigned)head[c])
 
 
 typedef void (*kb_step_fn)(const Params);

@@ -17,7 +17,9 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
 
     float *px = (float *)(smem + p.L.px), *py = (float *)(smem + p.L.py);
     float *vx = (float *)(smem + p.L.vx), *vy = (float *)(smem + p.L.vy);
-    unsigned *head = (unsigned *)(smem + p.L.head), *dirCnt = (unsigned *)(smem + p.L.dirCnt);
+    unsigned short *head = (unsigned short *)(smem + p.L.head);   // per-cell list heads (EMPTY16 = empty)
+    unsigned *dirCnt = (unsigned *)(smem + p.L.dirCnt);
+    float *x0s = (float *)(smem + p.L.x0), *y0s = (float *)(smem + p.L.y0);   // positions at the start of the substep
     unsigned *islCnt = dirCnt;  // alias: dirCnt is dead once the contacts are emitted
     unsigned *parent = (unsigned *)(smem + p.L.parent);
     unsigned *misc = (unsigned *)(smem + p.L.misc), *wsum = (unsigned *)(smem + p.L.wsum);
@@ -31,7 +33,6 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
     unsigned *bkMaxRank = (unsigned *)(smem + p.L.bkMaxRank);
     unsigned short *bkList = (unsigned short *)(smem + p.L.bkList);
     unsigned short *nextb = (unsigned short *)(smem + p.L.next), *cellOf = (unsigned short *)(smem + p.L.cellOf);
-    unsigned *cellXY = (unsigned *)(smem + p.L.cellXY);   // cx | cy << 16 (saves the div / mod by the grid width)
     unsigned char *wsCnt = smem + p.L.wsCnt, *wsCntNew = smem + p.L.wsCntNew;
     unsigned char *active = smem + p.L.active, *nList = smem + p.L.nList;
     float *objIm = (float *)(smem + p.L.objF), *objR = objIm + MAXOBJ;   // inverse mass / radius of object m
@@ -55,13 +56,14 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
     unsigned short *gCbk = reinterpret_cast<unsigned short *>(gAcc + p.cap), *gOrder = gCbk + p.cap;
 
 #ifdef KB_PROFILE
-    long long prof_acc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long prof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     constexpr int M_PROF_DEPTH = 12;
     long long prof_t = clock64();
 #endif
 
     // ---- load state; optional fused set_action (kilobot.py:235-241, 283-289) ----
     float th[BPT], bw[BPT], cv[BPT], cw[BPT], av[BPT], aw[BPT];
+    float sth0[BPT];     // angle at the start of the substep (continuous step against the walls)
     const bool velmode = DRIVE_MODE == KB_DRIVE_VELOCITY || DRIVE_MODE == KB_DRIVE_ACCEL;
 #pragma unroll
     for (int q = 0; q < BPT; ++q) {
@@ -98,7 +100,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
         objIm[tid] = p.im_obj[tid]; objR[tid] = p.r_obj[tid];
     }
     for (int k = tid; k < M * OWS; k += nt) owsOld[k] = g.ows_acc[(size_t)e * MAXOBJ * OWS + k];
-    for (int c = tid; c < p.ncell; c += nt) head[c] = EMPTY32;
+    for (int c = tid; c < p.ncell; c += nt) head[c] = EMPTY16;
     if (tid == 0) misc[M_STATUS] = 0;
     float lx = 0.0f, ly = 0.0f;
     if (LIGHT_TYPE == KB_LIGHT_CIRCULAR) { lx = g.light_x[e]; ly = g.light_y[e]; }
@@ -150,6 +152,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
     }
     __syncthreads();
 
+    KB_STAMP(13);    // kernel start: state loads, warm-start scan and list load
     for (int sub = 0; sub < p.n_substeps; ++sub) {
         // ---- light.step: SinglePositionLight.step, light.py:59-75 (uniform per env) ----
         if (p.light_action && LGEN && drive) {
@@ -196,6 +199,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
             if (b >= N) continue;
             float bvx = 0.0f, bvy = 0.0f, bww = 0.0f;
             const float bx = px[b], by = py[b];
+            x0s[b] = bx; y0s[b] = by; sth0[q] = th[q];
             if (drive) {
                 const float t = th[q];
                 float lval = 0.0f, lgx = 0.0f, lgy = 0.0f;
@@ -267,9 +271,10 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
             cy = cy < 0 ? 0 : (cy >= p.gh ? p.gh - 1 : cy);
             const int cell = cy * p.gw + cx;
             cellOf[b] = (unsigned short)cell;
-            cellXY[b] = (unsigned)cx | ((unsigned)cy << 16);
-            nextb[b] = (unsigned short)atomicExch(&head[cell], (unsigned)b);
+            nextb[b] = (unsigned short)kb_exch16(head, cell, (unsigned)b);
         }
+        float oth0 = 0.0f;
+        if (tid < M) { x0s[N + tid] = px[N + tid]; y0s[N + tid] = py[N + tid]; oth0 = oth; }
         if (tid < M) {   // b2Island::Solve damping of the objects; they keep their velocity between substeps
             vx[N + tid] *= p.kl_obj; vy[N + tid] *= p.kl_obj; oww *= p.ka_obj;
             parent[N + tid] = N + tid;
@@ -285,8 +290,8 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
         auto find_pass = [&](unsigned *sPair, unsigned *sInfo, int stageCap_) __attribute__((always_inline)) {
 #pragma unroll 1
             for (int a = tid; a < N; a += nt) {
-                const unsigned cxy = cellXY[a];
-                const int cx = cxy & 0xFFFF, cy = cxy >> 16;
+                const int cell = cellOf[a];
+                const int cx = cell % p.gw, cy = cell / p.gw;
                 const float ax = px[a], ay = py[a];
                 unsigned cnt = 0, mine = 0;
 #pragma unroll
@@ -294,7 +299,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                     const int ox = cx + dir_dx(k), oy = cy + dir_dy(k);
                     if (ox < 0 || ox >= p.gw || oy >= p.gh) continue;
                     unsigned ck = 0;
-                    for (unsigned b = head[oy * p.gw + ox]; b != EMPTY32; b = KB_NEXT(b)) {
+                    for (unsigned b = KB_HEAD(oy * p.gw + ox); b != EMPTY32; b = KB_NEXT(b)) {
                         if (k == 0 && (int)b <= a) continue;
                         const float dx = px[b] - ax, dy = py[b] - ay;
                         const float dd = dx * dx + dy * dy;
@@ -489,8 +494,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                     const int a = pr & 0xFFFF;
                     const unsigned b = pr >> 16;
                     const int cell = cellOf[a];
-                    const unsigned cxy = cellXY[a];
-                    const int cx = cxy & 0xFFFF, cy = cxy >> 16;
+                    const int cx = cell % p.gw, cy = cell / p.gw;
                     const float ax = px[a], ay = py[a];
                     if (k == 0) cls = CLS_SAME;
                     else if (k == 1) cls = CLS_E + (cx & 1);
@@ -502,13 +506,13 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                     for (int k2 = 0; k2 < k; ++k2) sbase += (int)((dc >> (6 * k2)) & 63u);
                     // rank base: contacts of this (cell, direction) group owned by lower-id bots of the cell
                     int rbase = 0;
-                    for (unsigned a2 = head[cell]; a2 != EMPTY32; a2 = KB_NEXT(a2))
+                    for (unsigned a2 = KB_HEAD(cell); a2 != EMPTY32; a2 = KB_NEXT(a2))
                         if ((int)a2 < a) rbase += (int)((dirCnt[a2] >> (6 * k)) & 63u);
                     // position of b among a's touching partners of this direction, in ascending id order
                     int j = 0;
                     if (((dc >> (6 * k)) & 63u) > 1u) {
                         const int oc = (cy + dir_dy(k)) * p.gw + (cx + dir_dx(k));
-                        for (unsigned b2 = head[oc]; b2 != EMPTY32; b2 = KB_NEXT(b2)) {
+                        for (unsigned b2 = KB_HEAD(oc); b2 != EMPTY32; b2 = KB_NEXT(b2)) {
                             if (b2 >= b || (k == 0 && (int)b2 <= a)) continue;
                             const float ex = px[b2] - ax, ey = py[b2] - ay;
                             if (!(ex * ex + ey * ey > rr2)) j++;
@@ -546,7 +550,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
             while (true) { unsigned t = ((volatile unsigned *)parent)[r]; if (t == r) break; r = t; }
             parent[b] = r;   // only ever replaces an ancestor by an older ancestor: concurrent walks stay valid
             islCnt[b] = 0;
-            head[cellOf[b]] = EMPTY32;
+            head[cellOf[b]] = EMPTY16;
             active[b] = 1; active[NB + b] = 0;
         }
         if (tid < M) {
@@ -559,6 +563,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
         }
         const unsigned newTotal = block_scan_u8(wsCntNew, newOff, NP, wsum);   // (barriers inside)
         const bool newInLds = newTotal <= (unsigned)p.capL;
+        KB_STAMP(14);    // flatten roots + warm-start offset scan
         // per contact: island size (giant islands force the cooperative sweep) and contacts per wave
         auto census = [&](const unsigned *sPair) __attribute__((always_inline)) {
             for (int c = tid; c < ncon; c += nt) {
@@ -911,6 +916,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                 }
                 px[b] += h * vxx; py[b] += h * vyy;
                 th[q] += h * ww;
+                vx[b] = vxx; vy[b] = vyy; bw[q] = ww;
             }
             if (tid < M) {   // objects: same integrator (b2Island writes the clamped velocity back to the body)
                 const int b = N + tid;
@@ -1102,6 +1108,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                     }
                     px[b] += h * vxx; py[b] += h * vyy;
                     th[q] += h * ww;
+                    vx[b] = vxx; vy[b] = vyy; bw[q] = ww;
                 }
                 if (tid < M) {   // objects
                     const int b = N + tid;
@@ -1181,6 +1188,51 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
             if (big) solve_list(gPair, gInfo, gAcc, gCbk, gOrder); else solve_list(lPair, lInfo, lAcc, lCbk, lOrder);
         }
         __syncthreads();
+        // ---- b2World::SolveTOI: continuous step of every dynamic body against the static walls ----
+        // Only bodies that come within their contact radius of a wall can have a TOI event.  They are collected in
+        // a candidate list (in the staging area, idle after the solve) and processed one per thread, so that
+        // the event logic exists once in the kernel instead of once per unrolled bot slot.
+        if (p.toi_walls) {
+            float *cTh0 = reinterpret_cast<float *>(lInfo), *cTh = lAcc, *cW = reinterpret_cast<float *>(lCbk);
+            int cand[BPT], candObj = -1;
+            if (tid == 0) misc[M_NCON] = 0;
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < BPT; ++q) {
+                const int b = tid + q * nt;
+                cand[q] = -1;
+                if (b >= N) continue;
+                const float total = p.r_bot + B2_POLYGON_RADIUS;
+                const float xa = x0s[b], ya = y0s[b], xb = px[b], yb = py[b];
+                const float m0 = fminf(fminf(xa - p.xmin, p.xmax - xa), fminf(ya - p.ymin, p.ymax - ya));
+                const float m1 = fminf(fminf(xb - p.xmin, p.xmax - xb), fminf(yb - p.ymin, p.ymax - yb));
+                if (m0 > total && m1 > total) continue;          // stays clear of every wall: no event possible
+                const int i = (int)atomicAdd(&misc[M_NCON], 1u);
+                if (i >= p.capL / 2) { atomicOr(&misc[M_STATUS], 8u); continue; }
+                cand[q] = i;
+                lPair[i] = (unsigned)b; cTh0[i] = sth0[q]; cTh[i] = th[q]; cW[i] = bw[q];
+            }
+            if (tid < M) {
+                const int i = (int)atomicAdd(&misc[M_NCON], 1u);
+                if (i < p.capL / 2) { candObj = i; lPair[i] = (unsigned)(N + tid); cTh0[i] = oth0; cTh[i] = oth; cW[i] = oww; }
+                else atomicOr(&misc[M_STATUS], 8u);
+            }
+            __syncthreads();
+            const int ncand = min((int)misc[M_NCON], p.capL / 2);
+            for (int i = tid; i < ncand; i += nt) {
+                const int b = (int)lPair[i];
+                const bool isObj = b >= N;
+                const float R = isObj ? objR[b - N] : p.r_bot, im = isObj ? objIm[b - N] : p.im_bot;
+                float x_ = px[b], y_ = py[b], a_ = cTh[i], vx_ = vx[b], vy_ = vy[b], w_ = cW[i];
+                kb_toi_walls_body(p, R, im, x0s[b], y0s[b], cTh0[i], x_, y_, a_, vx_, vy_, w_);
+                px[b] = x_; py[b] = y_; vx[b] = vx_; vy[b] = vy_; cTh[i] = a_; cW[i] = w_;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < BPT; ++q)
+                if (cand[q] >= 0) { th[q] = cTh[cand[q]]; bw[q] = cW[cand[q]]; }
+            if (candObj >= 0) { oth = cTh[candObj]; oww = cW[candObj]; }
+        }
         // the new warm-start list becomes the old one
         for (int b = tid; b < NP; b += nt) { wsCnt[b] = wsCntNew[b]; wsOff[b] = newOff[b]; }
         for (int k = tid; k < M * OWS; k += nt) owsOld[k] = owsNew[k];
@@ -1220,8 +1272,9 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
         if (misc[M_STATUS]) atomicOr(&g.status[e], (int)misc[M_STATUS]);
 #ifdef KB_PROFILE
         prof_acc[7] += clock64() - prof_t;
-        for (int k = 0; k < 8; ++k) g.status[p.E + 13 * e + k] += (int)(prof_acc[k] >> 4);   // units of 16 cycles
-        for (int k = 8; k < 13; ++k) g.status[p.E + 13 * e + k] += (int)prof_acc[k];
+        for (int k = 0; k < 8; ++k) g.status[p.E + 16 * e + k] += (int)(prof_acc[k] >> 4);   // units of 16 cycles
+        for (int k = 8; k < 13; ++k) g.status[p.E + 16 * e + k] += (int)prof_acc[k];
+        for (int k = 13; k < 16; ++k) g.status[p.E + 16 * e + k] += (int)(prof_acc[k] >> 4);
 #endif
     }
 }

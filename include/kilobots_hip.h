@@ -85,7 +85,7 @@ typedef struct kb_config {
     float obj_radius[KB_MAX_OBJECTS];           /* metres; Circle(radius=...), body.py:181-192 */
     float obj_density, obj_friction;            /* [2, 0.01] body.py:11-12; friction is not modelled */
     float obj_linear_damping, obj_angular_damping; /* [0.8, 0.8] body.py:15-16 */
-    int32_t toi_walls;                          /* reserved */
+    int32_t toi_walls;                          /* [1] b2World::SolveTOI against the static walls (continuousPhysics) */
     int32_t solver_mode;                        /* 0 = automatic.  Test knobs (results are identical in every mode):
                                                    1 list solver, one wave per island set; 2 list solver, whole
                                                    workgroup per sweep; 3 / 4 = 1 / 2 with contacts staged in `scratch` */
@@ -120,7 +120,8 @@ typedef struct kb_buffers {
     float *light_value, *light_gx, *light_gy; /* optional outputs: last sensed light (kilobots_env.py:176-180) */
     float *cmd_vx, *cmd_vy, *cmd_w;     /* optional outputs: body velocity written by the drive law */
     int32_t *status;                    /* required: [num_envs]; bit0 contact capacity overflow,
-                                           bit1 warm-start slot overflow, bit2 rank/cell overflow */
+                                           bit1 warm-start slot overflow, bit2 rank/cell overflow,
+                                           bit3 more than 512 bodies near the walls in one substep (TOI skipped for the rest) */
     void *scratch;                      /* required: kb_scratch_bytes() bytes; contact staging of envs whose
                                            contacts do not fit the LDS staging area (contents are transient) */
     float *ows_acc;                     /* objects: [num_envs][8][12] warm-start impulses of object-object (column =

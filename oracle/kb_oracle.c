@@ -23,6 +23,9 @@
  *   - arena walls are the four infinite lines of the closed chain loop of
  *     kilobots_env.py:46-51 with exact axis normals.
  *   - no sleeping (world is created with doSleep=True, kilobots_env.py:45).
+ *   - continuous step (b2World::SolveTOI) only against the static walls, which is all Box2D does for
+ *     non-bullet bodies; b2TimeOfImpact's control flow is followed with the closed-form linear distance
+ *     of a circle centre to an axis-aligned wall instead of GJK + separating-axis evaluation.
  *   - pushable objects are circles (body.py:181-192); their Coulomb friction against walls (mixed
  *     coefficient sqrt(0.01 * 0.2)) and against each other (0.01) is not modelled, so contacts never
  *     spin an object; kilobot contacts are frictionless in the reference too (kilobot.py:26).
@@ -48,6 +51,8 @@
 #define B2_MAX_ROTATION (0.5f * B2_PI)
 #define B2_MAX_ROTATION_SQ (B2_MAX_ROTATION * B2_MAX_ROTATION)
 #define B2_EPSILON 1.19209290e-07f
+#define B2_TOI_BAUMGARTE 0.75f
+#define B2_MAX_SUBSTEPS 8         /* b2World::SolveTOI k_maxSubSteps */
 #define WORLD_SCALE 25.0f              /* body.py:7 */
 
 #define CELL_SIZE 0.875f               /* world units; >= 2 * bot radius (0.825) */
@@ -287,6 +292,7 @@ typedef struct {
     contact_t *con; int ncon, cap;
     int *parent; unsigned char *active, *next_active;
     int *woff, *wnoff;     /* packed warm-start offsets: previous / next substep */
+    float *x0, *y0, *a0;   /* poses at the start of the step (continuous step) */
     int status;
 } work_t;
 
@@ -432,6 +438,118 @@ static inline float wall_dist(const derived_t *d, int wl, float x, float y, floa
     }
 }
 
+/* b2TimeOfImpact for a circle (radius R) whose centre moves linearly from (x0,y0) to (x1,y1) against wall wl.
+ * Returns 1 and *t in [0,1] when the state is e_touching, 0 otherwise (separated / overlapped / failed). */
+static int toi_wall(const derived_t *d, int wl, float R, float x0, float y0, float x1, float y1, float *tout) {
+    const float total = R + B2_POLYGON_RADIUS;
+    const float target = fmaxf(B2_LINEAR_SLOP, total - 3.0f * B2_LINEAR_SLOP);
+    const float tol = 0.25f * B2_LINEAR_SLOP;
+    float nx, ny;
+#define DIST_AT(t) wall_dist(d, wl, (1.0f - (t)) * x0 + (t) * x1, (1.0f - (t)) * y0 + (t) * y1, &nx, &ny)
+    float t1 = 0.0f;
+    for (int iter = 0; iter < 20; ++iter) {
+        const float dist = DIST_AT(t1);
+        if (fabsf(dist) <= 0.0f) return 0;                       /* overlapped */
+        if (fabsf(dist) < target + tol) { *tout = t1; return 1; }  /* touching */
+        int done = 0;
+        float t2 = 1.0f;
+        for (int push = 0; push < 8; ++push) {
+            float s2 = DIST_AT(t2);
+            if (s2 > target + tol) return 0;                     /* separated at the end of the step */
+            if (s2 > target - tol) { t1 = t2; break; }
+            float s1 = DIST_AT(t1);
+            if (s1 < target - tol) return 0;                     /* failed */
+            if (s1 <= target + tol) { *tout = t1; return 1; }
+            float a1 = t1, a2 = t2;
+            for (int root = 0; root < 50; ++root) {              /* bisection / secant alternating, b2_toiRootIters */
+                float t = (root & 1) ? a1 + (target - s1) * (a2 - a1) / (s2 - s1) : 0.5f * (a1 + a2);
+                float sv = DIST_AT(t);
+                if (fabsf(sv - target) < tol) { t2 = t; break; }
+                if (sv > target) { a1 = t; s1 = sv; } else { a2 = t; s2 = sv; }
+            }
+            (void)done;
+        }
+    }
+#undef DIST_AT
+    return 0;                                                    /* failed (iteration cap) */
+}
+
+/* b2World::SolveTOI + b2Island::SolveTOI for ONE circular body against the arena walls (the only TOI events Box2D
+ * computes for non-bullet bodies).  (x0,y0,a0): pose at the start of the step; (x,y,a): pose after b2Island::Solve;
+ * (vx,vy,w): velocity after the solve.  Pose and velocity are updated in place. */
+static void toi_walls_body(const kbo_config *cfg, const derived_t *d, float R, float im,
+                           float x0, float y0, float a0, float *x, float *y, float *a, float *vx, float *vy, float *w) {
+    const float h = d->h;
+    const float total = R + B2_POLYGON_RADIUS;
+    float alpha0 = 0.0f;
+    float c0x = x0, c0y = y0, ca0 = a0, cx = *x, cy = *y, ca = *a;
+    for (int ev = 0; ev < B2_MAX_SUBSTEPS; ++ev) {
+        float minAlpha = 1.0f;
+        for (int wl = 0; wl < 4; ++wl) {
+            float t;
+            float alpha = 1.0f;
+            if (toi_wall(d, wl, R, c0x, c0y, cx, cy, &t)) alpha = fminf(alpha0 + (1.0f - alpha0) * t, 1.0f);
+            if (alpha < minAlpha) minAlpha = alpha;
+        }
+        if (1.0f - 10.0f * B2_EPSILON < minAlpha) break;
+        /* b2Body::Advance */
+        const float beta = (minAlpha - alpha0) / (1.0f - alpha0);
+        c0x += beta * (cx - c0x); c0y += beta * (cy - c0y); ca0 += beta * (ca - ca0);
+        alpha0 = minAlpha;
+        cx = c0x; cy = c0y; ca = ca0;
+        /* manifolds of the static contacts at the TOI pose */
+        int touch[4]; float wnx[4], wny[4];
+        for (int wl = 0; wl < 4; ++wl) {
+            float dist = wall_dist(d, wl, cx, cy, &wnx[wl], &wny[wl]);
+            touch[wl] = !(dist * dist > total * total);
+            if (dist < 0.0f) { wnx[wl] = -wnx[wl]; wny[wl] = -wny[wl]; }
+        }
+        /* b2ContactSolver::SolveTOIPositionConstraints, 20 iterations */
+        for (int it = 0; it < 20; ++it) {
+            float minSep = 0.0f;
+            for (int wl = 0; wl < 4; ++wl) {
+                if (!touch[wl]) continue;
+                float bx, by; float dist = wall_dist(d, wl, cx, cy, &bx, &by);
+                float along = (wnx[wl] == bx && wny[wl] == by) ? dist : -dist;
+                float sep = along - B2_POLYGON_RADIUS - R;
+                minSep = fminf(minSep, sep);
+                float C = clampf(B2_TOI_BAUMGARTE * (sep + B2_LINEAR_SLOP), -B2_MAX_LINEAR_CORRECTION, 0.0f);
+                float K = 0.0f + im;
+                float imp = K > 0.0f ? -C / K : 0.0f;
+                cx += im * (imp * wnx[wl]); cy += im * (imp * wny[wl]);
+            }
+            if (minSep >= -1.5f * B2_LINEAR_SLOP) break;
+        }
+        c0x = cx; c0y = cy; ca0 = ca;                              /* leap of faith to the new safe state */
+        /* velocity constraints without warm starting */
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int it = 0; it < cfg->vel_iters; ++it) {
+            for (int wl = 0; wl < 4; ++wl) {
+                if (!touch[wl]) continue;
+                float vn = *vx * wnx[wl] + *vy * wny[wl];
+                float k = 0.0f + im;
+                float nm = k > 0.0f ? 1.0f / k : 0.0f;
+                float lambda = -(nm * vn);
+                float newimp = fmaxf(acc[wl] + lambda, 0.0f);
+                lambda = newimp - acc[wl];
+                acc[wl] = newimp;
+                *vx += im * (lambda * wnx[wl]); *vy += im * (lambda * wny[wl]);
+            }
+        }
+        /* integrate the rest of the step */
+        const float hh = (1.0f - minAlpha) * h;
+        float tx = hh * *vx, ty = hh * *vy;
+        if (tx * tx + ty * ty > B2_MAX_TRANSLATION_SQ) {
+            float ratio = B2_MAX_TRANSLATION / sqrtf(tx * tx + ty * ty);
+            *vx *= ratio; *vy *= ratio;
+        }
+        float rot = hh * *w;
+        if (rot * rot > B2_MAX_ROTATION_SQ) *w *= B2_MAX_ROTATION / fabsf(rot);
+        cx += hh * *vx; cy += hh * *vy; ca += hh * *w;
+    }
+    *x = cx; *y = cy; *a = ca;
+}
+
 /* b2Island::Solve for one env (all islands; islands only matter for the position-iteration early-out) */
 static void world_step_env(const kbo_config *cfg, const derived_t *d, kbo_state *st, int e, work_t *w) {
     const int N = w->N;
@@ -515,6 +633,9 @@ static void world_step_env(const kbo_config *cfg, const derived_t *d, kbo_state 
         st->ws_key[idx] = key; st->ws_acc[idx] = c->acc;
     }
     /* integrate positions */
+    for (int b = 0; b < N + w->M; ++b) { w->x0[b] = w->px[b]; w->y0[b] = w->py[b]; }
+    for (int b = 0; b < N; ++b) w->a0[b] = st->theta[(size_t)e * N + b];
+    for (int m = 0; m < w->M; ++m) w->a0[N + m] = st->otheta[(size_t)e * w->M + m];
     for (int b = 0; b < N; ++b) {
         float tx = h * w->vx[b], ty = h * w->vy[b];
         if (tx * tx + ty * ty > B2_MAX_TRANSLATION_SQ) {
@@ -581,6 +702,15 @@ static void world_step_env(const kbo_config *cfg, const derived_t *d, kbo_state 
         }
         memcpy(w->active, w->next_active, (size_t)T);
         if (!any) break;
+    }
+    /* b2World::SolveTOI: continuous step of every dynamic body against the static walls */
+    if (cfg->toi_walls) {
+        for (int b = 0; b < N; ++b)
+            toi_walls_body(cfg, d, d->r_bot, d->im_bot, w->x0[b], w->y0[b], w->a0[b], &w->px[b], &w->py[b],
+                           &st->theta[(size_t)e * N + b], &w->vx[b], &w->vy[b], &w->bw[b]);
+        for (int m = 0; m < w->M; ++m)
+            toi_walls_body(cfg, d, d->r_obj[m], d->im_obj[m], w->x0[N + m], w->y0[N + m], w->a0[N + m], &w->px[N + m],
+                           &w->py[N + m], &st->otheta[(size_t)e * w->M + m], &w->vx[N + m], &w->vy[N + m], &w->bw[N + m]);
     }
 }
 
@@ -684,8 +814,9 @@ static int work_alloc(work_t *w, const kbo_config *cfg, const derived_t *d) {
     memset(w, 0, sizeof(*w));
     int N = cfg->num_bots, M = cfg->num_objects, T = N + M;
     w->N = N; w->M = M; w->S = cfg->ws_slots;
-    w->px = (float *)malloc(sizeof(float) * T * 5);
+    w->px = (float *)malloc(sizeof(float) * T * 8);
     w->py = w->px + T; w->vx = w->py + T; w->vy = w->vx + T; w->bw = w->vy + T;
+    w->x0 = w->bw + T; w->y0 = w->x0 + T; w->a0 = w->y0 + T;
     w->cell = (int *)malloc(sizeof(int) * T * 3); w->cx = w->cell + T; w->cy = w->cx + T;
     w->cell_start = (int *)malloc(sizeof(int) * (d->gw * d->gh + 1));
     w->cell_items = (int *)malloc(sizeof(int) * T);

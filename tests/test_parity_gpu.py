@@ -203,6 +203,40 @@ def test_walls_and_corners():
     assert (np.abs(p[:, 0]) <= 1.0 - lim).all() and (np.abs(p[:, 1]) <= 0.75 - lim).all()
 
 
+@pytest.mark.parametrize('toi', [0, 1])
+def test_continuous_step_against_walls(toi):
+    """b2World::SolveTOI restated for the walls: pivoting kilobots (2.5 mm per substep) and a pushed disc hit the
+    walls at every phase; with toi_walls=1 nobody ends a substep deeper than the TOI target."""
+    E, N = 2, 48
+    rng = np.random.RandomState(29)
+    xy = np.zeros((E, N, 2))
+    for e in range(E):
+        xy[e, :12] = np.stack([0.975 - rng.uniform(0, 0.004, 12), np.linspace(-0.6, 0.6, 12)], -1)
+        xy[e, 12:24] = np.stack([-0.975 + rng.uniform(0, 0.004, 12), np.linspace(-0.6, 0.6, 12)], -1)
+        xy[e, 24:36] = np.stack([np.linspace(-0.8, 0.8, 12), 0.725 - rng.uniform(0, 0.004, 12)], -1)
+        xy[e, 36:48] = np.stack([np.linspace(-0.8, 0.8, 12), -0.725 + rng.uniform(0, 0.004, 12)], -1)
+    th = rng.uniform(-np.pi, np.pi, size=(E, N))
+    objs = np.tile(np.array([[0.9, 0.2], [-0.55, -0.655]])[None], (E, 1, 1))
+    osim, gsim = make_pair(E, N, O.DRIVE_MOTORS, xy=xy, th=th, objects=objs, toi_walls=toi)
+    ml = np.where(rng.rand(E, N) < 0.5, 255, 0).astype(np.uint8)
+    mr = (255 - ml).astype(np.uint8)
+    osim.motor_l[...], osim.motor_r[...] = ml, mr
+    gsim.motor_l.copy_(dev(ml))
+    gsim.motor_r.copy_(dev(mr))
+    deepest = 1.0
+    for k in range(40):
+        osim.step(1)
+        gsim.step(1)
+        assert_same(osim, gsim, 'toi=%d substep %d' % (toi, k), OBJ_FIELDS)
+        p = osim.poses_m()
+        deepest = min(deepest, (1.0 - np.abs(p[..., 0])).min(), (0.75 - np.abs(p[..., 1])).min())
+    assert int(cpu(gsim.status).max()) == 0
+    if toi:
+        assert deepest > 0.0165 - 0.005 / 25 - 0.25 * 0.005 / 25 - 1e-6     # TOI target - tolerance
+    else:
+        assert deepest < 0.0165 - 0.0008                                     # discrete step alone tunnels ~1-2 mm
+
+
 @pytest.mark.parametrize('mode', [O.DRIVE_SIMPLE_PHOTOTAXIS, O.DRIVE_PHOTOTAXIS])
 def test_light_driven_modes(mode):
     E, N = 8, 48

@@ -31,7 +31,7 @@ def main():
     E, N = args.envs, args.bots
     assert 'prof' in os.environ.get('KB_HIP_LIB', ''), 'run with KB_HIP_LIB=.../libkilobots_hip_prof.so'
     sim = KilobotSim(E, N)
-    sim.status = torch.zeros(E + 13 * E, dtype=torch.int32, device=sim.device)   # status + stamp area
+    sim.status = torch.zeros(E + 16 * E, dtype=torch.int32, device=sim.device)   # status + stamp area
     sim._bind()
     xy1, th1 = scenes.lattice_spawn(8, N, seed=1000)
     reps = (E + 7) // 8
@@ -48,14 +48,16 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / args.steps
-    raw = sim.status[E:].reshape(E, 13).double().cpu().numpy() / (args.steps * args.fused)
+    raw = sim.status[E:].reshape(E, 16).double().cpu().numpy() / (args.steps * args.fused)
     st = raw[:, :8] * 16
     mean = st.mean(0)
     print('launch %.3f ms (%d substeps per launch); cycles per env-substep (wave 0), mean over %d envs:' % (ms, args.fused, E))
     for name, c in zip(PHASES, mean):
         print('  %-18s %9.0f  %5.1f%%' % (name, c, 100 * c / mean.sum()))
     print('  %-18s %9.0f' % ('total', mean.sum()))
-    ex = raw[:, 8:].mean(0)
+    ex = raw[:, 8:13].mean(0)
+    extra = raw[:, 13:16].mean(0) * 16
+    print('  kernel start (per launch) %.0f, flatten+scan (part of islands+buckets) %.0f' % (extra[0], extra[1]))
     print('  wave 0 per substep: keys %.1f, depth rounds/sweep %.1f (deepest wave of the env %.1f), position sweeps %.2f, reg-path fraction %.2f' % (ex[0], ex[4], ex[1], ex[2], ex[3]))
 
 
