@@ -159,6 +159,7 @@ int kb_create(const kb_config *cfg, kb_sim **out) {
     if (cap > 2304) cap = 2304;
     if (cap < 4L * p.N + 64) cap = 4L * p.N + 64;
     cap += 40L * cfg->num_objects;
+    cap = (cap + 7) & ~7L;
     p.cap = (int)cap;
     p.capL = p.cap < CAP_LDS ? p.cap : CAP_LDS;
     p.NP = (p.N + 3) & ~3;
@@ -173,8 +174,8 @@ int kb_create(const kb_config *cfg, kb_sim **out) {
     p.ka_obj = 1.0f / (1.0f + p.h * cfg->obj_angular_damping);
     p.solver_mode = cfg->solver_mode;
     p.toi_walls = cfg->toi_walls;
-    p.L = make_layout(p.NP, p.ncell, p.capL);
-    if (p.L.total > 160 * 1024) {
+    p.lds_total = lds::total(p.NB, p.capL, p.NP, p.ncell);
+    if (p.lds_total > 160 * 1024) {
         delete s;
         return fail(KB_ELDS, "kb_create: configuration needs more than 160 KiB of LDS per env");
     }
@@ -255,13 +256,13 @@ int kb_step(kb_sim *sim, const float *d_actions, const float *d_light_action, in
     default: break;
     }
     if (!fn) return fail(KB_EINVAL, "kb_step: no kernel for this drive mode / light type");
-    if (p.L.total > 64 * 1024 && !sim->attr_set) {
+    if (p.lds_total > 64 * 1024 && !sim->attr_set) {
         hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, p.L.total);
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, p.lds_total);
         if (e2 != hipSuccess) return fail(KB_EHIP, "kb_step: hipFuncSetAttribute: %s", hipGetErrorString(e2));
         sim->attr_set = true;
     }
-    hipLaunchKernelGGL(fn, dim3((unsigned)p.E), dim3((unsigned)sim->threads), (size_t)p.L.total,
+    hipLaunchKernelGGL(fn, dim3((unsigned)p.E), dim3((unsigned)sim->threads), (size_t)p.lds_total,
                        (hipStream_t)stream, p);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return fail(KB_EHIP, "kb_step: %s", hipGetErrorString(err));
@@ -279,7 +280,7 @@ int kb_get_poses(kb_sim *sim, float *d_out, void *stream) {
     return KB_OK;
 }
 
-int kb_lds_bytes(const kb_sim *sim) { return sim ? sim->p.L.total : KB_EINVAL; }
+int kb_lds_bytes(const kb_sim *sim) { return sim ? sim->p.lds_total : KB_EINVAL; }
 int kb_light_action_dim(const kb_sim *sim) { return sim ? sim->p.ladim : KB_EINVAL; }
 int kb_light_count(const kb_sim *sim) { return sim ? (sim->cfg.light_type == KB_LIGHT_NONE ? 0 : sim->p.lcount) : KB_EINVAL; }
 size_t kb_scratch_bytes(const kb_sim *sim) { return sim ? (size_t)sim->p.E * (size_t)sim->p.cap * 16u : 0; }

@@ -86,18 +86,42 @@ constexpr int KREG = KB_KREG;               // contacts a lane can keep in regis
 constexpr int CAP_LDS = 1024;         // contacts staged in LDS; denser envs stage in the global scratch slice
 
 enum { M_NCON = 0, M_TOTAL = 1, M_ANY = 2, M_STATUS = 3, M_MAXISL = 4, M_PROF = 5, M_WCNT = 8, M_WFILL = 8 + MAX_WAVES, M_COUNT = 8 + 2 * MAX_WAVES };
+static_assert(M_COUNT <= 64, "misc area");
 
-struct Layout {  // byte offsets into dynamic LDS
-    int px, py, vx, vy;
-    int head, dirCnt, parent, misc, wsum;
-    int wsOff, newOff, oldKey, oldAcc;
-    int sPair, sInfo, sAcc, cbk, order;
-    int bkStart, bkFill, bkMaxRank, bkList;
-    int next, cellOf, x0, y0;
-    int wsCnt, wsCntNew, active, nList;
-    int objF, objCnt, objList, owsOld, owsNew;
-    int total;
-};
+// ---- LDS layout ----------------------------------------------------------------------------------
+// Fixed-size arrays sit at compile-time offsets; the arrays that scale with the scene are grouped by stride so
+// that every offset is (constant + k * stride) of four scene sizes.  The kernel recomputes offsets where they
+// are used instead of keeping ~35 of them alive in scalar registers for the whole launch.
+namespace lds {
+constexpr int A16(int x) { return (x + 15) & ~15; }
+constexpr int MISC = 0;
+constexpr int WSUM = MISC + A16(4 * 64);
+constexpr int BKSTART = WSUM + A16(4 * 16);
+constexpr int BKFILL = BKSTART + A16(4 * (MAX_BUCKETS + 1));
+constexpr int BKMAXRANK = BKFILL + A16(4 * MAX_BUCKETS);
+constexpr int BKLIST = BKMAXRANK + A16(4 * MAX_WAVES * NUM_CLS);
+constexpr int NLIST = BKLIST + A16(2 * MAX_BUCKETS);
+constexpr int OBJF = NLIST + 16;
+constexpr int OBJCNT = OBJF + A16(4 * 2 * KB_MAX_OBJECTS);
+constexpr int OBJLIST = OBJCNT + A16(4 * KB_MAX_OBJECTS);
+constexpr int OWSOLD = OBJLIST + A16(2 * KB_MAX_OBJECTS * 32);
+constexpr int OWSNEW = OWSOLD + A16(4 * KB_MAX_OBJECTS * 12);
+constexpr int FIXED = OWSNEW + A16(4 * KB_MAX_OBJECTS * 12);
+// per-body 32-bit arrays (stride 4 * NB): px py vx vy x0 y0 dirCnt parent
+constexpr int BODY32_COUNT = 8;
+// per-contact 32-bit arrays (stride 4 * capL): sPair sInfo sAcc oldAcc;  16-bit (stride 2 * capL): cbk order oldKey
+constexpr int CON32_COUNT = 4, CON16_COUNT = 3;
+// per-bot 16-bit arrays (stride 2 * NP): wsOff newOff next cellOf;  8-bit (stride NP): wsCnt wsCntNew
+constexpr int BOT16_COUNT = 4, BOT8_COUNT = 2;
+__host__ __device__ inline int body32(int NB, int k) { return FIXED + 4 * NB * k; }
+__host__ __device__ inline int con32(int NB, int capL, int k) { return body32(NB, BODY32_COUNT) + 4 * capL * k; }
+__host__ __device__ inline int con16(int NB, int capL, int k) { return con32(NB, capL, CON32_COUNT) + 2 * capL * k; }
+__host__ __device__ inline int bot16(int NB, int capL, int NP, int k) { return con16(NB, capL, CON16_COUNT) + 2 * NP * k; }
+__host__ __device__ inline int bot8(int NB, int capL, int NP, int k) { return bot16(NB, capL, NP, BOT16_COUNT) + NP * k; }
+__host__ __device__ inline int active(int NB, int capL, int NP) { return bot8(NB, capL, NP, BOT8_COUNT); }
+__host__ __device__ inline int head(int NB, int capL, int NP) { return (active(NB, capL, NP) + 2 * NB + 15) & ~15; }
+__host__ __device__ inline int total(int NB, int capL, int NP, int ncell) { return (head(NB, capL, NP) + 2 * ncell + 4 + 15) & ~15; }
+}  // namespace lds
 
 struct Params {
     kb_buffers buf;
@@ -112,29 +136,9 @@ struct Params {
     float lradius[KB_MAX_LIGHTS], lmaxv[KB_MAX_LIGHTS];
     float llo[KB_MAX_LIGHTS][2], lhi[KB_MAX_LIGHTS][2], lalo[KB_MAX_LIGHTS][2], lahi[KB_MAX_LIGHTS][2];
     float r_obj[KB_MAX_OBJECTS], im_obj[KB_MAX_OBJECTS], kl_obj, ka_obj;
-    Layout L;
+    int lds_total;
 };
 
-inline Layout make_layout(int NP, int ncell, int capL) {
-    const int NB = NP + KB_MAX_OBJECTS + 4;   // bodies: kilobots, then objects at index N + m; last slot = scratch body
-    Layout L;
-    int o = 0;
-    auto take = [&](int bytes) { int r = o; o += (bytes + 15) & ~15; return r; };
-    L.px = take(4 * NB); L.py = take(4 * NB); L.vx = take(4 * NB); L.vy = take(4 * NB);
-    L.head = take(2 * ncell + 4); L.dirCnt = take(4 * NB); L.parent = take(4 * NB);   // head: u16 pairs
-    L.misc = take(4 * M_COUNT); L.wsum = take(4 * 16);
-    L.wsOff = take(2 * NP); L.newOff = take(2 * NP); L.oldKey = take(2 * capL); L.oldAcc = take(4 * capL);
-    L.sPair = take(4 * capL); L.sInfo = take(4 * capL); L.sAcc = take(4 * capL);
-    L.cbk = take(2 * capL); L.order = take(2 * capL);
-    L.bkStart = take(4 * (MAX_BUCKETS + 1)); L.bkFill = take(4 * MAX_BUCKETS);
-    L.bkMaxRank = take(4 * MAX_WAVES * NUM_CLS); L.bkList = take(2 * MAX_BUCKETS);
-    L.next = take(2 * NP); L.cellOf = take(2 * NP); L.x0 = take(4 * NB); L.y0 = take(4 * NB);
-    L.wsCnt = take(NP); L.wsCntNew = take(NP); L.active = take(2 * NB); L.nList = take(16);
-    L.objF = take(4 * 2 * KB_MAX_OBJECTS); L.objCnt = take(4 * KB_MAX_OBJECTS); L.objList = take(2 * KB_MAX_OBJECTS * 32);
-    L.owsOld = take(4 * KB_MAX_OBJECTS * 12); L.owsNew = take(4 * KB_MAX_OBJECTS * 12);
-    L.total = o;
-    return L;
-}
 
 // ---- device math ----------------------------------------------------------------------------
 // sin/cos: Cephes single-precision algorithm (argument reduction by pi/4 in three parts, degree-3

@@ -8,38 +8,40 @@ namespace kb {
 template <int DRIVE_MODE, int LIGHT_TYPE, bool OBJ>
 __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_step_kernel(const Params p) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int e = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    int e = blockIdx.x;
+    const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
     const int N = p.N, NP = p.NP, S = p.S;
-    const size_t o = (size_t)e * N;
-    const size_t wo = (size_t)e * p.cap;       // this env's slice of the packed warm-start / scratch arrays
+    size_t o = (size_t)e * N;
+    size_t wo = (size_t)e * p.cap;       // this env's slice of the packed warm-start / scratch arrays
     const float h = p.h;
 
-    float *px = (float *)(smem + p.L.px), *py = (float *)(smem + p.L.py);
-    float *vx = (float *)(smem + p.L.vx), *vy = (float *)(smem + p.L.vy);
-    unsigned short *head = (unsigned short *)(smem + p.L.head);   // per-cell list heads (EMPTY16 = empty)
-    unsigned *dirCnt = (unsigned *)(smem + p.L.dirCnt);
-    float *x0s = (float *)(smem + p.L.x0), *y0s = (float *)(smem + p.L.y0);   // positions at the start of the substep
+    const int NB = p.NB, capL_ = p.capL;
+    // LDS arrays (offsets: namespace lds in kb_common.h)
+    // positions, velocities and start-of-substep positions as (x, y) pairs: one 8-byte LDS access per body
+    float2 *pos = (float2 *)(smem + lds::body32(NB, 0)), *vel = (float2 *)(smem + lds::body32(NB, 2));
+    float2 *start = (float2 *)(smem + lds::body32(NB, 4));
+    unsigned *dirCnt = (unsigned *)(smem + lds::body32(NB, 6)), *parent = (unsigned *)(smem + lds::body32(NB, 7));
     unsigned *islCnt = dirCnt;  // alias: dirCnt is dead once the contacts are emitted
-    unsigned *parent = (unsigned *)(smem + p.L.parent);
-    unsigned *misc = (unsigned *)(smem + p.L.misc), *wsum = (unsigned *)(smem + p.L.wsum);
-    unsigned short *wsOff = (unsigned short *)(smem + p.L.wsOff), *newOff = (unsigned short *)(smem + p.L.newOff);
-    unsigned short *oldKey = (unsigned short *)(smem + p.L.oldKey);
-    float *oldAcc = (float *)(smem + p.L.oldAcc);
-    unsigned *lPair = (unsigned *)(smem + p.L.sPair), *lInfo = (unsigned *)(smem + p.L.sInfo);
-    float *lAcc = (float *)(smem + p.L.sAcc);
-    unsigned short *lCbk = (unsigned short *)(smem + p.L.cbk), *lOrder = (unsigned short *)(smem + p.L.order);
-    unsigned *bkStart = (unsigned *)(smem + p.L.bkStart), *bkFill = (unsigned *)(smem + p.L.bkFill);
-    unsigned *bkMaxRank = (unsigned *)(smem + p.L.bkMaxRank);
-    unsigned short *bkList = (unsigned short *)(smem + p.L.bkList);
-    unsigned short *nextb = (unsigned short *)(smem + p.L.next), *cellOf = (unsigned short *)(smem + p.L.cellOf);
-    unsigned char *wsCnt = smem + p.L.wsCnt, *wsCntNew = smem + p.L.wsCntNew;
-    unsigned char *active = smem + p.L.active, *nList = smem + p.L.nList;
-    float *objIm = (float *)(smem + p.L.objF), *objR = objIm + MAXOBJ;   // inverse mass / radius of object m
-    unsigned *objCnt = (unsigned *)(smem + p.L.objCnt);                 // kilobots touching object m
-    unsigned short *objList = (unsigned short *)(smem + p.L.objList);   // ... and who they are
-    float *owsOld = (float *)(smem + p.L.owsOld), *owsNew = (float *)(smem + p.L.owsNew);   // object warm-start tables
-    const int M = OBJ ? p.M : 0, NB = p.NB;   // OBJ = false: every object loop below folds away
+    unsigned *lPair = (unsigned *)(smem + lds::con32(NB, capL_, 0)), *lInfo = (unsigned *)(smem + lds::con32(NB, capL_, 1));
+    float *lAcc = (float *)(smem + lds::con32(NB, capL_, 2)), *oldAcc = (float *)(smem + lds::con32(NB, capL_, 3));
+    unsigned short *lCbk = (unsigned short *)(smem + lds::con16(NB, capL_, 0)), *lOrder = (unsigned short *)(smem + lds::con16(NB, capL_, 1));
+    unsigned short *oldKey = (unsigned short *)(smem + lds::con16(NB, capL_, 2));
+    unsigned short *wsOff = (unsigned short *)(smem + lds::bot16(NB, capL_, NP, 0)), *newOff = (unsigned short *)(smem + lds::bot16(NB, capL_, NP, 1));
+    unsigned short *nextb = (unsigned short *)(smem + lds::bot16(NB, capL_, NP, 2)), *cellOf = (unsigned short *)(smem + lds::bot16(NB, capL_, NP, 3));
+    unsigned char *wsCnt = smem + lds::bot8(NB, capL_, NP, 0), *wsCntNew = smem + lds::bot8(NB, capL_, NP, 1);
+    unsigned char *active = smem + lds::active(NB, capL_, NP);
+    unsigned short *head = (unsigned short *)(smem + lds::head(NB, capL_, NP));   // per-cell list heads (EMPTY16 = empty)
+    unsigned *misc = (unsigned *)(smem + lds::MISC), *wsum = (unsigned *)(smem + lds::WSUM);
+    unsigned *bkStart = (unsigned *)(smem + lds::BKSTART), *bkFill = (unsigned *)(smem + lds::BKFILL);
+    unsigned *bkMaxRank = (unsigned *)(smem + lds::BKMAXRANK);
+    unsigned short *bkList = (unsigned short *)(smem + lds::BKLIST);
+    unsigned char *nList = smem + lds::NLIST;
+    float *objIm = (float *)(smem + lds::OBJF), *objR = objIm + MAXOBJ;   // inverse mass / radius of object m
+    unsigned *objCnt = (unsigned *)(smem + lds::OBJCNT);                 // kilobots touching object m
+    unsigned short *objList = (unsigned short *)(smem + lds::OBJLIST);   // ... and who they are
+    float *owsOld = (float *)(smem + lds::OWSOLD), *owsNew = (float *)(smem + lds::OWSNEW);   // object warm-start tables
+    const int M = OBJ ? p.M : 0;   // OBJ = false: every object loop below folds away
     // inverse mass / radius of a body id: kilobot < N, object N + m, wall >= WALL_CODE (static, edge skin radius)
     auto bim = [&](int id) __attribute__((always_inline)) -> float {
         return id >= WALL_CODE ? 0.0f : ((!OBJ || id < N) ? p.im_bot : objIm[id - N]);
@@ -50,10 +52,23 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
 
     const kb_buffers &g = p.buf;
     // contact staging in global scratch, used when an env has more contacts than fit the LDS staging area
-    unsigned *gPair = reinterpret_cast<unsigned *>(g.scratch) + wo * 4;
-    unsigned *gInfo = gPair + p.cap;
-    float *gAcc = reinterpret_cast<float *>(gInfo + p.cap);
-    unsigned short *gCbk = reinterpret_cast<unsigned short *>(gAcc + p.cap), *gOrder = gCbk + p.cap;
+    unsigned *gPair, *gInfo;
+    float *gAcc;
+    unsigned short *gCbk, *gOrder;
+    // Global addresses are re-derived from an opaque copy of the block index at the top of every substep and in
+    // the epilogue: otherwise the compiler keeps the prologue's per-lane 64-bit addresses alive (and spilled to
+    // scratch memory) across the whole substep loop just to reuse them for the final stores.
+#define KB_ENV_ADDRESSES()                                                                          \
+    do {                                                                                            \
+        int e_ = blockIdx.x;                                                                        \
+        asm volatile("" : "+s"(e_));                                                                \
+        e = e_; o = (size_t)e * N; wo = (size_t)e * p.cap;                                          \
+        gPair = reinterpret_cast<unsigned *>(g.scratch) + wo * 4;                                   \
+        gInfo = gPair + p.cap;                                                                      \
+        gAcc = reinterpret_cast<float *>(gInfo + p.cap);                                            \
+        gCbk = reinterpret_cast<unsigned short *>(gAcc + p.cap); gOrder = gCbk + p.cap;             \
+    } while (0)
+    KB_ENV_ADDRESSES();
 
 #ifdef KB_PROFILE
     long long prof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -70,7 +85,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
         const int b = tid + q * nt;
         th[q] = 0.0f; bw[q] = 0.0f; cv[q] = 0.0f; cw[q] = 0.0f; av[q] = 0.0f; aw[q] = 0.0f;
         if (b < N) {
-            px[b] = g.x[o + b]; py[b] = g.y[o + b]; th[q] = g.theta[o + b];
+            pos[b].x = g.x[o + b]; pos[b].y = g.y[o + b]; th[q] = g.theta[o + b];
             wsCnt[b] = g.ws_cnt[o + b];
             if (velmode) { cv[q] = g.v[o + b]; cw[q] = g.w[o + b]; }
             if (DRIVE_MODE == KB_DRIVE_ACCEL) { av[q] = g.acc_v[o + b]; aw[q] = g.acc_w[o + b]; }
@@ -95,7 +110,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
     float oth = 0.0f, oww = 0.0f;
     if (tid < M) {
         const size_t oi = (size_t)e * M + tid;
-        px[N + tid] = g.ox[oi]; py[N + tid] = g.oy[oi]; vx[N + tid] = g.ovx[oi]; vy[N + tid] = g.ovy[oi];
+        pos[N + tid].x = g.ox[oi]; pos[N + tid].y = g.oy[oi]; vel[N + tid].x = g.ovx[oi]; vel[N + tid].y = g.ovy[oi];
         oth = g.otheta[oi]; oww = g.ow[oi];
         objIm[tid] = p.im_obj[tid]; objR[tid] = p.r_obj[tid];
     }
@@ -154,6 +169,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
 
     KB_STAMP(13);    // kernel start: state loads, warm-start scan and list load
     for (int sub = 0; sub < p.n_substeps; ++sub) {
+        KB_ENV_ADDRESSES();
         // ---- light.step: SinglePositionLight.step, light.py:59-75 (uniform per env) ----
         if (p.light_action && LGEN && drive) {
             // Light.step of every component: light.py:59-75 (positional), 300-316 (momentum), 237-253 (gradient)
@@ -198,8 +214,8 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
             const int b = tid + q * nt;
             if (b >= N) continue;
             float bvx = 0.0f, bvy = 0.0f, bww = 0.0f;
-            const float bx = px[b], by = py[b];
-            x0s[b] = bx; y0s[b] = by; sth0[q] = th[q];
+            const float bx = pos[b].x, by = pos[b].y;
+            start[b].x = bx; start[b].y = by; sth0[q] = th[q];
             if (drive) {
                 const float t = th[q];
                 float lval = 0.0f, lgx = 0.0f, lgy = 0.0f;
@@ -262,7 +278,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
             if (g.cmd_vx) { g.cmd_vx[o + b] = bvx; g.cmd_vy[o + b] = bvy; g.cmd_w[o + b] = bww; }
             // b2Island::Solve: v *= 1/(1 + h c)  (SimplePhototaxisKilobot sets linearDamping = 0, kilobot.py:203)
             const float kl = (DRIVE_MODE == KB_DRIVE_SIMPLE_PHOTOTAXIS) ? 1.0f / (1.0f + h * 0.0f) : p.kl_bot;
-            vx[b] = bvx * kl; vy[b] = bvy * kl; bw[q] = bww * p.ka_bot;
+            vel[b].x = bvx * kl; vel[b].y = bvy * kl; bw[q] = bww * p.ka_bot;
             parent[b] = b;
             // broadphase: push the bot on its cell's list
             int cx = (int)floorf((bx - p.xmin) * p.inv_cell);
@@ -274,9 +290,9 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
             nextb[b] = (unsigned short)kb_exch16(head, cell, (unsigned)b);
         }
         float oth0 = 0.0f;
-        if (tid < M) { x0s[N + tid] = px[N + tid]; y0s[N + tid] = py[N + tid]; oth0 = oth; }
+        if (tid < M) { start[N + tid].x = pos[N + tid].x; start[N + tid].y = pos[N + tid].y; oth0 = oth; }
         if (tid < M) {   // b2Island::Solve damping of the objects; they keep their velocity between substeps
-            vx[N + tid] *= p.kl_obj; vy[N + tid] *= p.kl_obj; oww *= p.ka_obj;
+            vel[N + tid].x *= p.kl_obj; vel[N + tid].y *= p.kl_obj; oww *= p.ka_obj;
             parent[N + tid] = N + tid;
             objCnt[tid] = 0;
         }
@@ -292,7 +308,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
             for (int a = tid; a < N; a += nt) {
                 const int cell = cellOf[a];
                 const int cx = cell % p.gw, cy = cell / p.gw;
-                const float ax = px[a], ay = py[a];
+                const float ax = pos[a].x, ay = pos[a].y;
                 unsigned cnt = 0, mine = 0;
 #pragma unroll
                 for (int k = 0; k < 5; ++k) {
@@ -301,7 +317,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                     unsigned ck = 0;
                     for (unsigned b = KB_HEAD(oy * p.gw + ox); b != EMPTY32; b = KB_NEXT(b)) {
                         if (k == 0 && (int)b <= a) continue;
-                        const float dx = px[b] - ax, dy = py[b] - ay;
+                        const float dx = pos[b].x - ax, dy = pos[b].y - ay;
                         const float dd = dx * dx + dy * dy;
                         if (dd > rr2) continue;  // b2CollideCircles
                         ck++;
@@ -328,7 +344,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                 }
                 // pushable objects: b2CollideCircles kilobot - object m (info 9 + m)
                 for (int m = 0; m < M; ++m) {
-                    const float dx = px[N + m] - ax, dy = py[N + m] - ay;
+                    const float dx = pos[N + m].x - ax, dy = pos[N + m].y - ay;
                     const float ro = p.r_bot + objR[m];
                     if (dx * dx + dy * dy > ro * ro) continue;
                     mine++;
@@ -344,9 +360,9 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
             }
             if (tid < M) {   // object - object (info 17) and object - wall (info 18 + wall), found by the object's thread
                 const int m = tid;
-                const float ax = px[N + m], ay = py[N + m];
+                const float ax = pos[N + m].x, ay = pos[N + m].y;
                 for (int m2 = m + 1; m2 < M; ++m2) {
-                    const float dx = px[N + m2] - ax, dy = py[N + m2] - ay;
+                    const float dx = pos[N + m2].x - ax, dy = pos[N + m2].y - ay;
                     const float ro = objR[m] + objR[m2];
                     if (dx * dx + dy * dy > ro * ro) continue;
                     const unsigned c = atomicAdd(&misc[M_NCON], 1u);
@@ -413,7 +429,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                         for (int w2 = 0; w2 < 4; ++w2) {
                             if (m2 == mo && w2 >= wl) break;
                             float dist, nx, ny;
-                            wall_geom(p, w2, px[N + m2], py[N + m2], dist, nx, ny);
+                            wall_geom(p, w2, pos[N + m2].x, pos[N + m2].y, dist, nx, ny);
                             if (!(dist * dist > rwo * rwo)) r++;
                         }
                     }
@@ -426,7 +442,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                     for (int i1 = 0; i1 <= m1; ++i1)
                         for (int i2 = i1 + 1; i2 < M; ++i2) {
                             if (i1 == m1 && i2 >= m2) break;
-                            const float dx = px[N + i2] - px[N + i1], dy = py[N + i2] - py[N + i1];
+                            const float dx = pos[N + i2].x - pos[N + i1].x, dy = pos[N + i2].y - pos[N + i1].y;
                             const float ro = objR[i1] + objR[i2];
                             if (!(dx * dx + dy * dy > ro * ro)) r++;
                         }
@@ -443,7 +459,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                     }
                 } else if (k >= 9) {    // kilobot - object m, owned by the kilobot; all of them strictly sequential
                     const int a = pr & 0xFFFF, m = k - 9;
-                    const float ax = px[a], ay = py[a];
+                    const float ax = pos[a].x, ay = pos[a].y;
                     r = 0;
                     for (int m2 = 0; m2 < m; ++m2) r += (int)min(objCnt[m2], (unsigned)OBJ_LIST);
                     const int nm_ = (int)min(objCnt[m], (unsigned)OBJ_LIST);
@@ -459,7 +475,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                         if (!(dist * dist > rw2)) slot++;
                     }
                     for (int m2 = 0; m2 < m; ++m2) {
-                        const float dx = px[N + m2] - ax, dy = py[N + m2] - ay;
+                        const float dx = pos[N + m2].x - ax, dy = pos[N + m2].y - ay;
                         const float ro = p.r_bot + objR[m2];
                         if (!(dx * dx + dy * dy > ro * ro)) slot++;
                     }
@@ -475,7 +491,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                     }
                 } else if (k >= 5) {   // wall contact, owned by the bot
                     const int a = pr >> 16, wl = k - 5;
-                    const float ax = px[a], ay = py[a];
+                    const float ax = pos[a].x, ay = pos[a].y;
                     const unsigned dc = dirCnt[a];
                     int nbots = 0;
 #pragma unroll
@@ -495,7 +511,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                     const unsigned b = pr >> 16;
                     const int cell = cellOf[a];
                     const int cx = cell % p.gw, cy = cell / p.gw;
-                    const float ax = px[a], ay = py[a];
+                    const float ax = pos[a].x, ay = pos[a].y;
                     if (k == 0) cls = CLS_SAME;
                     else if (k == 1) cls = CLS_E + (cx & 1);
                     else if (k == 2) cls = CLS_N + (cy & 1);
@@ -514,7 +530,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                         const int oc = (cy + dir_dy(k)) * p.gw + (cx + dir_dx(k));
                         for (unsigned b2 = KB_HEAD(oc); b2 != EMPTY32; b2 = KB_NEXT(b2)) {
                             if (b2 >= b || (k == 0 && (int)b2 <= a)) continue;
-                            const float ex = px[b2] - ax, ey = py[b2] - ay;
+                            const float ex = pos[b2].x - ax, ey = pos[b2].y - ay;
                             if (!(ex * ex + ey * ey > rr2)) j++;
                         }
                     }
@@ -728,55 +744,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
             for (int j = 0; j < KREG; ++j) maxD = max(maxD, rdepth[j]);
             for (int dd = 32; dd >= 1; dd >>= 1) maxD = max(maxD, __shfl_xor(maxD, dd));
             maxD = __builtin_amdgcn_readfirstlane(maxD);
-            // ---- re-deal the contacts to the lanes level by level (a level never straddles two register slots
-            // if it fits one), so that a round executes the body for ONE slot instead of all KREG ----
-            unsigned slotMask[KREG];     // bit d: register slot j holds contacts of depth d
-#pragma unroll
-            for (int j = 0; j < KREG; ++j) slotMask[j] = 0xFFFFFFFFu;
-            if (maxD >= 1 && maxD <= 31 && p.capL >= nw * 64 * KREG) {
-                unsigned *lvlCnt = bkStart + wave * BK_PER_WAVE;    // (the bucket arrays are idle on this path)
-                unsigned *lvlStart = bkFill + wave * BK_PER_WAVE;
-                unsigned short *deal = lCbk + wave * 64 * KREG;
-                if (lane < 32) lvlCnt[lane] = 0;
-#pragma unroll
-                for (int j = 0; j < KREG; ++j) deal[lane + 64 * j] = EMPTY16;
-                wave_sync();
-                unsigned posIn[KREG];
-#pragma unroll
-                for (int j = 0; j < KREG; ++j) posIn[j] = rvalid[j] ? atomicAdd(&lvlCnt[rdepth[j]], 1u) : 0u;
-                wave_sync();
-                unsigned run = 0, sm[KREG];
-#pragma unroll
-                for (int j = 0; j < KREG; ++j) sm[j] = 0;
-                for (int d = 1; d <= maxD; ++d) {      // wave-uniform
-                    const unsigned n = lvlCnt[d];
-                    if (n <= 64u && (run & 63u) + n > 64u) run = (run + 63u) & ~63u;
-                    if (lane == 0) lvlStart[d] = run;
-#pragma unroll
-                    for (int j = 0; j < KREG; ++j)
-                        if (n > 0 && run < 64u * (j + 1) && run + n > 64u * j) sm[j] |= 1u << d;
-                    run += n;
-                }
-                if (run <= 64u * KREG) {
-                    wave_sync();
-#pragma unroll
-                    for (int j = 0; j < KREG; ++j)
-                        if (rvalid[j]) {
-                            deal[lvlStart[rdepth[j]] + posIn[j]] = (unsigned short)rc[j];
-                            lInfo[rc[j]] = (lInfo[rc[j]] & 0x00FFFFFFu) | ((unsigned)rdepth[j] << 24);
-                        }
-                    wave_sync();
-#pragma unroll
-                    for (int j = 0; j < KREG; ++j) {
-                        const unsigned c = deal[lane + 64 * j];
-                        rvalid[j] = c != EMPTY16;
-                        rc[j] = rvalid[j] ? (int)c : 0;
-                        rdepth[j] = rvalid[j] ? (int)(lInfo[rc[j]] >> 24) : 0;
-                        slotMask[j] = __builtin_amdgcn_readfirstlane(sm[j]);
-                    }
-                }
-            }
-            // ---- full load of the (re-dealt) contacts ----
+            // ---- full load of the contacts ----
 #pragma unroll
             for (int j = 0; j < KREG; ++j) {
                 ra[j] = 0; rb[j] = 0; rslot[j] = 255; risl[j] = 0;
@@ -797,11 +765,11 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                     // velocity-phase normal from the start-of-step positions (b2WorldManifold::Initialize)
                     if (a >= WALL_CODE) {
                         float dist, nx, ny;
-                        wall_geom(p, a - WALL_CODE, px[b], py[b], dist, nx, ny);
+                        wall_geom(p, a - WALL_CODE, pos[b].x, pos[b].y, dist, nx, ny);
                         if (rflip[j]) { nx = -nx; ny = -ny; }
                         rnx[j] = nx; rny[j] = ny;
                     } else {
-                        const float dx = px[b] - px[a], dy = py[b] - py[a];
+                        const float dx = pos[b].x - pos[a].x, dy = pos[b].y - pos[a].y;
                         const float dd = dx * dx + dy * dy;
                         if (dd > B2_EPSILON * B2_EPSILON) {
                             const float len = sqrtf(dd);
@@ -819,9 +787,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
 #define KB_REG_ROUNDS(...)                                                                          \
             for (int d_ = 1; d_ <= maxD; ++d_) {                                                    \
                 _Pragma("unroll") for (int j = 0; j < KREG; ++j)                                    \
-                    if ((slotMask[j] >> (d_ & 31)) & 1u) {                                          \
-                        if (rvalid[j] && rdepth[j] == d_) { __VA_ARGS__ }                           \
-                    }                                                                               \
+                    if (rvalid[j] && rdepth[j] == d_) { __VA_ARGS__ }                               \
                 wave_sync();                                                                        \
             }
 
@@ -829,8 +795,8 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
             KB_REG_ROUNDS({
                 const int a = ra[j], b = rb[j];
                 const float Px = racc[j] * rnx[j], Py = racc[j] * rny[j];
-                if (a < WALL_CODE) { vx[a] -= R_IMA(j) * Px; vy[a] -= R_IMA(j) * Py; }
-                vx[b] += R_IMB(j) * Px; vy[b] += R_IMB(j) * Py;
+                if (a < WALL_CODE) { vel[a].x -= R_IMA(j) * Px; vel[a].y -= R_IMA(j) * Py; }
+                vel[b].x += R_IMB(j) * Px; vel[b].y += R_IMB(j) * Py;
             })
             // SolveVelocityConstraints: friction 0, restitution 0, one manifold point.
             // Branch-free rounds: slots that are not part of the current depth level work on a scratch body, so
@@ -848,14 +814,12 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                     float vax[KREG], vay[KREG], vbx[KREG], vby[KREG];
 #pragma unroll
                     for (int j = 0; j < KREG; ++j) {
-                        if (!((slotMask[j] >> (d_ & 31)) & 1u)) continue;      // wave-uniform
                         const bool on = rdepth[j] == d_;
                         ia[j] = on ? iaS[j] : DUMMY; ib[j] = on ? ibS[j] : DUMMY;
-                        vax[j] = vx[ia[j]]; vay[j] = vy[ia[j]]; vbx[j] = vx[ib[j]]; vby[j] = vy[ib[j]];
+                        vax[j] = vel[ia[j]].x; vay[j] = vel[ia[j]].y; vbx[j] = vel[ib[j]].x; vby[j] = vel[ib[j]].y;
                     }
 #pragma unroll
                     for (int j = 0; j < KREG; ++j) {
-                        if (!((slotMask[j] >> (d_ & 31)) & 1u)) continue;
                         const bool on = rdepth[j] == d_;
                         const bool wallA = ra[j] >= WALL_CODE;
                         const float nx = rnx[j], ny = rny[j];
@@ -869,8 +833,8 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                         lambda = newimp - accOld;
                         racc[j] = on ? newimp : accOld;
                         const float Px = lambda * nx, Py = lambda * ny;
-                        vx[ia[j]] = ax_ - ima * Px; vy[ia[j]] = ay_ - ima * Py;
-                        vx[ib[j]] = vbx[j] + imb * Px; vy[ib[j]] = vby[j] + imb * Py;
+                        vel[ia[j]].x = ax_ - ima * Px; vel[ia[j]].y = ay_ - ima * Py;
+                        vel[ib[j]].x = vbx[j] + imb * Px; vel[ib[j]].y = vby[j] + imb * Py;
                     }
                     wave_sync();
                 }
@@ -903,7 +867,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
             for (int q = 0; q < BPT; ++q) {
                 const int b = tid + q * nt;
                 if (b >= N) continue;
-                float vxx = vx[b], vyy = vy[b], ww = bw[q];
+                float vxx = vel[b].x, vyy = vel[b].y, ww = bw[q];
                 const float tx = h * vxx, ty = h * vyy;
                 if (tx * tx + ty * ty > B2_MAX_TRANSLATION_SQ) {
                     const float ratio = B2_MAX_TRANSLATION / sqrtf(tx * tx + ty * ty);
@@ -914,13 +878,13 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                     const float ratio = B2_MAX_ROTATION / fabsf(rot);
                     ww *= ratio;
                 }
-                px[b] += h * vxx; py[b] += h * vyy;
+                pos[b].x += h * vxx; pos[b].y += h * vyy;
                 th[q] += h * ww;
-                vx[b] = vxx; vy[b] = vyy; bw[q] = ww;
+                vel[b].x = vxx; vel[b].y = vyy; bw[q] = ww;
             }
             if (tid < M) {   // objects: same integrator (b2Island writes the clamped velocity back to the body)
                 const int b = N + tid;
-                float vxx = vx[b], vyy = vy[b], ww = oww;
+                float vxx = vel[b].x, vyy = vel[b].y, ww = oww;
                 const float tx = h * vxx, ty = h * vyy;
                 if (tx * tx + ty * ty > B2_MAX_TRANSLATION_SQ) {
                     const float ratio = B2_MAX_TRANSLATION / sqrtf(tx * tx + ty * ty);
@@ -928,8 +892,8 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                 }
                 const float rot = h * ww;
                 if (rot * rot > B2_MAX_ROTATION_SQ) ww *= B2_MAX_ROTATION / fabsf(rot);
-                vx[b] = vxx; vy[b] = vyy; oww = ww;
-                px[b] += h * vxx; py[b] += h * vyy;
+                vel[b].x = vxx; vel[b].y = vyy; oww = ww;
+                pos[b].x += h * vxx; pos[b].y += h * vyy;
                 oth += h * ww;
             }
             __syncthreads();
@@ -944,7 +908,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                     if (act[isl]) {
                         float nx, ny, sep;
                         const float ima = R_IMA(j), imb = R_IMB(j);
-                        const float bx = px[b], by = py[b];
+                        const float bx = pos[b].x, by = pos[b].y;
                         float axx = 0.0f, ayy = 0.0f;
                         if (a >= WALL_CODE) {
                             float dist, wx, wy;
@@ -953,7 +917,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                             const float along = rflip[j] ? -dist : dist;
                             sep = along - R_RA(j) - R_RB(j);
                         } else {
-                            axx = px[a]; ayy = py[a];
+                            axx = pos[a].x; ayy = pos[a].y;
                             const float dx = bx - axx, dy = by - ayy;
                             const float len = sqrtf(dx * dx + dy * dy);
                             nx = dx; ny = dy;
@@ -965,8 +929,8 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                         const float K = ima + imb;
                         const float imp = K > 0.0f ? -C / K : 0.0f;
                         const float Px = imp * nx, Py = imp * ny;
-                        if (a < WALL_CODE) { px[a] = axx - ima * Px; py[a] = ayy - ima * Py; }
-                        px[b] = bx + imb * Px; py[b] = by + imb * Py;
+                        if (a < WALL_CODE) { pos[a].x = axx - ima * Px; pos[a].y = ayy - ima * Py; }
+                        pos[b].x = bx + imb * Px; pos[b].y = by + imb * Py;
                     }
                 })
 #ifdef KB_PROFILE
@@ -1018,10 +982,10 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                 float nx, ny;                                                                       \
                 if (a >= WALL_CODE) {                                                               \
                     float dist_;                                                                    \
-                    wall_geom(p, a - WALL_CODE, px[b], py[b], dist_, nx, ny);                       \
+                    wall_geom(p, a - WALL_CODE, pos[b].x, pos[b].y, dist_, nx, ny);                       \
                     if (flip) { nx = -nx; ny = -ny; }                                               \
                 } else {                                                                            \
-                    const float dx_ = px[b] - px[a], dy_ = py[b] - py[a];                           \
+                    const float dx_ = pos[b].x - pos[a].x, dy_ = pos[b].y - pos[a].y;                           \
                     const float dd_ = dx_ * dx_ + dy_ * dy_;                                        \
                     nx = 1.0f; ny = 0.0f;                                                           \
                     if (dd_ > B2_EPSILON * B2_EPSILON) {                                            \
@@ -1039,8 +1003,8 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                     const float acc = sAcc[c];
                     const float Px = acc * nx, Py = acc * ny;
                     const float ima = bim(a), imb = bim(b);
-                    if (a < WALL_CODE) { vx[a] -= ima * Px; vy[a] -= ima * Py; }
-                    vx[b] += imb * Px; vy[b] += imb * Py;
+                    if (a < WALL_CODE) { vel[a].x -= ima * Px; vel[a].y -= ima * Py; }
+                    vel[b].x += imb * Px; vel[b].y += imb * Py;
                 })
                 // SolveVelocityConstraints
                 for (int it = 0; it < p.vel_iters; ++it) {
@@ -1051,8 +1015,8 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                         KB_VEL_NORMAL(a, b, flip, nx, ny)
                         float vax = 0.0f, vay = 0.0f;
                         const float ima = bim(a), imb = bim(b);
-                        if (a < WALL_CODE) { vax = vx[a]; vay = vy[a]; }
-                        const float vbx = vx[b], vby = vy[b];
+                        if (a < WALL_CODE) { vax = vel[a].x; vay = vel[a].y; }
+                        const float vbx = vel[b].x, vby = vel[b].y;
                         const float dvx = vbx - vax, dvy = vby - vay;
                         const float vn = dvx * nx + dvy * ny;
                         const float k = ima + imb;
@@ -1063,8 +1027,8 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                         lambda = newimp - accOld;
                         sAcc[c] = newimp;
                         const float Px = lambda * nx, Py = lambda * ny;
-                        if (a < WALL_CODE) { vx[a] = vax - ima * Px; vy[a] = vay - ima * Py; }
-                        vx[b] = vbx + imb * Px; vy[b] = vby + imb * Py;
+                        if (a < WALL_CODE) { vel[a].x = vax - ima * Px; vel[a].y = vay - ima * Py; }
+                        vel[b].x = vbx + imb * Px; vel[b].y = vby + imb * Py;
                     })
                 }
                 __syncthreads();
@@ -1095,7 +1059,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                 for (int q = 0; q < BPT; ++q) {
                     const int b = tid + q * nt;
                     if (b >= N) continue;
-                    float vxx = vx[b], vyy = vy[b], ww = bw[q];
+                    float vxx = vel[b].x, vyy = vel[b].y, ww = bw[q];
                     const float tx = h * vxx, ty = h * vyy;
                     if (tx * tx + ty * ty > B2_MAX_TRANSLATION_SQ) {
                         const float ratio = B2_MAX_TRANSLATION / sqrtf(tx * tx + ty * ty);
@@ -1106,13 +1070,13 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                         const float ratio = B2_MAX_ROTATION / fabsf(rot);
                         ww *= ratio;
                     }
-                    px[b] += h * vxx; py[b] += h * vyy;
+                    pos[b].x += h * vxx; pos[b].y += h * vyy;
                     th[q] += h * ww;
-                    vx[b] = vxx; vy[b] = vyy; bw[q] = ww;
+                    vel[b].x = vxx; vel[b].y = vyy; bw[q] = ww;
                 }
                 if (tid < M) {   // objects
                     const int b = N + tid;
-                    float vxx = vx[b], vyy = vy[b], ww = oww;
+                    float vxx = vel[b].x, vyy = vel[b].y, ww = oww;
                     const float tx = h * vxx, ty = h * vyy;
                     if (tx * tx + ty * ty > B2_MAX_TRANSLATION_SQ) {
                         const float ratio = B2_MAX_TRANSLATION / sqrtf(tx * tx + ty * ty);
@@ -1120,8 +1084,8 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                     }
                     const float rot = h * ww;
                     if (rot * rot > B2_MAX_ROTATION_SQ) ww *= B2_MAX_ROTATION / fabsf(rot);
-                    vx[b] = vxx; vy[b] = vyy; oww = ww;
-                    px[b] += h * vxx; py[b] += h * vyy;
+                    vel[b].x = vxx; vel[b].y = vyy; oww = ww;
+                    pos[b].x += h * vxx; pos[b].y += h * vyy;
                     oth += h * ww;
                 }
                 __syncthreads();
@@ -1137,7 +1101,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                         if (act[isl]) {
                             float nx, ny, sep;
                             const float ima = bim(a), imb = bim(b), rda = brad(a), rdb = brad(b);
-                            const float bx = px[b], by = py[b];
+                            const float bx = pos[b].x, by = pos[b].y;
                             float axx = 0.0f, ayy = 0.0f;
                             if (a >= WALL_CODE) {
                                 float dist, wx, wy;
@@ -1147,7 +1111,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                                 const float along = flipped ? -dist : dist;
                                 sep = along - rda - rdb;
                             } else {
-                                axx = px[a]; ayy = py[a];
+                                axx = pos[a].x; ayy = pos[a].y;
                                 const float dx = bx - axx, dy = by - ayy;
                                 const float len = sqrtf(dx * dx + dy * dy);
                                 nx = dx; ny = dy;
@@ -1159,8 +1123,8 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                             const float K = ima + imb;
                             const float imp = K > 0.0f ? -C / K : 0.0f;
                             const float Px = imp * nx, Py = imp * ny;
-                            if (a < WALL_CODE) { px[a] = axx - ima * Px; py[a] = ayy - ima * Py; }
-                            px[b] = bx + imb * Px; py[b] = by + imb * Py;
+                            if (a < WALL_CODE) { pos[a].x = axx - ima * Px; pos[a].y = ayy - ima * Py; }
+                            pos[b].x = bx + imb * Px; pos[b].y = by + imb * Py;
                         }
                     })
                     bool any;
@@ -1203,7 +1167,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                 cand[q] = -1;
                 if (b >= N) continue;
                 const float total = p.r_bot + B2_POLYGON_RADIUS;
-                const float xa = x0s[b], ya = y0s[b], xb = px[b], yb = py[b];
+                const float xa = start[b].x, ya = start[b].y, xb = pos[b].x, yb = pos[b].y;
                 const float m0 = fminf(fminf(xa - p.xmin, p.xmax - xa), fminf(ya - p.ymin, p.ymax - ya));
                 const float m1 = fminf(fminf(xb - p.xmin, p.xmax - xb), fminf(yb - p.ymin, p.ymax - yb));
                 if (m0 > total && m1 > total) continue;          // stays clear of every wall: no event possible
@@ -1223,9 +1187,9 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                 const int b = (int)lPair[i];
                 const bool isObj = b >= N;
                 const float R = isObj ? objR[b - N] : p.r_bot, im = isObj ? objIm[b - N] : p.im_bot;
-                float x_ = px[b], y_ = py[b], a_ = cTh[i], vx_ = vx[b], vy_ = vy[b], w_ = cW[i];
-                kb_toi_walls_body(p, R, im, x0s[b], y0s[b], cTh0[i], x_, y_, a_, vx_, vy_, w_);
-                px[b] = x_; py[b] = y_; vx[b] = vx_; vy[b] = vy_; cTh[i] = a_; cW[i] = w_;
+                float x_ = pos[b].x, y_ = pos[b].y, a_ = cTh[i], vx_ = vel[b].x, vy_ = vel[b].y, w_ = cW[i];
+                kb_toi_walls_body(p, R, im, start[b].x, start[b].y, cTh0[i], x_, y_, a_, vx_, vy_, w_);
+                pos[b].x = x_; pos[b].y = y_; vel[b].x = vx_; vel[b].y = vy_; cTh[i] = a_; cW[i] = w_;
             }
             __syncthreads();
 #pragma unroll
@@ -1243,19 +1207,20 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
     }
 
     // ---- write back ----
+    KB_ENV_ADDRESSES();
 #pragma unroll
     for (int q = 0; q < BPT; ++q) {
         const int b = tid + q * nt;
         if (b < N) {
-            g.x[o + b] = px[b]; g.y[o + b] = py[b]; g.theta[o + b] = th[q];
+            g.x[o + b] = pos[b].x; g.y[o + b] = pos[b].y; g.theta[o + b] = th[q];
             if (p.n_substeps > 0) g.ws_cnt[o + b] = wsCnt[b];
             if (DRIVE_MODE == KB_DRIVE_ACCEL && p.n_substeps > 0 && drive) { g.v[o + b] = cv[q]; g.w[o + b] = cw[q]; }
         }
     }
     if (tid < M && p.n_substeps > 0) {
         const size_t oi = (size_t)e * M + tid;
-        g.ox[oi] = px[N + tid]; g.oy[oi] = py[N + tid]; g.otheta[oi] = oth;
-        g.ovx[oi] = vx[N + tid]; g.ovy[oi] = vy[N + tid]; g.ow[oi] = oww;
+        g.ox[oi] = pos[N + tid].x; g.oy[oi] = pos[N + tid].y; g.otheta[oi] = oth;
+        g.ovx[oi] = vel[N + tid].x; g.ovy[oi] = vel[N + tid].y; g.ow[oi] = oww;
     }
     if (p.n_substeps > 0) for (int k = tid; k < M * OWS; k += nt) g.ows_acc[(size_t)e * MAXOBJ * OWS + k] = owsOld[k];
     if (tid == 0) {

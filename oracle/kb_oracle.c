@@ -807,6 +807,7 @@ int kbo_contact_capacity(const kbo_config *cfg) {
     if (cap > 2304) cap = 2304;
     if (cap < 4L * N + 64) cap = 4L * N + 64;
     cap += 40L * cfg->num_objects;
+    cap = (cap + 7) & ~7L;
     return (int)cap;
 }
 
