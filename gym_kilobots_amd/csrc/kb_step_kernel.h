@@ -310,19 +310,29 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                 const int cx = cell % p.gw, cy = cell / p.gw;
                 const float ax = pos[a].x, ay = pos[a].y;
                 unsigned cnt = 0, mine = 0;
+                unsigned hd[5];      // heads of the five cell lists, fetched together (one LDS round trip)
 #pragma unroll
                 for (int k = 0; k < 5; ++k) {
                     const int ox = cx + dir_dx(k), oy = cy + dir_dy(k);
-                    if (ox < 0 || ox >= p.gw || oy >= p.gh) continue;
+                    const bool in = ox >= 0 && ox < p.gw && oy < p.gh;
+                    hd[k] = in ? (unsigned)head[in ? oy * p.gw + ox : cell] : (unsigned)EMPTY16;
+                }
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
                     unsigned ck = 0;
-                    for (unsigned b = KB_HEAD(oy * p.gw + ox); b != EMPTY32; b = KB_NEXT(b)) {
-                        if (k == 0 && (int)b <= a) continue;
-                        const float dx = pos[b].x - ax, dy = pos[b].y - ay;
-                        const float dd = dx * dx + dy * dy;
-                        if (dd > rr2) continue;  // b2CollideCircles
-                        ck++;
-                        const unsigned c = atomicAdd(&misc[M_NCON], 1u);
-                        if (c < (unsigned)stageCap_) { sPair[c] = (unsigned)a | (b << 16); sInfo[c] = (unsigned)k; }
+                    for (unsigned b = hd[k]; b != (unsigned)EMPTY16;) {
+                        const float2 pb = pos[b];
+                        const unsigned nb = nextb[b];
+                        if (!(k == 0 && (int)b <= a)) {
+                            const float dx = pb.x - ax, dy = pb.y - ay;
+                            const float dd = dx * dx + dy * dy;
+                            if (!(dd > rr2)) {  // b2CollideCircles
+                                ck++;
+                                const unsigned c = atomicAdd(&misc[M_NCON], 1u);
+                                if (c < (unsigned)stageCap_) { sPair[c] = (unsigned)a | (b << 16); sInfo[c] = (unsigned)k; }
+                            }
+                        }
+                        b = nb;
                     }
                     mine += ck;
                     if (ck > 63u) { ck = 63u; atomicOr(&misc[M_STATUS], 4u); }
@@ -522,15 +532,16 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                     for (int k2 = 0; k2 < k; ++k2) sbase += (int)((dc >> (6 * k2)) & 63u);
                     // rank base: contacts of this (cell, direction) group owned by lower-id bots of the cell
                     int rbase = 0;
-                    for (unsigned a2 = KB_HEAD(cell); a2 != EMPTY32; a2 = KB_NEXT(a2))
+                    for (unsigned a2 = head[cell]; a2 != (unsigned)EMPTY16; a2 = nextb[a2])
                         if ((int)a2 < a) rbase += (int)((dirCnt[a2] >> (6 * k)) & 63u);
                     // position of b among a's touching partners of this direction, in ascending id order
                     int j = 0;
                     if (((dc >> (6 * k)) & 63u) > 1u) {
                         const int oc = (cy + dir_dy(k)) * p.gw + (cx + dir_dx(k));
-                        for (unsigned b2 = KB_HEAD(oc); b2 != EMPTY32; b2 = KB_NEXT(b2)) {
+                        for (unsigned b2 = head[oc]; b2 != (unsigned)EMPTY16; b2 = nextb[b2]) {
                             if (b2 >= b || (k == 0 && (int)b2 <= a)) continue;
-                            const float ex = pos[b2].x - ax, ey = pos[b2].y - ay;
+                            const float2 pb2 = pos[b2];
+                            const float ex = pb2.x - ax, ey = pb2.y - ay;
                             if (!(ex * ex + ey * ey > rr2)) j++;
                         }
                     }
