@@ -1,7 +1,7 @@
 """KilobotSim: device buffers (torch-ROCm tensors) + the HIP world step behind the C ABI.
 
 This is the host side of the hot path only.  torch is used for device memory and streams; all
-simulation arithmetic happens inside libkilobots_hip.so (gym_kilobots_amd/csrc/kb_sim.hip).
+simulation arithmetic happens inside libkilobots_hip.so (gym_kilobots_amd/csrc/).
 """
 import ctypes as C
 
