@@ -26,9 +26,12 @@
  *   - continuous step (b2World::SolveTOI) only against the static walls, which is all Box2D does for
  *     non-bullet bodies; b2TimeOfImpact's control flow is followed with the closed-form linear distance
  *     of a circle centre to an axis-aligned wall instead of GJK + separating-axis evaluation.
- *   - pushable objects are circles (body.py:181-192); their Coulomb friction against walls (mixed
- *     coefficient sqrt(0.01 * 0.2)) and against each other (0.01) is not modelled, so contacts never
- *     spin an object; kilobot contacts are frictionless in the reference too (kilobot.py:26).
+ *   - pushable objects are circles, boxes or single convex polygons (body.py:129-192, 217-262) with Box2D's
+ *     full contact model among themselves and against the walls (manifolds with feature ids, Coulomb friction
+ *     sqrt(f1 f2), two-point block solver, rotation); kilobot contacts are frictionless in the reference
+ *     (kilobot.py:26) and central on the kilobot side.  A polygon's centre of mass is taken as its body origin
+ *     (exact for boxes, ~1e-8 for the reference's Triangle); no continuous step for polygons; multi-fixture
+ *     bodies (LForm, TForm, CForm) are not restated.
  */
 #include "kb_oracle.h"
 
@@ -70,9 +73,12 @@
 #define CLS_NW 7
 #define CLS_WALL 9
 #define CLS_BOT_OBJ 10          /* kilobot - object, group = object, sequential inside a group */
-#define CLS_OBJ_OBJ 11          /* object - object, pairs in lexicographic order */
-#define CLS_OBJ_WALL 12         /* object - wall, group = object */
-#define OWS 12                  /* object warm-start table: KBO_MAX_OBJECTS partner objects + 4 walls */
+/* after them, in every sweep: the manifold constraints object - object (pairs in lexicographic order), then
+ * object - wall (by object, wall) */
+#define OWS KBO_OWS_COLS
+#define OWW KBO_OWS_WORDS
+#define MAX_MC (KBO_MAX_OBJECTS * (KBO_MAX_OBJECTS - 1) / 2 + 4 * KBO_MAX_OBJECTS)
+#define B2_VELOCITY_THRESHOLD 1.0f
 
 /* ---- sin/cos: Cephes single-precision algorithm (public domain, S. Moshier), restated ---- */
 void kbo_sincosf(float xx, float *sp, float *cp) {
@@ -97,6 +103,47 @@ void kbo_sincosf(float xx, float *sp, float *cp) {
 
 static inline float clampf(float a, float lo, float hi) { return fmaxf(lo, fminf(a, hi)); }
 
+
+/* ---- small 2-D algebra in Box2D's operation order (b2Math.h) ---------------------------------- */
+typedef struct { float x, y; } v2;
+typedef struct { v2 p; float s, c; } xf_t;            /* b2Transform: position + b2Rot (sin, cos) */
+static inline v2 V2(float x, float y) { v2 r; r.x = x; r.y = y; return r; }
+static inline v2 v_add(v2 a, v2 b) { return V2(a.x + b.x, a.y + b.y); }
+static inline v2 v_sub(v2 a, v2 b) { return V2(a.x - b.x, a.y - b.y); }
+static inline v2 v_scale(float s, v2 a) { return V2(s * a.x, s * a.y); }
+static inline v2 v_neg(v2 a) { return V2(-a.x, -a.y); }
+static inline float v_dot(v2 a, v2 b) { return a.x * b.x + a.y * b.y; }
+static inline float v_cross(v2 a, v2 b) { return a.x * b.y - a.y * b.x; }
+static inline v2 v_cross_vs(v2 a, float s) { return V2(s * a.y, -s * a.x); }   /* b2Cross(vector, scalar) */
+static inline v2 v_cross_sv(float s, v2 a) { return V2(-s * a.y, s * a.x); }   /* b2Cross(scalar, vector) */
+static inline v2 v_normalize(v2 a) {                                            /* b2Vec2::Normalize */
+    float len = sqrtf(a.x * a.x + a.y * a.y);
+    if (len < B2_EPSILON) return a;
+    float inv = 1.0f / len;
+    return V2(a.x * inv, a.y * inv);
+}
+static inline xf_t xf_make(float px, float py, float ang) {
+    xf_t t; t.p = V2(px, py); kbo_sincosf(ang, &t.s, &t.c); return t;
+}
+static inline v2 rot_mul(const xf_t *t, v2 v) { return V2(t->c * v.x - t->s * v.y, t->s * v.x + t->c * v.y); }
+static inline v2 rot_mulT(const xf_t *t, v2 v) { return V2(t->c * v.x + t->s * v.y, -t->s * v.x + t->c * v.y); }
+static inline v2 xf_mul(const xf_t *t, v2 v) {
+    return V2((t->c * v.x - t->s * v.y) + t->p.x, (t->s * v.x + t->c * v.y) + t->p.y);
+}
+static inline v2 xf_mulT(const xf_t *t, v2 v) {
+    float px = v.x - t->p.x, py = v.y - t->p.y;
+    return V2(t->c * px + t->s * py, -t->s * px + t->c * py);
+}
+static inline xf_t xf_mulT_xf(const xf_t *A, const xf_t *B) {                   /* b2MulT(A, B) = inv(A) B */
+    xf_t C;
+    C.s = A->c * B->s - A->s * B->c; C.c = A->c * B->c + A->s * B->s;
+    C.p = rot_mulT(A, v_sub(B->p, A->p));
+    return C;
+}
+
+/* fixture shape of a pushable object: circle (b2CircleShape) or convex polygon (b2PolygonShape, skin radius) */
+typedef struct { int kind, n; v2 v[KBO_MAX_POLY_VERTS], nrm[KBO_MAX_POLY_VERTS]; float radius, bound; } shape_t;
+
 /* ---- derived per-config parameters ------------------------------------------------------- */
 typedef struct {
     float xmin, ymin, xmax, ymax;   /* arena, world units */
@@ -106,7 +153,36 @@ typedef struct {
     float h;
     float r_obj[KBO_MAX_OBJECTS], im_obj[KBO_MAX_OBJECTS], ii_obj[KBO_MAX_OBJECTS];
     float kl_obj, ka_obj;
+    shape_t shape[KBO_MAX_OBJECTS];
+    float mu_oo, mu_ow;             /* b2MixFriction: sqrt(f1 * f2) */
 } derived_t;
+
+/* b2PolygonShape::ComputeMass (triangle fan about the vertex average); inertia about the centre of mass as
+ * b2Body::ResetMassData leaves it */
+static void polygon_mass(const shape_t *sh, float density, float *mass, float *inertia) {
+    v2 center = V2(0.0f, 0.0f), s = V2(0.0f, 0.0f);
+    float area = 0.0f, I = 0.0f;
+    for (int i = 0; i < sh->n; ++i) s = v_add(s, sh->v[i]);
+    s = v_scale(1.0f / (float)sh->n, s);
+    const float k_inv3 = 1.0f / 3.0f;
+    for (int i = 0; i < sh->n; ++i) {
+        v2 e1 = v_sub(sh->v[i], s), e2 = v_sub(sh->v[i + 1 < sh->n ? i + 1 : 0], s);
+        float D = v_cross(e1, e2);
+        float triangleArea = 0.5f * D;
+        area += triangleArea;
+        center = v_add(center, v_scale(triangleArea * k_inv3, v_add(e1, e2)));
+        float intx2 = e1.x * e1.x + e2.x * e1.x + e2.x * e2.x;
+        float inty2 = e1.y * e1.y + e2.y * e1.y + e2.y * e2.y;
+        I += (0.25f * k_inv3 * D) * (intx2 + inty2);
+    }
+    float m = density * area;
+    center = v_scale(1.0f / area, center);
+    v2 c = v_add(center, s);
+    float Io = density * I;
+    Io += m * (v_dot(c, c) - v_dot(center, center));
+    Io -= m * v_dot(c, c);                     /* b2Body::ResetMassData: about the centre of mass */
+    *mass = m; *inertia = Io;
+}
 
 static void derive(const kbo_config *c, derived_t *d) {
     float W = c->world_width * WORLD_SCALE, H = c->world_height * WORLD_SCALE;
@@ -130,13 +206,41 @@ static void derive(const kbo_config *c, derived_t *d) {
     d->kl_bot = 1.0f / (1.0f + d->h * c->bot_linear_damping);
     d->ka_bot = 1.0f / (1.0f + d->h * c->bot_angular_damping);
     for (int k = 0; k < KBO_MAX_OBJECTS; ++k) {
-        d->r_obj[k] = c->obj_radius[k] * WORLD_SCALE;
-        float mo = c->obj_density * B2_PI * d->r_obj[k] * d->r_obj[k];
+        shape_t *sh = &d->shape[k];
+        memset(sh, 0, sizeof(*sh));
+        sh->kind = c->obj_shape[k];
+        float mo, io;
+        if (sh->kind == KBO_SHAPE_CIRCLE) {
+            d->r_obj[k] = c->obj_radius[k] * WORLD_SCALE;
+            sh->radius = d->r_obj[k]; sh->bound = d->r_obj[k];
+            mo = c->obj_density * B2_PI * d->r_obj[k] * d->r_obj[k];     /* b2CircleShape::ComputeMass */
+            io = mo * (0.5f * d->r_obj[k] * d->r_obj[k]);                /* I = mass * (0.5 r^2 + |p|^2), p = 0 */
+        } else {
+            if (sh->kind == KBO_SHAPE_BOX) {                               /* b2PolygonShape::SetAsBox */
+                float hx = c->obj_verts[k][0][0] * WORLD_SCALE, hy = c->obj_verts[k][0][1] * WORLD_SCALE;
+                sh->n = 4;
+                sh->v[0] = V2(-hx, -hy); sh->v[1] = V2(hx, -hy); sh->v[2] = V2(hx, hy); sh->v[3] = V2(-hx, hy);
+                sh->nrm[0] = V2(0.0f, -1.0f); sh->nrm[1] = V2(1.0f, 0.0f); sh->nrm[2] = V2(0.0f, 1.0f); sh->nrm[3] = V2(-1.0f, 0.0f);
+            } else {                                                       /* b2PolygonShape::Set on an ordered hull */
+                sh->n = c->obj_nverts[k] < 3 ? 3 : (c->obj_nverts[k] > KBO_MAX_POLY_VERTS ? KBO_MAX_POLY_VERTS : c->obj_nverts[k]);
+                for (int i = 0; i < sh->n; ++i) sh->v[i] = V2(c->obj_verts[k][i][0] * WORLD_SCALE, c->obj_verts[k][i][1] * WORLD_SCALE);
+                for (int i = 0; i < sh->n; ++i) {
+                    v2 edge = v_sub(sh->v[i + 1 < sh->n ? i + 1 : 0], sh->v[i]);
+                    sh->nrm[i] = v_normalize(v_cross_vs(edge, 1.0f));
+                }
+            }
+            sh->radius = B2_POLYGON_RADIUS;
+            float far2 = 0.0f;
+            for (int i = 0; i < sh->n; ++i) far2 = fmaxf(far2, v_dot(sh->v[i], sh->v[i]));
+            sh->bound = sqrtf(far2) + B2_POLYGON_RADIUS;
+            d->r_obj[k] = sh->bound;
+            polygon_mass(sh, c->obj_density, &mo, &io);
+        }
         d->im_obj[k] = mo > 0.0f ? 1.0f / mo : 0.0f;
-        /* I = mass * (0.5 r^2 + |p|^2), p = 0 */
-        float io = mo * (0.5f * d->r_obj[k] * d->r_obj[k]);
         d->ii_obj[k] = io > 0.0f ? 1.0f / io : 0.0f;
     }
+    d->mu_oo = sqrtf(c->obj_friction * c->obj_friction);
+    d->mu_ow = sqrtf(c->obj_friction * c->wall_friction);
     d->kl_obj = 1.0f / (1.0f + d->h * c->obj_linear_damping);
     d->ka_obj = 1.0f / (1.0f + d->h * c->obj_angular_damping);
 }
@@ -272,7 +376,30 @@ typedef struct {
     float ima, imb;
     float ra, rb;
     int owner, slot;    /* warm-start slot (owner bot, slot index) or -1 */
+    /* kilobot - polygon object (b2CollidePolygonAndCircle; Box2D's A = the polygon = body b, B = the kilobot = body a) */
+    int poly;
+    v2 ln, lp;          /* manifold: localNormal, localPoint in the polygon's frame */
+    v2 rA;              /* velocity phase: contact point relative to the polygon's centre */
+    float nmass;        /* velocity phase: normalMass */
 } contact_t;
+
+/* manifold constraint: an object-object or object-wall contact with Box2D's full contact model */
+typedef struct {
+    int type, count;            /* b2Manifold::e_circles 0 / e_faceA 1 / e_faceB 2; pointCount */
+    v2 localNormal, localPoint;
+    v2 lp[2]; int id[2];        /* b2ManifoldPoint: localPoint, id (contact feature key, here a small code) */
+} manifold_t;
+typedef struct {
+    int a, b;                   /* bodies; a = -1 - wall for a wall */
+    int owner, col;             /* warm-start table entry ows[owner object][col] */
+    manifold_t m;
+    float friction, radA, radB;
+    float nimp[2], timp[2];
+    v2 normal, rA[2], rB[2];    /* b2ContactVelocityConstraint */
+    float nmass[2], tmass[2];
+    float k11, k12, k22, n11, n12, n21, n22;   /* K and normalMass = inverse(K) */
+    int vcount;
+} mc_t;
 
 static int contact_cmp(const void *pa, const void *pb) {
     const contact_t *x = (const contact_t *)pa, *y = (const contact_t *)pb;
@@ -290,6 +417,8 @@ typedef struct {
     int *cell, *cx, *cy;
     int *cell_start, *cell_items;
     contact_t *con; int ncon, cap;
+    mc_t mc[MAX_MC]; int nmc;
+    float *ang;            /* working copy of the object angles (index N + m) */
     int *parent; unsigned char *active, *next_active;
     int *woff, *wnoff;     /* packed warm-start offsets: previous / next substep */
     float *x0, *y0, *a0;   /* poses at the start of the step (continuous step) */
@@ -320,6 +449,258 @@ static void add_contact(work_t *w, int a, int b, int cls, int group, float ima, 
     contact_t *c = &w->con[w->ncon++];
     c->a = a; c->b = b; c->cls = cls; c->group = group; c->ima = ima; c->imb = imb;
     c->ra = ra; c->rb = rb; c->acc = acc; c->owner = owner; c->slot = slot; c->nx = 0; c->ny = 0;
+    c->poly = 0; c->ln = V2(0.0f, 0.0f); c->lp = V2(0.0f, 0.0f); c->rA = V2(0.0f, 0.0f); c->nmass = 0.0f;
+}
+
+static inline float wall_dist(const derived_t *d, int wl, float x, float y, float *nx, float *ny);
+
+/* ---- narrowphase of the object shapes (b2CollideCircle.cpp, b2CollidePolygon.cpp, b2CollideEdge.cpp) ---------- */
+
+/* b2CollidePolygonAndCircle: polygon A at xfA, circle centre c (world), circle radius rc */
+static int collide_poly_circle(const shape_t *P, const xf_t *xfA, v2 c, float rc, v2 *ln, v2 *lp) {
+    const v2 cLocal = xf_mulT(xfA, c);
+    int normalIndex = 0;
+    float separation = -3.402823466e+38f;
+    const float radius = P->radius + rc;
+    for (int i = 0; i < P->n; ++i) {
+        float sp = v_dot(P->nrm[i], v_sub(cLocal, P->v[i]));
+        if (sp > radius) return 0;
+        if (sp > separation) { separation = sp; normalIndex = i; }
+    }
+    const int i1 = normalIndex, i2 = i1 + 1 < P->n ? i1 + 1 : 0;
+    const v2 v1 = P->v[i1], v2_ = P->v[i2];
+    if (separation < B2_EPSILON) {                      /* centre inside the polygon */
+        *ln = P->nrm[normalIndex]; *lp = v_scale(0.5f, v_add(v1, v2_));
+        return 1;
+    }
+    const float u1 = v_dot(v_sub(cLocal, v1), v_sub(v2_, v1));
+    const float u2 = v_dot(v_sub(cLocal, v2_), v_sub(v1, v2_));
+    if (u1 <= 0.0f) {
+        v2 dd = v_sub(cLocal, v1);
+        if (v_dot(dd, dd) > radius * radius) return 0;
+        *ln = v_normalize(dd); *lp = v1;
+    } else if (u2 <= 0.0f) {
+        v2 dd = v_sub(cLocal, v2_);
+        if (v_dot(dd, dd) > radius * radius) return 0;
+        *ln = v_normalize(dd); *lp = v2_;
+    } else {
+        v2 faceCenter = v_scale(0.5f, v_add(v1, v2_));
+        float sp = v_dot(v_sub(cLocal, faceCenter), P->nrm[i1]);
+        if (sp > radius) return 0;
+        *ln = P->nrm[i1]; *lp = faceCenter;
+    }
+    return 1;
+}
+
+/* b2FindMaxSeparation (Box2D >= 2.3.1 brute-force form) */
+static float find_max_separation(int *edgeIndex, const shape_t *p1, const xf_t *xf1, const shape_t *p2, const xf_t *xf2) {
+    const xf_t xf = xf_mulT_xf(xf2, xf1);
+    int bestIndex = 0;
+    float maxSeparation = -3.402823466e+38f;
+    for (int i = 0; i < p1->n; ++i) {
+        v2 n = rot_mul(&xf, p1->nrm[i]);
+        v2 v1 = xf_mul(&xf, p1->v[i]);
+        float si = 3.402823466e+38f;
+        for (int j = 0; j < p2->n; ++j) {
+            float sij = v_dot(n, v_sub(p2->v[j], v1));
+            if (sij < si) si = sij;
+        }
+        if (si > maxSeparation) { maxSeparation = si; bestIndex = i; }
+    }
+    *edgeIndex = bestIndex;
+    return maxSeparation;
+}
+
+typedef struct { v2 v; int ia, ib, ta, tb; } clipv_t;     /* b2ClipVertex: point + contact feature */
+#define FEAT_VERTEX 0
+#define FEAT_FACE 1
+static inline int feature_key(int ia, int ib, int ta, int tb) { return ia | (ib << 2) | (ta << 4) | (tb << 5); }
+
+static int clip_segment_to_line(clipv_t vOut[2], const clipv_t vIn[2], v2 normal, float offset, int vertexIndexA) {
+    int numOut = 0;
+    float distance0 = v_dot(normal, vIn[0].v) - offset;
+    float distance1 = v_dot(normal, vIn[1].v) - offset;
+    if (distance0 <= 0.0f) vOut[numOut++] = vIn[0];
+    if (distance1 <= 0.0f) vOut[numOut++] = vIn[1];
+    if (distance0 * distance1 < 0.0f) {
+        float interp = distance0 / (distance0 - distance1);
+        vOut[numOut].v = v_add(vIn[0].v, v_scale(interp, v_sub(vIn[1].v, vIn[0].v)));
+        vOut[numOut].ia = vertexIndexA; vOut[numOut].ib = vIn[0].ib;
+        vOut[numOut].ta = FEAT_VERTEX; vOut[numOut].tb = FEAT_FACE;
+        ++numOut;
+    }
+    return numOut;
+}
+
+/* b2CollidePolygons */
+static void collide_polygons(manifold_t *m, const shape_t *pA, const xf_t *xfA, const shape_t *pB, const xf_t *xfB) {
+    m->count = 0;
+    const float totalRadius = pA->radius + pB->radius;
+    int edgeA = 0, edgeB = 0;
+    float separationA = find_max_separation(&edgeA, pA, xfA, pB, xfB);
+    if (separationA > totalRadius) return;
+    float separationB = find_max_separation(&edgeB, pB, xfB, pA, xfA);
+    if (separationB > totalRadius) return;
+    const shape_t *p1, *p2; const xf_t *xf1, *xf2; int edge1, flip;
+    const float k_tol = 0.1f * B2_LINEAR_SLOP;
+    if (separationB > separationA + k_tol) { p1 = pB; p2 = pA; xf1 = xfB; xf2 = xfA; edge1 = edgeB; m->type = 2; flip = 1; }
+    else { p1 = pA; p2 = pB; xf1 = xfA; xf2 = xfB; edge1 = edgeA; m->type = 1; flip = 0; }
+    clipv_t incident[2];
+    {   /* b2FindIncidentEdge */
+        v2 normal1 = rot_mulT(xf2, rot_mul(xf1, p1->nrm[edge1]));
+        int index = 0; float minDot = 3.402823466e+38f;
+        for (int i = 0; i < p2->n; ++i) { float dt = v_dot(normal1, p2->nrm[i]); if (dt < minDot) { minDot = dt; index = i; } }
+        int i1 = index, i2 = i1 + 1 < p2->n ? i1 + 1 : 0;
+        incident[0].v = xf_mul(xf2, p2->v[i1]); incident[0].ia = edge1; incident[0].ib = i1; incident[0].ta = FEAT_FACE; incident[0].tb = FEAT_VERTEX;
+        incident[1].v = xf_mul(xf2, p2->v[i2]); incident[1].ia = edge1; incident[1].ib = i2; incident[1].ta = FEAT_FACE; incident[1].tb = FEAT_VERTEX;
+    }
+    const int iv1 = edge1, iv2 = edge1 + 1 < p1->n ? edge1 + 1 : 0;
+    v2 v11 = p1->v[iv1], v12 = p1->v[iv2];
+    v2 localTangent = v_normalize(v_sub(v12, v11));
+    v2 localNormal = v_cross_vs(localTangent, 1.0f);
+    v2 planePoint = v_scale(0.5f, v_add(v11, v12));
+    v2 tangent = rot_mul(xf1, localTangent);
+    v2 normal = v_cross_vs(tangent, 1.0f);
+    v11 = xf_mul(xf1, v11); v12 = xf_mul(xf1, v12);
+    float frontOffset = v_dot(normal, v11);
+    float sideOffset1 = -v_dot(tangent, v11) + totalRadius;
+    float sideOffset2 = v_dot(tangent, v12) + totalRadius;
+    clipv_t clip1[2], clip2[2];
+    if (clip_segment_to_line(clip1, incident, v_neg(tangent), sideOffset1, iv1) < 2) return;
+    if (clip_segment_to_line(clip2, clip1, tangent, sideOffset2, iv2) < 2) return;
+    m->localNormal = localNormal; m->localPoint = planePoint;
+    int pc = 0;
+    for (int i = 0; i < 2; ++i) {
+        float separation = v_dot(normal, clip2[i].v) - frontOffset;
+        if (separation <= totalRadius) {
+            m->lp[pc] = xf_mulT(xf2, clip2[i].v);
+            m->id[pc] = flip ? feature_key(clip2[i].ib, clip2[i].ia, clip2[i].tb, clip2[i].ta)
+                             : feature_key(clip2[i].ia, clip2[i].ib, clip2[i].ta, clip2[i].tb);
+            ++pc;
+        }
+    }
+    m->count = pc;
+}
+
+/* wall w: a point on it (vertex v1 of its chain edge, kilobots_env.py:48-51) */
+static inline v2 wall_point(const derived_t *d, int wl) {
+    switch (wl) {
+    case 0: return V2(d->xmin, d->ymax);
+    case 1: return V2(d->xmin, d->ymin);
+    case 2: return V2(d->xmax, d->ymin);
+    default: return V2(d->xmax, d->ymax);
+    }
+}
+static inline v2 wall_normal(int wl) {       /* pointing into the arena */
+    switch (wl) {
+    case 0: return V2(1.0f, 0.0f);
+    case 1: return V2(0.0f, 1.0f);
+    case 2: return V2(-1.0f, 0.0f);
+    default: return V2(0.0f, -1.0f);
+    }
+}
+
+/* b2CollideEdgeAndPolygon for a long two-sided edge with the polygon on its inner side: the edge is the reference
+ * face, the incident edge is the polygon edge most anti-parallel to the wall normal, both of its vertices are
+ * candidates (the side planes of a long edge never clip), kept when within 2 * polygonRadius */
+static void collide_wall_poly(manifold_t *m, const derived_t *d, int wl, const shape_t *P, const xf_t *xfB) {
+    m->count = 0;
+    const v2 n = wall_normal(wl), v1 = wall_point(d, wl);
+    const float radius = 2.0f * B2_POLYGON_RADIUS;
+    v2 wv[KBO_MAX_POLY_VERTS], wn[KBO_MAX_POLY_VERTS];
+    float edgeSep = 3.402823466e+38f;
+    for (int i = 0; i < P->n; ++i) {
+        wv[i] = xf_mul(xfB, P->v[i]); wn[i] = rot_mul(xfB, P->nrm[i]);
+        float sp = v_dot(n, v_sub(wv[i], v1));
+        if (sp < edgeSep) edgeSep = sp;
+    }
+    if (edgeSep > radius) return;
+    int bestIndex = 0; float bestValue = v_dot(n, wn[0]);
+    for (int i = 1; i < P->n; ++i) { float value = v_dot(n, wn[i]); if (value < bestValue) { bestValue = value; bestIndex = i; } }
+    const int i1 = bestIndex, i2 = i1 + 1 < P->n ? i1 + 1 : 0;
+    m->type = 1; m->localNormal = n; m->localPoint = v1;
+    int pc = 0;
+    const int idx[2] = {i1, i2};
+    for (int k = 0; k < 2; ++k) {
+        float separation = v_dot(n, v_sub(wv[idx[k]], v1));
+        if (separation <= radius) { m->lp[pc] = P->v[idx[k]]; m->id[pc] = feature_key(0, idx[k], FEAT_FACE, FEAT_VERTEX); ++pc; }
+    }
+    m->count = pc;
+}
+
+static inline xf_t body_xf(const work_t *w, int b) {
+    if (b < 0) { xf_t t; t.p = V2(0.0f, 0.0f); t.s = 0.0f; t.c = 1.0f; return t; }     /* static arena body */
+    return xf_make(w->px[b], w->py[b], w->ang[b]);
+}
+
+/* previous manifold of the same pair -> impulses of the points whose feature id is unchanged (b2Contact::Update) */
+static void mc_warm(const kbo_state *st, int e, mc_t *c) {
+    const float *old = st->ows_acc + (((size_t)e * KBO_MAX_OBJECTS + c->owner) * OWS + c->col) * OWW;
+    for (int j = 0; j < c->m.count; ++j) {
+        c->nimp[j] = 0.0f; c->timp[j] = 0.0f;
+        for (int k = 0; k < 2; ++k)
+            if (old[3 * k] >= 0.0f && (int)old[3 * k] == c->m.id[j]) { c->nimp[j] = old[3 * k + 1]; c->timp[j] = old[3 * k + 2]; break; }
+    }
+}
+
+/* all object-object and object-wall manifolds of one env, in canonical order */
+static void detect_mc(const derived_t *d, const kbo_state *st, int e, work_t *w) {
+    const int N = w->N, M = w->M;
+    w->nmc = 0;
+    for (int m1 = 0; m1 < M; ++m1)
+        for (int m2 = m1 + 1; m2 < M; ++m2) {
+            const shape_t *s1 = &d->shape[m1], *s2 = &d->shape[m2];
+            {   /* bounding circles (stand-in for the broadphase; never rejects a touching pair) */
+                float dx = w->px[N + m2] - w->px[N + m1], dy = w->py[N + m2] - w->py[N + m1];
+                float rb = s1->bound + s2->bound;
+                if (dx * dx + dy * dy > rb * rb) continue;
+            }
+            mc_t c; memset(&c, 0, sizeof(c));
+            c.owner = m1; c.col = m2; c.friction = d->mu_oo;
+            if (s1->kind == KBO_SHAPE_CIRCLE && s2->kind == KBO_SHAPE_CIRCLE) {      /* b2CollideCircles */
+                float dx = w->px[N + m2] - w->px[N + m1], dy = w->py[N + m2] - w->py[N + m1];
+                float rr = s1->radius + s2->radius;
+                if (dx * dx + dy * dy > rr * rr) continue;
+                c.a = N + m1; c.b = N + m2; c.m.type = 0; c.m.count = 1; c.m.id[0] = 0;
+                c.m.localPoint = V2(0.0f, 0.0f); c.m.lp[0] = V2(0.0f, 0.0f);
+            } else if (s1->kind != KBO_SHAPE_CIRCLE && s2->kind != KBO_SHAPE_CIRCLE) {
+                c.a = N + m1; c.b = N + m2;
+                xf_t xa = body_xf(w, c.a), xb = body_xf(w, c.b);
+                collide_polygons(&c.m, s1, &xa, s2, &xb);
+                if (c.m.count == 0) continue;
+            } else {                                                                   /* polygon is fixture A */
+                const int mp = s1->kind != KBO_SHAPE_CIRCLE ? m1 : m2, mcirc = mp == m1 ? m2 : m1;
+                c.a = N + mp; c.b = N + mcirc;
+                xf_t xa = body_xf(w, c.a);
+                v2 ln, lp;
+                if (!collide_poly_circle(&d->shape[mp], &xa, V2(w->px[c.b], w->py[c.b]), d->shape[mcirc].radius, &ln, &lp)) continue;
+                c.m.type = 1; c.m.count = 1; c.m.localNormal = ln; c.m.localPoint = lp; c.m.lp[0] = V2(0.0f, 0.0f); c.m.id[0] = 0;
+            }
+            c.radA = d->shape[c.a - N].radius; c.radB = d->shape[c.b - N].radius;
+            mc_warm(st, e, &c);
+            w->mc[w->nmc++] = c;
+        }
+    for (int m = 0; m < M; ++m)
+        for (int wl = 0; wl < 4; ++wl) {
+            const shape_t *sh = &d->shape[m];
+            mc_t c; memset(&c, 0, sizeof(c));
+            c.a = -1 - wl; c.b = N + m; c.owner = m; c.col = 8 + wl; c.friction = d->mu_ow;
+            c.radA = B2_POLYGON_RADIUS; c.radB = sh->radius;
+            if (sh->kind == KBO_SHAPE_CIRCLE) {                                        /* b2CollideEdgeAndCircle, region AB */
+                float nx, ny; float dist = wall_dist(d, wl, w->px[N + m], w->py[N + m], &nx, &ny);
+                float rwo = B2_POLYGON_RADIUS + sh->radius;
+                if (dist * dist > rwo * rwo) continue;
+                if (dist < 0.0f) { nx = -nx; ny = -ny; }
+                c.m.type = 1; c.m.count = 1; c.m.localNormal = V2(nx, ny); c.m.localPoint = wall_point(d, wl);
+                c.m.lp[0] = V2(0.0f, 0.0f); c.m.id[0] = 0;
+            } else {
+                xf_t xb = body_xf(w, c.b);
+                collide_wall_poly(&c.m, d, wl, sh, &xb);
+                if (c.m.count == 0) continue;
+            }
+            mc_warm(st, e, &c);
+            w->mc[w->nmc++] = c;
+        }
 }
 
 /* b2CollideCircles + canonical class/group; emits contacts owned by bot `a` in emission order */
@@ -389,41 +770,30 @@ static void detect_env(const kbo_config *cfg, const derived_t *d, const kbo_stat
             nslot++;
             add_contact(w, -1 - wl, a, CLS_WALL, a, 0.0f, d->im_bot, B2_POLYGON_RADIUS, d->r_bot, acc, a, slot);
         }
-        /* pushable objects: b2CollideCircles kilobot - object */
+        /* pushable objects: b2CollideCircles / b2CollidePolygonAndCircle kilobot - object */
         for (int m = 0; m < w->M; ++m) {
+            const shape_t *sh = &d->shape[m];
             float dx = w->px[N + m] - w->px[a], dy = w->py[N + m] - w->py[a];
-            float ro = d->r_bot + d->r_obj[m];
+            float ro = d->r_bot + d->r_obj[m];                  /* circle: contact radius; polygon: bounding radius */
             if (dx * dx + dy * dy > ro * ro) continue;
+            v2 ln = V2(0.0f, 0.0f), lp = V2(0.0f, 0.0f);
+            if (sh->kind != KBO_SHAPE_CIRCLE) {
+                xf_t xo = body_xf(w, N + m);
+                if (!collide_poly_circle(sh, &xo, V2(w->px[a], w->py[a]), d->r_bot, &ln, &lp)) continue;
+            }
             float acc = ws_lookup(st, w, e, a, KEY_OBJ + (unsigned)m);
             if (acc < 0.0f) acc = 0.0f;
             int slot = nslot < S ? nslot : -1;
             if (slot < 0) w->status |= 2;
             nslot++;
-            add_contact(w, a, N + m, CLS_BOT_OBJ, m, d->im_bot, d->im_obj[m], d->r_bot, d->r_obj[m], acc, a, slot);
+            add_contact(w, a, N + m, CLS_BOT_OBJ, m, d->im_bot, d->im_obj[m], d->r_bot, sh->radius, acc, a, slot);
+            if (sh->kind != KBO_SHAPE_CIRCLE && w->ncon > 0 && w->con[w->ncon - 1].a == a && w->con[w->ncon - 1].b == N + m) {
+                contact_t *c = &w->con[w->ncon - 1];
+                c->poly = 1; c->ln = ln; c->lp = lp;
+            }
         }
     }
-    /* object - object and object - wall; warm start from the per-object table ows_acc[m][partner | 8 + wall] */
-    for (int m = 0; m < w->M; ++m) {
-        for (int m2 = m + 1; m2 < w->M; ++m2) {
-            float dx = w->px[N + m2] - w->px[N + m], dy = w->py[N + m2] - w->py[N + m];
-            float ro = d->r_obj[m] + d->r_obj[m2];
-            if (dx * dx + dy * dy > ro * ro) continue;
-            float acc = st->ows_acc[((size_t)e * KBO_MAX_OBJECTS + m) * OWS + m2];
-            if (!(acc >= 0.0f)) acc = 0.0f;
-            add_contact(w, N + m, N + m2, CLS_OBJ_OBJ, 0, d->im_obj[m], d->im_obj[m2], d->r_obj[m], d->r_obj[m2], acc, N + m, m2);
-        }
-    }
-    for (int m = 0; m < w->M; ++m) {
-        for (int wl = 0; wl < 4; ++wl) {
-            float rwo = B2_POLYGON_RADIUS + d->r_obj[m];
-            float dist = wl == 0 ? w->px[N + m] - d->xmin : wl == 1 ? w->py[N + m] - d->ymin
-                       : wl == 2 ? d->xmax - w->px[N + m] : d->ymax - w->py[N + m];
-            if (dist * dist > rwo * rwo) continue;
-            float acc = st->ows_acc[((size_t)e * KBO_MAX_OBJECTS + m) * OWS + 8 + wl];
-            if (!(acc >= 0.0f)) acc = 0.0f;
-            add_contact(w, -1 - wl, N + m, CLS_OBJ_WALL, m, 0.0f, d->im_obj[m], B2_POLYGON_RADIUS, d->r_obj[m], acc, N + m, 8 + wl);
-        }
-    }
+    detect_mc(d, st, e, w);
     qsort(w->con, w->ncon, sizeof(contact_t), contact_cmp);
     (void)cfg;
 }
@@ -550,6 +920,204 @@ static void toi_walls_body(const kbo_config *cfg, const derived_t *d, float R, f
     *x = cx; *y = cy; *a = ca;
 }
 
+/* ---- b2ContactSolver for the manifold constraints (object-object, object-wall) ------------------------------- */
+typedef struct { v2 c; float a; v2 v; float w; float m, i; } bstate_t;
+static inline bstate_t body_get(const derived_t *d, const work_t *w, int b) {
+    bstate_t s; memset(&s, 0, sizeof(s));
+    if (b < 0) return s;                                   /* static: zero velocity, zero inverse mass */
+    s.c = V2(w->px[b], w->py[b]); s.a = w->ang[b]; s.v = V2(w->vx[b], w->vy[b]); s.w = w->bw[b];
+    s.m = d->im_obj[b - w->N]; s.i = d->ii_obj[b - w->N];
+    return s;
+}
+static inline void body_put_vel(work_t *w, int b, const bstate_t *s) {
+    if (b < 0) return;
+    w->vx[b] = s->v.x; w->vy[b] = s->v.y; w->bw[b] = s->w;
+}
+static inline void body_put_pos(work_t *w, int b, const bstate_t *s) {
+    if (b < 0) return;
+    w->px[b] = s->c.x; w->py[b] = s->c.y; w->ang[b] = s->a;
+}
+
+/* b2ContactSolver::InitializeVelocityConstraints (b2WorldManifold::Initialize inside) */
+static void mc_init_velocity(const derived_t *d, const work_t *w, mc_t *c) {
+    const bstate_t A = body_get(d, w, c->a), B = body_get(d, w, c->b);
+    const xf_t xfA = body_xf(w, c->a), xfB = body_xf(w, c->b);
+    v2 pts[2];
+    if (c->m.type == 0) {
+        v2 normal = V2(1.0f, 0.0f);
+        v2 pointA = xf_mul(&xfA, c->m.localPoint), pointB = xf_mul(&xfB, c->m.lp[0]);
+        v2 dd = v_sub(pointB, pointA);
+        if (v_dot(dd, dd) > B2_EPSILON * B2_EPSILON) normal = v_normalize(dd);
+        v2 cA = v_add(pointA, v_scale(c->radA, normal)), cB = v_sub(pointB, v_scale(c->radB, normal));
+        pts[0] = v_scale(0.5f, v_add(cA, cB));
+        c->normal = normal;
+    } else if (c->m.type == 1) {
+        v2 normal = rot_mul(&xfA, c->m.localNormal);
+        v2 planePoint = xf_mul(&xfA, c->m.localPoint);
+        for (int j = 0; j < c->m.count; ++j) {
+            v2 clipPoint = xf_mul(&xfB, c->m.lp[j]);
+            v2 cA = v_add(clipPoint, v_scale(c->radA - v_dot(v_sub(clipPoint, planePoint), normal), normal));
+            v2 cB = v_sub(clipPoint, v_scale(c->radB, normal));
+            pts[j] = v_scale(0.5f, v_add(cA, cB));
+        }
+        c->normal = normal;
+    } else {
+        v2 normal = rot_mul(&xfB, c->m.localNormal);
+        v2 planePoint = xf_mul(&xfB, c->m.localPoint);
+        for (int j = 0; j < c->m.count; ++j) {
+            v2 clipPoint = xf_mul(&xfA, c->m.lp[j]);
+            v2 cB = v_add(clipPoint, v_scale(c->radB - v_dot(v_sub(clipPoint, planePoint), normal), normal));
+            v2 cA = v_sub(clipPoint, v_scale(c->radA, normal));
+            pts[j] = v_scale(0.5f, v_add(cA, cB));
+        }
+        c->normal = v_neg(normal);
+    }
+    c->vcount = c->m.count;
+    const v2 tangent = v_cross_vs(c->normal, 1.0f);
+    for (int j = 0; j < c->m.count; ++j) {
+        c->rA[j] = v_sub(pts[j], A.c); c->rB[j] = v_sub(pts[j], B.c);
+        float rnA = v_cross(c->rA[j], c->normal), rnB = v_cross(c->rB[j], c->normal);
+        float kNormal = A.m + B.m + A.i * rnA * rnA + B.i * rnB * rnB;
+        c->nmass[j] = kNormal > 0.0f ? 1.0f / kNormal : 0.0f;
+        float rtA = v_cross(c->rA[j], tangent), rtB = v_cross(c->rB[j], tangent);
+        float kTangent = A.m + B.m + A.i * rtA * rtA + B.i * rtB * rtB;
+        c->tmass[j] = kTangent > 0.0f ? 1.0f / kTangent : 0.0f;
+        /* restitution 0: velocityBias = 0 */
+    }
+    if (c->m.count == 2) {                                 /* block solver set-up */
+        float rn1A = v_cross(c->rA[0], c->normal), rn1B = v_cross(c->rB[0], c->normal);
+        float rn2A = v_cross(c->rA[1], c->normal), rn2B = v_cross(c->rB[1], c->normal);
+        float k11 = A.m + B.m + A.i * rn1A * rn1A + B.i * rn1B * rn1B;
+        float k22 = A.m + B.m + A.i * rn2A * rn2A + B.i * rn2B * rn2B;
+        float k12 = A.m + B.m + A.i * rn1A * rn2A + B.i * rn1B * rn2B;
+        const float k_maxConditionNumber = 1000.0f;
+        if (k11 * k11 < k_maxConditionNumber * (k11 * k22 - k12 * k12)) {
+            c->k11 = k11; c->k12 = k12; c->k22 = k22;
+            float det = k11 * k22 - k12 * k12;              /* b2Mat22::GetInverse */
+            if (det != 0.0f) det = 1.0f / det;
+            c->n11 = det * k22; c->n12 = -det * k12; c->n21 = -det * k12; c->n22 = det * k11;
+        } else {
+            c->vcount = 1;                                  /* the constraints are redundant: use one */
+        }
+    }
+}
+
+static inline void mc_apply(bstate_t *A, bstate_t *B, v2 rA, v2 rB, v2 P) {
+    A->v = v_sub(A->v, v_scale(A->m, P)); A->w -= A->i * v_cross(rA, P);
+    B->v = v_add(B->v, v_scale(B->m, P)); B->w += B->i * v_cross(rB, P);
+}
+
+/* b2ContactSolver::WarmStart */
+static void mc_warm_start(const derived_t *d, work_t *w, mc_t *c) {
+    bstate_t A = body_get(d, w, c->a), B = body_get(d, w, c->b);
+    const v2 tangent = v_cross_vs(c->normal, 1.0f);
+    for (int j = 0; j < c->vcount; ++j) {
+        v2 P = v_add(v_scale(c->nimp[j], c->normal), v_scale(c->timp[j], tangent));
+        A.w -= A.i * v_cross(c->rA[j], P); A.v = v_sub(A.v, v_scale(A.m, P));
+        B.w += B.i * v_cross(c->rB[j], P); B.v = v_add(B.v, v_scale(B.m, P));
+    }
+    body_put_vel(w, c->a, &A); body_put_vel(w, c->b, &B);
+}
+
+static inline v2 mc_dv(const bstate_t *A, const bstate_t *B, v2 rA, v2 rB) {
+    return v_sub(v_sub(v_add(B->v, v_cross_sv(B->w, rB)), A->v), v_cross_sv(A->w, rA));
+}
+
+/* b2ContactSolver::SolveVelocityConstraints for one contact */
+static void mc_solve_velocity(const derived_t *d, work_t *w, mc_t *c) {
+    bstate_t A = body_get(d, w, c->a), B = body_get(d, w, c->b);
+    const v2 normal = c->normal, tangent = v_cross_vs(c->normal, 1.0f);
+    for (int j = 0; j < c->vcount; ++j) {                  /* friction first */
+        v2 dv = mc_dv(&A, &B, c->rA[j], c->rB[j]);
+        float vt = v_dot(dv, tangent) - 0.0f;
+        float lambda = c->tmass[j] * (-vt);
+        float maxFriction = c->friction * c->nimp[j];
+        float newImpulse = clampf(c->timp[j] + lambda, -maxFriction, maxFriction);
+        lambda = newImpulse - c->timp[j];
+        c->timp[j] = newImpulse;
+        mc_apply(&A, &B, c->rA[j], c->rB[j], v_scale(lambda, tangent));
+    }
+    if (c->vcount == 1) {
+        v2 dv = mc_dv(&A, &B, c->rA[0], c->rB[0]);
+        float vn = v_dot(dv, normal);
+        float lambda = -c->nmass[0] * (vn - 0.0f);
+        float newImpulse = fmaxf(c->nimp[0] + lambda, 0.0f);
+        lambda = newImpulse - c->nimp[0];
+        c->nimp[0] = newImpulse;
+        mc_apply(&A, &B, c->rA[0], c->rB[0], v_scale(lambda, normal));
+    } else {                                               /* block solver (total enumeration of the 2x2 LCP) */
+        const float ax = c->nimp[0], ay = c->nimp[1];
+        v2 dv1 = mc_dv(&A, &B, c->rA[0], c->rB[0]), dv2 = mc_dv(&A, &B, c->rA[1], c->rB[1]);
+        float vn1 = v_dot(dv1, normal), vn2 = v_dot(dv2, normal);
+        float bx = vn1 - 0.0f, by = vn2 - 0.0f;
+        bx -= c->k11 * ax + c->k12 * ay; by -= c->k12 * ax + c->k22 * ay;      /* b -= K a */
+        float xx, xy; int solved = 0;
+        for (;;) {
+            xx = -(c->n11 * bx + c->n21 * by); xy = -(c->n12 * bx + c->n22 * by);   /* x = -normalMass b */
+            if (xx >= 0.0f && xy >= 0.0f) { solved = 1; break; }
+            xx = -c->nmass[0] * bx; xy = 0.0f; vn1 = 0.0f; vn2 = c->k12 * xx + by;
+            if (xx >= 0.0f && vn2 >= 0.0f) { solved = 1; break; }
+            xx = 0.0f; xy = -c->nmass[1] * by; vn1 = c->k12 * xy + bx; vn2 = 0.0f;
+            if (xy >= 0.0f && vn1 >= 0.0f) { solved = 1; break; }
+            xx = 0.0f; xy = 0.0f; vn1 = bx; vn2 = by;
+            if (vn1 >= 0.0f && vn2 >= 0.0f) { solved = 1; break; }
+            break;                                          /* no solution: give up */
+        }
+        if (solved) {
+            float dx = xx - ax, dy = xy - ay;
+            v2 P1 = v_scale(dx, normal), P2 = v_scale(dy, normal);
+            A.v = v_sub(A.v, v_scale(A.m, v_add(P1, P2)));
+            A.w -= A.i * (v_cross(c->rA[0], P1) + v_cross(c->rA[1], P2));
+            B.v = v_add(B.v, v_scale(B.m, v_add(P1, P2)));
+            B.w += B.i * (v_cross(c->rB[0], P1) + v_cross(c->rB[1], P2));
+            c->nimp[0] = xx; c->nimp[1] = xy;
+        }
+    }
+    body_put_vel(w, c->a, &A); body_put_vel(w, c->b, &B);
+}
+
+/* b2ContactSolver::SolvePositionConstraints for one contact; returns its minimum separation */
+static float mc_solve_position(const derived_t *d, work_t *w, mc_t *c) {
+    bstate_t A = body_get(d, w, c->a), B = body_get(d, w, c->b);
+    float minSeparation = 0.0f;
+    for (int j = 0; j < c->m.count; ++j) {
+        xf_t xfA, xfB;
+        if (c->a < 0) { xfA.p = V2(0.0f, 0.0f); xfA.s = 0.0f; xfA.c = 1.0f; } else xfA = xf_make(A.c.x, A.c.y, A.a);
+        xfB = xf_make(B.c.x, B.c.y, B.a);
+        v2 normal, point; float separation;
+        if (c->m.type == 0) {                               /* b2PositionSolverManifold */
+            v2 pointA = xf_mul(&xfA, c->m.localPoint), pointB = xf_mul(&xfB, c->m.lp[0]);
+            normal = v_normalize(v_sub(pointB, pointA));
+            point = v_scale(0.5f, v_add(pointA, pointB));
+            separation = v_dot(v_sub(pointB, pointA), normal) - c->radA - c->radB;
+        } else if (c->m.type == 1) {
+            normal = rot_mul(&xfA, c->m.localNormal);
+            v2 planePoint = xf_mul(&xfA, c->m.localPoint);
+            v2 clipPoint = xf_mul(&xfB, c->m.lp[j]);
+            separation = v_dot(v_sub(clipPoint, planePoint), normal) - c->radA - c->radB;
+            point = clipPoint;
+        } else {
+            normal = rot_mul(&xfB, c->m.localNormal);
+            v2 planePoint = xf_mul(&xfB, c->m.localPoint);
+            v2 clipPoint = xf_mul(&xfA, c->m.lp[j]);
+            separation = v_dot(v_sub(clipPoint, planePoint), normal) - c->radA - c->radB;
+            point = clipPoint;
+            normal = v_neg(normal);
+        }
+        v2 rA = v_sub(point, A.c), rB = v_sub(point, B.c);
+        minSeparation = fminf(minSeparation, separation);
+        float C = clampf(B2_BAUMGARTE * (separation + B2_LINEAR_SLOP), -B2_MAX_LINEAR_CORRECTION, 0.0f);
+        float rnA = v_cross(rA, normal), rnB = v_cross(rB, normal);
+        float K = A.m + B.m + A.i * rnA * rnA + B.i * rnB * rnB;
+        float impulse = K > 0.0f ? -C / K : 0.0f;
+        v2 P = v_scale(impulse, normal);
+        A.c = v_sub(A.c, v_scale(A.m, P)); A.a -= A.i * v_cross(rA, P);
+        B.c = v_add(B.c, v_scale(B.m, P)); B.a += B.i * v_cross(rB, P);
+    }
+    body_put_pos(w, c->a, &A); body_put_pos(w, c->b, &B);
+    return minSeparation;
+}
+
 /* b2Island::Solve for one env (all islands; islands only matter for the position-iteration early-out) */
 static void world_step_env(const kbo_config *cfg, const derived_t *d, kbo_state *st, int e, work_t *w) {
     const int N = w->N;
@@ -570,6 +1138,20 @@ static void world_step_env(const kbo_config *cfg, const derived_t *d, kbo_state 
             float nx, ny; float dist = wall_dist(d, -1 - c->a, w->px[c->b], w->py[c->b], &nx, &ny);
             if (dist < 0.0f) { nx = -nx; ny = -ny; }      /* b2CollideEdgeAndCircle: flip towards the centre */
             c->nx = nx; c->ny = ny;
+        } else if (c->poly) {
+            /* b2WorldManifold::Initialize, e_faceA with A = the polygon (body b), B = the kilobot (body a) */
+            const xf_t xo = body_xf(w, c->b);
+            v2 normal = rot_mul(&xo, c->ln);
+            v2 planePoint = xf_mul(&xo, c->lp);
+            v2 clipPoint = V2(w->px[c->a], w->py[c->a]);
+            v2 cA = v_add(clipPoint, v_scale(c->rb - v_dot(v_sub(clipPoint, planePoint), normal), normal));
+            v2 cB = v_sub(clipPoint, v_scale(c->ra, normal));
+            v2 point = v_scale(0.5f, v_add(cA, cB));
+            c->rA = v_sub(point, V2(w->px[c->b], w->py[c->b]));
+            c->nx = normal.x; c->ny = normal.y;            /* from the polygon to the kilobot */
+            float rnA = v_cross(c->rA, normal);
+            float kNormal = c->imb + c->ima + d->ii_obj[c->b - N] * rnA * rnA;      /* mA + mB + iA rnA^2 (kilobot side central) */
+            c->nmass = kNormal > 0.0f ? 1.0f / kNormal : 0.0f;
         } else {
             float dx = w->px[c->b] - w->px[c->a], dy = w->py[c->b] - w->py[c->a];
             if (dx * dx + dy * dy > B2_EPSILON * B2_EPSILON) {   /* b2WorldManifold::Initialize */
@@ -579,17 +1161,39 @@ static void world_step_env(const kbo_config *cfg, const derived_t *d, kbo_state 
             } else { c->nx = 1.0f; c->ny = 0.0f; }
         }
     }
+    for (int i = 0; i < w->nmc; ++i) mc_init_velocity(d, w, &w->mc[i]);
     /* WarmStart */
     for (int i = 0; i < w->ncon; ++i) {
         contact_t *c = &w->con[i];
         float Px = c->acc * c->nx, Py = c->acc * c->ny;
+        if (c->poly) {                                      /* A = polygon b, B = kilobot a */
+            w->bw[c->b] -= d->ii_obj[c->b - N] * (c->rA.x * Py - c->rA.y * Px);
+            w->vx[c->b] -= c->imb * Px; w->vy[c->b] -= c->imb * Py;
+            w->vx[c->a] += c->ima * Px; w->vy[c->a] += c->ima * Py;
+            continue;
+        }
         if (c->a >= 0) { w->vx[c->a] -= c->ima * Px; w->vy[c->a] -= c->ima * Py; }
         w->vx[c->b] += c->imb * Px; w->vy[c->b] += c->imb * Py;
     }
-    /* SolveVelocityConstraints (friction 0, restitution 0, one point) */
+    for (int i = 0; i < w->nmc; ++i) mc_warm_start(d, w, &w->mc[i]);
+    /* SolveVelocityConstraints */
     for (int it = 0; it < cfg->vel_iters; ++it) {
         for (int i = 0; i < w->ncon; ++i) {
             contact_t *c = &w->con[i];
+            if (c->poly) {                                  /* one point, friction sqrt(0 * f) = 0; A = polygon b, B = kilobot a */
+                const float wA = w->bw[c->b];
+                float dvx = (w->vx[c->a] - w->vx[c->b]) - (-wA * c->rA.y), dvy = (w->vy[c->a] - w->vy[c->b]) - (wA * c->rA.x);
+                float vn = dvx * c->nx + dvy * c->ny;
+                float lambda = -(c->nmass * vn);
+                float newimp = fmaxf(c->acc + lambda, 0.0f);
+                lambda = newimp - c->acc;
+                c->acc = newimp;
+                float Px = lambda * c->nx, Py = lambda * c->ny;
+                w->vx[c->b] -= c->imb * Px; w->vy[c->b] -= c->imb * Py;
+                w->bw[c->b] = wA - d->ii_obj[c->b - N] * (c->rA.x * Py - c->rA.y * Px);
+                w->vx[c->a] += c->ima * Px; w->vy[c->a] += c->ima * Py;
+                continue;
+            }
             float vax = 0.0f, vay = 0.0f;
             if (c->a >= 0) { vax = w->vx[c->a]; vay = w->vy[c->a]; }
             float dvx = w->vx[c->b] - vax, dvy = w->vy[c->b] - vay;
@@ -604,18 +1208,20 @@ static void world_step_env(const kbo_config *cfg, const derived_t *d, kbo_state 
             if (c->a >= 0) { w->vx[c->a] = vax - c->ima * Px; w->vy[c->a] = vay - c->ima * Py; }
             w->vx[c->b] += c->imb * Px; w->vy[c->b] += c->imb * Py;
         }
+        for (int i = 0; i < w->nmc; ++i) mc_solve_velocity(d, w, &w->mc[i]);
     }
     /* StoreImpulses -> warm-start cache of the next substep */
     memset(st->ws_cnt + (size_t)e * N, 0, (size_t)N);
     for (int m = 0; m < w->M; ++m)
-        for (int k = 0; k < OWS; ++k) st->ows_acc[((size_t)e * KBO_MAX_OBJECTS + m) * OWS + k] = -1.0f;
-    for (int i = 0; i < w->ncon; ++i) {
-        contact_t *c = &w->con[i];
-        if (c->owner >= N) st->ows_acc[((size_t)e * KBO_MAX_OBJECTS + (c->owner - N)) * OWS + c->slot] = c->acc;
+        for (int k = 0; k < OWS * OWW; ++k) st->ows_acc[((size_t)e * KBO_MAX_OBJECTS + m) * OWS * OWW + k] = -1.0f;
+    for (int i = 0; i < w->nmc; ++i) {
+        const mc_t *c = &w->mc[i];
+        float *dst = st->ows_acc + (((size_t)e * KBO_MAX_OBJECTS + c->owner) * OWS + c->col) * OWW;
+        for (int j = 0; j < c->m.count; ++j) { dst[3 * j] = (float)c->m.id[j]; dst[3 * j + 1] = c->nimp[j]; dst[3 * j + 2] = c->timp[j]; }
     }
     for (int i = 0; i < w->ncon; ++i) {
         contact_t *c = &w->con[i];
-        if (c->slot < 0 || c->owner >= N) continue;
+        if (c->slot < 0) continue;
         size_t ci = (size_t)e * N + c->owner;
         if (st->ws_cnt[ci] < c->slot + 1) st->ws_cnt[ci] = (uint8_t)(c->slot + 1);
     }
@@ -625,7 +1231,7 @@ static void world_step_env(const kbo_config *cfg, const derived_t *d, kbo_state 
     }
     for (int i = 0; i < w->ncon; ++i) {
         contact_t *c = &w->con[i];
-        if (c->slot < 0 || c->owner >= N) continue;
+        if (c->slot < 0) continue;
         int pos = w->wnoff[c->owner] + c->slot;
         if (pos >= w->cap) continue;
         size_t idx = (size_t)e * w->cap + (size_t)pos;
@@ -635,7 +1241,7 @@ static void world_step_env(const kbo_config *cfg, const derived_t *d, kbo_state 
     /* integrate positions */
     for (int b = 0; b < N + w->M; ++b) { w->x0[b] = w->px[b]; w->y0[b] = w->py[b]; }
     for (int b = 0; b < N; ++b) w->a0[b] = st->theta[(size_t)e * N + b];
-    for (int m = 0; m < w->M; ++m) w->a0[N + m] = st->otheta[(size_t)e * w->M + m];
+    for (int m = 0; m < w->M; ++m) w->a0[N + m] = w->ang[N + m];
     for (int b = 0; b < N; ++b) {
         float tx = h * w->vx[b], ty = h * w->vy[b];
         if (tx * tx + ty * ty > B2_MAX_TRANSLATION_SQ) {
@@ -663,12 +1269,13 @@ static void world_step_env(const kbo_config *cfg, const derived_t *d, kbo_state 
             w->bw[b] *= ratio;
         }
         w->px[b] += h * w->vx[b]; w->py[b] += h * w->vy[b];
-        st->otheta[(size_t)e * w->M + m] += h * w->bw[b];
+        w->ang[b] += h * w->bw[b];
     }
     /* islands (connected components over dynamic-dynamic contacts) for the per-island early-out */
     const int T = N + w->M;
     for (int b = 0; b < T; ++b) { w->parent[b] = b; }
     for (int i = 0; i < w->ncon; ++i) if (w->con[i].a >= 0) uf_union(w->parent, w->con[i].a, w->con[i].b);
+    for (int i = 0; i < w->nmc; ++i) if (w->mc[i].a >= 0) uf_union(w->parent, w->mc[i].a, w->mc[i].b);
     for (int b = 0; b < T; ++b) { w->parent[b] = uf_find(w->parent, b); w->active[b] = 1; }
     /* SolvePositionConstraints, b2ContactSolver.cpp; per island: break when minSeparation >= -3 slop */
     for (int it = 0; it < cfg->pos_iters; ++it) {
@@ -679,6 +1286,25 @@ static void world_step_env(const kbo_config *cfg, const derived_t *d, kbo_state 
             int isl = w->parent[c->b];
             if (!w->active[isl]) continue;
             float nx, ny, sep;
+            if (c->poly) {
+                /* b2PositionSolverManifold e_faceA, A = polygon (body b), B = kilobot (body a); point = clipPoint */
+                const xf_t xo = body_xf(w, c->b);
+                v2 normal = rot_mul(&xo, c->ln);
+                v2 planePoint = xf_mul(&xo, c->lp);
+                v2 clipPoint = V2(w->px[c->a], w->py[c->a]);
+                sep = v_dot(v_sub(clipPoint, planePoint), normal) - c->rb - c->ra;
+                v2 rA = v_sub(clipPoint, V2(w->px[c->b], w->py[c->b]));
+                if (sep < -3.0f * B2_LINEAR_SLOP) { w->next_active[isl] = 1; any = 1; }
+                float C = clampf(B2_BAUMGARTE * (sep + B2_LINEAR_SLOP), -B2_MAX_LINEAR_CORRECTION, 0.0f);
+                float rnA = v_cross(rA, normal);
+                float K = c->imb + c->ima + d->ii_obj[c->b - N] * rnA * rnA;
+                float imp = K > 0.0f ? -C / K : 0.0f;
+                v2 P = v_scale(imp, normal);
+                w->px[c->b] -= c->imb * P.x; w->py[c->b] -= c->imb * P.y;
+                w->ang[c->b] -= d->ii_obj[c->b - N] * v_cross(rA, P);
+                w->px[c->a] += c->ima * P.x; w->py[c->a] += c->ima * P.y;
+                continue;
+            }
             if (c->a < 0) {
                 float bx, by; float dist = wall_dist(d, -1 - c->a, w->px[c->b], w->py[c->b], &bx, &by);
                 /* manifold normal is fixed at detection time (stored in c->nx, c->ny) */
@@ -700,6 +1326,13 @@ static void world_step_env(const kbo_config *cfg, const derived_t *d, kbo_state 
             if (c->a >= 0) { w->px[c->a] -= c->ima * Px; w->py[c->a] -= c->ima * Py; }
             w->px[c->b] += c->imb * Px; w->py[c->b] += c->imb * Py;
         }
+        for (int i = 0; i < w->nmc; ++i) {
+            mc_t *c = &w->mc[i];
+            int isl = w->parent[c->b];
+            if (!w->active[isl]) continue;
+            float minSep = mc_solve_position(d, w, c);
+            if (minSep < -3.0f * B2_LINEAR_SLOP) { w->next_active[isl] = 1; any = 1; }
+        }
         memcpy(w->active, w->next_active, (size_t)T);
         if (!any) break;
     }
@@ -708,9 +1341,11 @@ static void world_step_env(const kbo_config *cfg, const derived_t *d, kbo_state 
         for (int b = 0; b < N; ++b)
             toi_walls_body(cfg, d, d->r_bot, d->im_bot, w->x0[b], w->y0[b], w->a0[b], &w->px[b], &w->py[b],
                            &st->theta[(size_t)e * N + b], &w->vx[b], &w->vy[b], &w->bw[b]);
-        for (int m = 0; m < w->M; ++m)
+        for (int m = 0; m < w->M; ++m) {
+            if (d->shape[m].kind != KBO_SHAPE_CIRCLE) continue;       /* polygons: no continuous step (see header) */
             toi_walls_body(cfg, d, d->r_obj[m], d->im_obj[m], w->x0[N + m], w->y0[N + m], w->a0[N + m], &w->px[N + m],
-                           &w->py[N + m], &st->otheta[(size_t)e * w->M + m], &w->vx[N + m], &w->vy[N + m], &w->bw[N + m]);
+                           &w->py[N + m], &w->ang[N + m], &w->vx[N + m], &w->vy[N + m], &w->bw[N + m]);
+        }
     }
 }
 
@@ -789,6 +1424,7 @@ static void substep_env(const kbo_config *cfg, const derived_t *d, kbo_state *st
         const size_t oi = (size_t)e * w->M + m;
         w->px[N + m] = st->ox[oi]; w->py[N + m] = st->oy[oi];
         w->vx[N + m] = st->ovx[oi]; w->vy[N + m] = st->ovy[oi]; w->bw[N + m] = st->ow[oi];
+        w->ang[N + m] = st->otheta[oi];
     }
     world_step_env(cfg, d, st, e, w);
     for (int b = 0; b < N; ++b) { st->x[o + b] = w->px[b]; st->y[o + b] = w->py[b]; }
@@ -796,6 +1432,7 @@ static void substep_env(const kbo_config *cfg, const derived_t *d, kbo_state *st
         const size_t oi = (size_t)e * w->M + m;
         st->ox[oi] = w->px[N + m]; st->oy[oi] = w->py[N + m];
         st->ovx[oi] = w->vx[N + m]; st->ovy[oi] = w->vy[N + m]; st->ow[oi] = w->bw[N + m];
+        st->otheta[oi] = w->ang[N + m];
     }
     if (st->status) st->status[e] |= w->status;
 }
@@ -815,9 +1452,10 @@ static int work_alloc(work_t *w, const kbo_config *cfg, const derived_t *d) {
     memset(w, 0, sizeof(*w));
     int N = cfg->num_bots, M = cfg->num_objects, T = N + M;
     w->N = N; w->M = M; w->S = cfg->ws_slots;
-    w->px = (float *)malloc(sizeof(float) * T * 8);
+    w->px = (float *)malloc(sizeof(float) * T * 9);
     w->py = w->px + T; w->vx = w->py + T; w->vy = w->vx + T; w->bw = w->vy + T;
-    w->x0 = w->bw + T; w->y0 = w->x0 + T; w->a0 = w->y0 + T;
+    w->x0 = w->bw + T; w->y0 = w->x0 + T; w->a0 = w->y0 + T; w->ang = w->a0 + T;
+    for (int i = 0; i < T; ++i) w->ang[i] = 0.0f;
     w->cell = (int *)malloc(sizeof(int) * T * 3); w->cx = w->cell + T; w->cy = w->cx + T;
     w->cell_start = (int *)malloc(sizeof(int) * (d->gw * d->gh + 1));
     w->cell_items = (int *)malloc(sizeof(int) * T);
@@ -892,12 +1530,14 @@ int kbo_count_contacts(const kbo_config *cfg, const kbo_state *st, int env, int 
     for (int m = 0; m < cfg->num_objects; ++m) {
         w.px[cfg->num_bots + m] = st->ox[(size_t)env * cfg->num_objects + m];
         w.py[cfg->num_bots + m] = st->oy[(size_t)env * cfg->num_objects + m];
+        w.ang[cfg->num_bots + m] = st->otheta[(size_t)env * cfg->num_objects + m];
     }
     detect_env(cfg, &d, st, env, &w);
     int nb = 0, nw = 0;
     for (int i = 0; i < w.ncon; ++i) { if (w.con[i].cls >= CLS_BOT_OBJ) continue; if (w.con[i].a < 0) nw++; else nb++; }
     int no = 0;
     for (int i = 0; i < w.ncon; ++i) if (w.con[i].cls >= CLS_BOT_OBJ) no++;
+    no += w.nmc;
     if (n_obj) *n_obj = no;
     if (n_botbot) *n_botbot = nb;
     if (n_wall) *n_wall = nw;
