@@ -15,6 +15,9 @@ LIGHT_NONE, LIGHT_CIRCULAR, LIGHT_GRADIENT, LIGHT_MOMENTUM, LIGHT_COMPOSITE = ra
 MAX_LIGHTS = 4
 STEP_NO_DRIVE = 1
 MAX_OBJECTS = 8
+MAX_POLY_VERTS = 4
+SHAPE_CIRCLE, SHAPE_BOX, SHAPE_POLYGON = range(3)
+OWS_COLS, OWS_WORDS = 12, 6
 MAX_BOTS = 1024
 WORLD_SCALE = 25.0    # reference gym_kilobots/lib/body.py:7
 
@@ -41,6 +44,9 @@ class KbConfig(C.Structure):
         ('lightc_radius', C.c_float * MAX_LIGHTS), ('lightc_max_velocity', C.c_float * MAX_LIGHTS),
         ('lightc_lo', (C.c_float * 2) * MAX_LIGHTS), ('lightc_hi', (C.c_float * 2) * MAX_LIGHTS),
         ('lightc_act_lo', (C.c_float * 2) * MAX_LIGHTS), ('lightc_act_hi', (C.c_float * 2) * MAX_LIGHTS),
+        ('obj_shape', C.c_int32 * MAX_OBJECTS), ('obj_nverts', C.c_int32 * MAX_OBJECTS),
+        ('obj_verts', ((C.c_float * 2) * MAX_POLY_VERTS) * MAX_OBJECTS),
+        ('wall_friction', C.c_float),
     ]
 
 
@@ -135,6 +141,7 @@ def default_config(num_envs, num_bots, drive_mode=DRIVE_VELOCITY, light_type=LIG
     c.obj_density, c.obj_friction = 2.0, 0.01
     c.obj_linear_damping = c.obj_angular_damping = 0.8
     c.toi_walls = 1      # b2World continuousPhysics defaults to true
+    c.wall_friction = 0.2  # b2FixtureDef default (the arena chain, kilobots_env.py:46-51)
     c.solver_mode = 0
     c.light_count = 1
     for i in range(MAX_LIGHTS):
@@ -152,11 +159,14 @@ def default_config(num_envs, num_bots, drive_mode=DRIVE_VELOCITY, light_type=LIG
 def _assign(c, k, v):
     cur = getattr(c, k)
     if hasattr(cur, '__len__'):
-        for i, vi in enumerate(v):
-            if hasattr(cur[i], '__len__'):
-                for j, vij in enumerate(vi):
-                    cur[i][j] = vij
-            else:
-                cur[i] = vi
+        _fill(cur, v)
     else:
         setattr(c, k, v)
+
+
+def _fill(dst, src):
+    for i, vi in enumerate(src):
+        if hasattr(dst[i], '__len__'):
+            _fill(dst[i], vi)
+        else:
+            dst[i] = vi

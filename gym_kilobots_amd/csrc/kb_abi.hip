@@ -26,6 +26,7 @@
 #include <new>
 
 #include "kb_common.h"
+#include "kb_objects.h"
 
 using namespace kb;
 
@@ -87,8 +88,24 @@ int kb_create(const kb_config *cfg, kb_sim **out) {
     if (cfg->num_envs < 1 || cfg->num_bots < 1 || cfg->num_bots > KB_MAX_BOTS)
         return fail(KB_EINVAL, "kb_create: num_envs >= 1 and 1 <= num_bots <= 1024 required");
     if (cfg->num_objects < 0 || cfg->num_objects > KB_MAX_OBJECTS) return fail(KB_EINVAL, "kb_create: 0 <= num_objects <= 8 required");
-    for (int m = 0; m < cfg->num_objects; ++m)
-        if (!(cfg->obj_radius[m] > 0.0f)) return fail(KB_EINVAL, "kb_create: obj_radius must be positive");
+    for (int m = 0; m < cfg->num_objects; ++m) {
+        const int sh = cfg->obj_shape[m];
+        if (sh < KB_SHAPE_CIRCLE || sh > KB_SHAPE_POLYGON) return fail(KB_EINVAL, "kb_create: bad obj_shape");
+        if (sh == KB_SHAPE_CIRCLE && !(cfg->obj_radius[m] > 0.0f)) return fail(KB_EINVAL, "kb_create: obj_radius must be positive");
+        if (sh == KB_SHAPE_BOX && !(cfg->obj_verts[m][0][0] > 0.0f && cfg->obj_verts[m][0][1] > 0.0f))
+            return fail(KB_EINVAL, "kb_create: box half extents (obj_verts[m][0]) must be positive");
+        if (sh == KB_SHAPE_POLYGON) {
+            const int n = cfg->obj_nverts[m];
+            if (n < 3 || n > KB_MAX_POLY_VERTS) return fail(KB_EINVAL, "kb_create: polygons need 3..4 vertices");
+            for (int i = 0; i < n; ++i) {       // counter-clockwise and convex
+                const float *p0 = cfg->obj_verts[m][i], *p1 = cfg->obj_verts[m][(i + 1) % n], *p2 = cfg->obj_verts[m][(i + 2) % n];
+                if (!((p1[0] - p0[0]) * (p2[1] - p1[1]) - (p1[1] - p0[1]) * (p2[0] - p1[0]) > 0.0f))
+                    return fail(KB_EINVAL, "kb_create: polygon vertices must form a counter-clockwise convex hull");
+            }
+        }
+    }
+    if (cfg->num_objects > 0 && (!(cfg->obj_friction >= 0.0f) || !(cfg->wall_friction >= 0.0f)))
+        return fail(KB_EINVAL, "kb_create: friction coefficients must be non-negative");
     if (cfg->num_objects > 0 && !(cfg->obj_density > 0.0f)) return fail(KB_EINVAL, "kb_create: obj_density must be positive");
     if (cfg->drive_mode < 0 || cfg->drive_mode > KB_DRIVE_PHOTOTAXIS) return fail(KB_EINVAL, "kb_create: bad drive_mode");
     if (cfg->light_type < KB_LIGHT_NONE || cfg->light_type > KB_LIGHT_COMPOSITE)
@@ -161,20 +178,64 @@ int kb_create(const kb_config *cfg, kb_sim **out) {
     cap += 40L * cfg->num_objects;
     cap = (cap + 7) & ~7L;
     p.cap = (int)cap;
-    p.capL = p.cap < CAP_LDS ? p.cap : CAP_LDS;
+    // with objects the LDS staging area gives up a few entries to the manifold-constraint records, so that two envs
+    // of 1024 kilobots still share a CU
+    const int capLmax = cfg->num_objects > 0 ? CAP_LDS - 8 * mc_candidates(cfg->num_objects) : CAP_LDS;
+    p.capL = p.cap < capLmax ? p.cap : capLmax;
     p.NP = (p.N + 3) & ~3;
     p.NB = p.NP + KB_MAX_OBJECTS + 4;
     p.M = cfg->num_objects;
     for (int m = 0; m < KB_MAX_OBJECTS; ++m) {
-        p.r_obj[m] = cfg->obj_radius[m] * WORLD_SCALE;
-        const float mo = cfg->obj_density * B2_PI * p.r_obj[m] * p.r_obj[m];   // b2CircleShape::ComputeMass
-        p.im_obj[m] = mo > 0.0f ? 1.0f / mo : 0.0f;
+        float *T = p.otab[m];
+        const int kind = m < cfg->num_objects ? cfg->obj_shape[m] : KB_SHAPE_CIRCLE;
+        float mo, io;
+        T[OT_KIND] = (float)kind; T[OT_N] = 0.0f;
+        if (kind == KB_SHAPE_CIRCLE) {
+            const float r = cfg->obj_radius[m] * WORLD_SCALE;
+            T[OT_RADIUS] = r; T[OT_BOUND] = r;
+            mo = cfg->obj_density * B2_PI * r * r;       // b2CircleShape::ComputeMass
+            io = mo * (0.5f * r * r);                     // I = mass * (0.5 r^2 + |p|^2), p = 0
+        } else {
+            int n;
+            if (kind == KB_SHAPE_BOX) {                   // b2PolygonShape::SetAsBox
+                const float hx = cfg->obj_verts[m][0][0] * WORLD_SCALE, hy = cfg->obj_verts[m][0][1] * WORLD_SCALE;
+                n = 4;
+                const float vx[4] = {-hx, hx, hx, -hx}, vy[4] = {-hy, -hy, hy, hy};
+                const float nx[4] = {0.0f, 1.0f, 0.0f, -1.0f}, ny[4] = {-1.0f, 0.0f, 1.0f, 0.0f};
+                for (int i = 0; i < 4; ++i) {
+                    T[OT_VERTS + 2 * i] = vx[i]; T[OT_VERTS + 2 * i + 1] = vy[i];
+                    T[OT_NORMALS + 2 * i] = nx[i]; T[OT_NORMALS + 2 * i + 1] = ny[i];
+                }
+            } else {                                      // b2PolygonShape::Set on an ordered hull
+                n = cfg->obj_nverts[m];
+                for (int i = 0; i < n; ++i) {
+                    T[OT_VERTS + 2 * i] = cfg->obj_verts[m][i][0] * WORLD_SCALE;
+                    T[OT_VERTS + 2 * i + 1] = cfg->obj_verts[m][i][1] * WORLD_SCALE;
+                }
+                for (int i = 0; i < n; ++i) {
+                    const V2 edge = v_sub(ot_v(T, i + 1 < n ? i + 1 : 0), ot_v(T, i));
+                    const V2 nr = v_normalize(v_cross_vs(edge, 1.0f));
+                    T[OT_NORMALS + 2 * i] = nr.x; T[OT_NORMALS + 2 * i + 1] = nr.y;
+                }
+            }
+            T[OT_N] = (float)n;
+            T[OT_RADIUS] = B2_POLYGON_RADIUS;
+            float far2 = 0.0f;
+            for (int i = 0; i < n; ++i) far2 = fmaxf(far2, v_dot(ot_v(T, i), ot_v(T, i)));
+            T[OT_BOUND] = sqrtf(far2) + B2_POLYGON_RADIUS;
+            polygon_mass(T, cfg->obj_density, mo, io);
+        }
+        T[OT_IM] = mo > 0.0f ? 1.0f / mo : 0.0f;
+        T[OT_II] = io > 0.0f ? 1.0f / io : 0.0f;
     }
+    p.mu_oo = sqrtf(cfg->obj_friction * cfg->obj_friction);
+    p.mu_ow = sqrtf(cfg->obj_friction * cfg->wall_friction);
+    p.nmc = mc_candidates(p.M);
     p.kl_obj = 1.0f / (1.0f + p.h * cfg->obj_linear_damping);
     p.ka_obj = 1.0f / (1.0f + p.h * cfg->obj_angular_damping);
     p.solver_mode = cfg->solver_mode;
     p.toi_walls = cfg->toi_walls;
-    p.lds_total = lds::total(p.NB, p.capL, p.NP, p.ncell);
+    p.lds_total = lds::total(p.NB, p.capL, p.NP, p.ncell, p.nmc);
     if (p.lds_total > 160 * 1024) {
         delete s;
         return fail(KB_ELDS, "kb_create: configuration needs more than 160 KiB of LDS per env");

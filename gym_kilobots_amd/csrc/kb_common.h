@@ -1,28 +1,3 @@
-// kb_sim.hip -- batched Kilobot world step for MI355X (gfx950 / CDNA4) + its C ABI.
-//
-// One workgroup owns one env for the whole launch: positions are loaded once from HBM into LDS,
-// `n_substeps` iterations of the reference substep loop
-// (gym_kilobots/envs/kilobots_env.py:168-190) run out of LDS / registers, poses are written back once.
-// Per substep:
-//   drive law (kilobot.py:86-127,191-203,253-258,294-300,318-333) + light (light.py:59-75,176-189)
-//   -> broadphase: uniform grid of per-cell linked lists in LDS (one atomic exchange per bot)
-//   -> narrowphase: circle-circle / circle-wall (Box2D b2CollideCircles, b2CollideEdgeAndCircle),
-//      5-cell half stencil, warm-start impulses matched from the previous substep
-//   -> islands: lock-free union-find in LDS
-//   -> solver (b2ContactSolver semantics): warm start + 10 sequential-impulse velocity sweeps,
-//      symplectic Euler, <= 10 position sweeps with Box2D's per-island early out.
-// Gauss-Seidel order.  Every contact gets a key (class, rank): class from the relative grid position
-// of the two bodies and the parity of the base cell, rank from its position inside its cell-pair
-// group.  Two contacts with the same key never share a body, so all contacts of one key can be
-// solved concurrently and the result equals the sequential sweep in (class, group, A, B) order that
-// DESIGN.md specifies.  Islands are independent, so each island is bound to ONE wavefront
-// (root id mod #waves): a wave walks its own contacts key by key with no workgroup barrier at all
-// (LDS operations of one wave execute in order).  Only when one island is very large does the whole
-// workgroup cooperate on the sweep with s_barrier between keys.
-// No MFMA anywhere: this is LDS/latency- and HBM-bound integer/float work.
-//
-// Arithmetic: fp32, compiled with -ffp-contract=off; every expression is written in the operation
-// order of the specification so results do not depend on launch fusion, workgroup size or sharding.
 // kb_common.h -- constants, kernel parameters, LDS layout and device helpers shared by the translation units.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -56,13 +31,15 @@ constexpr int MAX_CELLS = 8192;
 constexpr unsigned KEY_WALL = 0x10000u, KEY_OBJ = 0x20000u;
 constexpr int WALL_CODE = 0xFFF0;     // body id of wall w is WALL_CODE + w
 constexpr int OBJ_CODE = 0xFFE0;      // 16-bit warm-start key of object m (its body id is N + m)
-constexpr int MAXOBJ = KB_MAX_OBJECTS, OWS = 12, OBJ_LIST = 32;
+constexpr int MAXOBJ = KB_MAX_OBJECTS, OBJ_LIST = 32;
+constexpr int OT_WORDS_C = 6 + 4 * KB_MAX_POLY_VERTS;   // floats per object in the object table (kb_objects.h)
+constexpr int MC_FIELDS_C = 37;                        // words per manifold-constraint record (kb_objects.h)
 constexpr unsigned EMPTY32 = 0xFFFFFFFFu;
 constexpr unsigned short EMPTY16 = 0xFFFFu;
 
 // contact classes in canonical order; +1 on E/N/NE/NW for odd base-cell parity
 constexpr int CLS_SAME = 0, CLS_E = 1, CLS_N = 3, CLS_NE = 5, CLS_NW = 7, CLS_WALL = 9,
-              CLS_BOT_OBJ = 10, CLS_OBJ_OBJ = 11, CLS_OBJ_WALL = 12, NUM_CLS = 13;
+              CLS_BOT_OBJ = 10, NUM_CLS = 11;
 constexpr int RK = 4;                 // rank buckets per class; the last one holds every rank >= RK-1
 #ifndef KB_MAX_WAVES
 #define KB_MAX_WAVES 8
@@ -85,7 +62,7 @@ constexpr int GIANT_ISLAND = 256;     // contacts; larger islands are swept by t
 constexpr int KREG = KB_KREG;               // contacts a lane can keep in registers (register-resident solver)
 constexpr int CAP_LDS = 1024;         // contacts staged in LDS; denser envs stage in the global scratch slice
 
-enum { M_NCON = 0, M_TOTAL = 1, M_ANY = 2, M_STATUS = 3, M_MAXISL = 4, M_PROF = 5, M_WCNT = 8, M_WFILL = 8 + MAX_WAVES, M_COUNT = 8 + 2 * MAX_WAVES };
+enum { M_NCON = 0, M_TOTAL = 1, M_ANY = 2, M_STATUS = 3, M_MAXISL = 4, M_PROF = 5, M_POLY = 6, M_WCNT = 8, M_WFILL = 8 + MAX_WAVES, M_COUNT = 8 + 2 * MAX_WAVES };
 static_assert(M_COUNT <= 64, "misc area");
 
 // ---- LDS layout ----------------------------------------------------------------------------------
@@ -101,12 +78,14 @@ constexpr int BKFILL = BKSTART + A16(4 * (MAX_BUCKETS + 1));
 constexpr int BKMAXRANK = BKFILL + A16(4 * MAX_BUCKETS);
 constexpr int BKLIST = BKMAXRANK + A16(4 * MAX_WAVES * NUM_CLS);
 constexpr int NLIST = BKLIST + A16(2 * MAX_BUCKETS);
-constexpr int OBJF = NLIST + 16;
-constexpr int OBJCNT = OBJF + A16(4 * 2 * KB_MAX_OBJECTS);
+constexpr int OBJTAB = NLIST + 16;                                    // object table: mass, shape
+constexpr int OBJCNT = OBJTAB + A16(4 * OT_WORDS_C * KB_MAX_OBJECTS);
 constexpr int OBJLIST = OBJCNT + A16(4 * KB_MAX_OBJECTS);
-constexpr int OWSOLD = OBJLIST + A16(2 * KB_MAX_OBJECTS * 32);
-constexpr int OWSNEW = OWSOLD + A16(4 * KB_MAX_OBJECTS * 12);
-constexpr int FIXED = OWSNEW + A16(4 * KB_MAX_OBJECTS * 12);
+constexpr int OBJW = OBJLIST + A16(2 * KB_MAX_OBJECTS * 32);          // angular velocity, angle, angle at the start of the substep
+constexpr int OBJA = OBJW + A16(4 * KB_MAX_OBJECTS);
+constexpr int OBJA0 = OBJA + A16(4 * KB_MAX_OBJECTS);
+constexpr int MCMASK = OBJA0 + A16(4 * KB_MAX_OBJECTS);                // per wave: which manifold constraints it owns (u64)
+constexpr int FIXED = MCMASK + A16(8 * (MAX_WAVES + 1));
 // per-body 32-bit arrays (stride 4 * NB): px py vx vy x0 y0 dirCnt parent
 constexpr int BODY32_COUNT = 8;
 // per-contact 32-bit arrays (stride 4 * capL): sPair sInfo sAcc oldAcc;  16-bit (stride 2 * capL): cbk order oldKey
@@ -120,7 +99,9 @@ __host__ __device__ inline int bot16(int NB, int capL, int NP, int k) { return c
 __host__ __device__ inline int bot8(int NB, int capL, int NP, int k) { return bot16(NB, capL, NP, BOT16_COUNT) + NP * k; }
 __host__ __device__ inline int active(int NB, int capL, int NP) { return bot8(NB, capL, NP, BOT8_COUNT); }
 __host__ __device__ inline int head(int NB, int capL, int NP) { return (active(NB, capL, NP) + 2 * NB + 15) & ~15; }
-__host__ __device__ inline int total(int NB, int capL, int NP, int ncell) { return (head(NB, capL, NP) + 2 * ncell + 4 + 15) & ~15; }
+__host__ __device__ inline int mcarea(int NB, int capL, int NP, int ncell) { return (head(NB, capL, NP) + 2 * ncell + 4 + 15) & ~15; }
+// manifold-constraint records (objects only): MC_FIELDS words x nmc candidates, field-major
+__host__ __device__ inline int total(int NB, int capL, int NP, int ncell, int nmc) { return (mcarea(NB, capL, NP, ncell) + 4 * MC_FIELDS_C * nmc + 15) & ~15; }
 }  // namespace lds
 
 struct Params {
@@ -135,7 +116,10 @@ struct Params {
     int lcount, ladim, lkind[KB_MAX_LIGHTS];
     float lradius[KB_MAX_LIGHTS], lmaxv[KB_MAX_LIGHTS];
     float llo[KB_MAX_LIGHTS][2], lhi[KB_MAX_LIGHTS][2], lalo[KB_MAX_LIGHTS][2], lahi[KB_MAX_LIGHTS][2];
-    float r_obj[KB_MAX_OBJECTS], im_obj[KB_MAX_OBJECTS], kl_obj, ka_obj;
+    float kl_obj, ka_obj;
+    float otab[KB_MAX_OBJECTS][OT_WORDS_C];   // object table (kb_objects.h: OT_*)
+    float mu_oo, mu_ow;                       // b2MixFriction: object-object, object-wall
+    int nmc;                                  // manifold-constraint candidates: pairs + 4 walls per object
     int lds_total;
 };
 

@@ -1,6 +1,7 @@
 // kb_step_kernel.h -- the world-step kernel template (see kb_common.h for the overview).
 #pragma once
 #include "kb_common.h"
+#include "kb_objects.h"
 
 namespace kb {
 
@@ -37,18 +38,28 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
     unsigned *bkMaxRank = (unsigned *)(smem + lds::BKMAXRANK);
     unsigned short *bkList = (unsigned short *)(smem + lds::BKLIST);
     unsigned char *nList = smem + lds::NLIST;
-    float *objIm = (float *)(smem + lds::OBJF), *objR = objIm + MAXOBJ;   // inverse mass / radius of object m
+    float *objTab = (float *)(smem + lds::OBJTAB);                       // object table (kb_objects.h: OT_*)
     unsigned *objCnt = (unsigned *)(smem + lds::OBJCNT);                 // kilobots touching object m
     unsigned short *objList = (unsigned short *)(smem + lds::OBJLIST);   // ... and who they are
-    float *owsOld = (float *)(smem + lds::OWSOLD), *owsNew = (float *)(smem + lds::OWSNEW);   // object warm-start tables
+    float *objW = (float *)(smem + lds::OBJW), *objA = (float *)(smem + lds::OBJA), *objA0 = (float *)(smem + lds::OBJA0);
+    unsigned long long *mcMask = (unsigned long long *)(smem + lds::MCMASK);   // manifold constraints owned by wave w
     const int M = OBJ ? p.M : 0;   // OBJ = false: every object loop below folds away
     // inverse mass / radius of a body id: kilobot < N, object N + m, wall >= WALL_CODE (static, edge skin radius)
     auto bim = [&](int id) __attribute__((always_inline)) -> float {
-        return id >= WALL_CODE ? 0.0f : ((!OBJ || id < N) ? p.im_bot : objIm[id - N]);
+        return id >= WALL_CODE ? 0.0f : ((!OBJ || id < N) ? p.im_bot : objTab[(id - N) * OT_WORDS + OT_IM]);
     };
     auto brad = [&](int id) __attribute__((always_inline)) -> float {
-        return id >= WALL_CODE ? B2_POLYGON_RADIUS : ((!OBJ || id < N) ? p.r_bot : objR[id - N]);
+        return id >= WALL_CODE ? B2_POLYGON_RADIUS : ((!OBJ || id < N) ? p.r_bot : objTab[(id - N) * OT_WORDS + OT_RADIUS]);
     };
+    // is body id a polygon object (kilobot - polygon contacts carry a lever arm on the object)
+    auto bpoly = [&](int id) __attribute__((always_inline)) -> bool {
+        return OBJ && id >= N && id < WALL_CODE && objTab[(id - N) * OT_WORDS + OT_KIND] != 0.0f;
+    };
+    ObjCtx ox;
+    ox.pos = pos; ox.vel = vel; ox.objW = objW; ox.objA = objA; ox.objTab = objTab;
+    ox.mc = (float *)(smem + lds::mcarea(NB, capL_, NP, p.ncell));
+    ox.N = N; ox.MCN = p.nmc; ox.mu_oo = p.mu_oo; ox.mu_ow = p.mu_ow;
+    const int NMC = OBJ ? p.nmc : 0;      // manifold-constraint candidates (object pairs, object-wall)
 
     const kb_buffers &g = p.buf;
     // contact staging in global scratch, used when an env has more contacts than fit the LDS staging area
@@ -106,15 +117,16 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
         }
     }
     for (int b = N + tid; b < NP; b += nt) { wsCnt[b] = 0; wsCntNew[b] = 0; }
-    // pushable objects: thread m owns object m (pose angle / angular velocity stay in its registers)
-    float oth = 0.0f, oww = 0.0f;
+    // pushable objects: pose and velocity live in LDS (pos / vel / objA / objW), thread m integrates object m
     if (tid < M) {
         const size_t oi = (size_t)e * M + tid;
         pos[N + tid].x = g.ox[oi]; pos[N + tid].y = g.oy[oi]; vel[N + tid].x = g.ovx[oi]; vel[N + tid].y = g.ovy[oi];
-        oth = g.otheta[oi]; oww = g.ow[oi];
-        objIm[tid] = p.im_obj[tid]; objR[tid] = p.r_obj[tid];
+        objA[tid] = g.otheta[oi]; objW[tid] = g.ow[oi];
     }
-    for (int k = tid; k < M * OWS; k += nt) owsOld[k] = g.ows_acc[(size_t)e * MAXOBJ * OWS + k];
+    for (int k = tid; k < M * OT_WORDS; k += nt) objTab[k] = p.otab[k / OT_WORDS][k % OT_WORDS];
+    // manifold-constraint candidate t (object pair / object-wall) is looked after by lane t of wave 0
+    bool mcTouch = false;
+    float *owsMine = nullptr;
     for (int c = tid; c < p.ncell; c += nt) head[c] = EMPTY16;
     if (tid == 0) misc[M_STATUS] = 0;
     float lx = 0.0f, ly = 0.0f;
@@ -289,17 +301,24 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
             cellOf[b] = (unsigned short)cell;
             nextb[b] = (unsigned short)kb_exch16(head, cell, (unsigned)b);
         }
-        float oth0 = 0.0f;
-        if (tid < M) { start[N + tid].x = pos[N + tid].x; start[N + tid].y = pos[N + tid].y; oth0 = oth; }
+        if (tid < M) { start[N + tid].x = pos[N + tid].x; start[N + tid].y = pos[N + tid].y; objA0[tid] = objA[tid]; }
         if (tid < M) {   // b2Island::Solve damping of the objects; they keep their velocity between substeps
-            vel[N + tid].x *= p.kl_obj; vel[N + tid].y *= p.kl_obj; oww *= p.ka_obj;
+            vel[N + tid].x *= p.kl_obj; vel[N + tid].y *= p.kl_obj; objW[tid] *= p.ka_obj;
             parent[N + tid] = N + tid;
             objCnt[tid] = 0;
         }
-        for (int k = tid; k < M * OWS; k += nt) owsNew[k] = -1.0f;
         if (tid < M_COUNT && tid != M_STATUS) misc[tid] = 0;
         __syncthreads();
         KB_STAMP(0);
+        // object-object / object-wall manifolds (b2Contact::Update) + their velocity-constraint set-up: candidate t
+        // is lane t of wave 0; the record lives in LDS, the previous substep's impulses come from g.ows_acc
+        if (OBJ && wave == 0) {
+            mcTouch = false;
+            if (lane < NMC) {
+                owsMine = g.ows_acc + (size_t)e * (MAXOBJ * KB_OWS_COLS * KB_OWS_WORDS);
+                mcTouch = mc_detect(ox, p, M, lane, owsMine);
+            }
+        }
 
         // ---- narrowphase pass 1 (thread per bot): find the contacts each bot owns (5-cell half stencil + walls),
         //      append them to the staging list, count them per direction ----
@@ -352,44 +371,30 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                         sInfo[c] = (unsigned)(5 + wl) | (dist < 0.0f ? 0x80u : 0u);
                     }
                 }
-                // pushable objects: b2CollideCircles kilobot - object m (info 9 + m)
+                // pushable objects: b2CollideCircles / b2CollidePolygonAndCircle kilobot - object m
+                // (info 9 + m; bits 8..: how many lower objects this kilobot touches)
+                unsigned nobj = 0;
                 for (int m = 0; m < M; ++m) {
+                    const float *T = objTab + m * OT_WORDS;
                     const float dx = pos[N + m].x - ax, dy = pos[N + m].y - ay;
-                    const float ro = p.r_bot + objR[m];
+                    const float ro = p.r_bot + T[OT_BOUND];       // circle: contact radius; polygon: bounding radius
                     if (dx * dx + dy * dy > ro * ro) continue;
+                    if (T[OT_KIND] != 0.0f) {
+                        V2 ln, lp;
+                        if (!collide_poly_circle(T, xf_make(pos[N + m].x, pos[N + m].y, objA[m]), mk2(ax, ay), p.r_bot, ln, lp)) continue;
+                        misc[M_POLY] = 1u;
+                    }
                     mine++;
                     const unsigned pos = atomicAdd(&objCnt[m], 1u);
                     if (pos < (unsigned)OBJ_LIST) objList[m * OBJ_LIST + pos] = (unsigned short)a;
                     else atomicOr(&misc[M_STATUS], 4u);
                     const unsigned c = atomicAdd(&misc[M_NCON], 1u);
-                    if (c < (unsigned)stageCap_) { sPair[c] = (unsigned)a | ((unsigned)(N + m) << 16); sInfo[c] = (unsigned)(9 + m); }
+                    if (c < (unsigned)stageCap_) { sPair[c] = (unsigned)a | ((unsigned)(N + m) << 16); sInfo[c] = (unsigned)(9 + m) | (nobj << 8); }
+                    nobj++;
                 }
                 dirCnt[a] = cnt;
                 if (mine > (unsigned)S) { atomicOr(&misc[M_STATUS], 2u); mine = S; }
                 wsCntNew[a] = (unsigned char)mine;
-            }
-            if (tid < M) {   // object - object (info 17) and object - wall (info 18 + wall), found by the object's thread
-                const int m = tid;
-                const float ax = pos[N + m].x, ay = pos[N + m].y;
-                for (int m2 = m + 1; m2 < M; ++m2) {
-                    const float dx = pos[N + m2].x - ax, dy = pos[N + m2].y - ay;
-                    const float ro = objR[m] + objR[m2];
-                    if (dx * dx + dy * dy > ro * ro) continue;
-                    const unsigned c = atomicAdd(&misc[M_NCON], 1u);
-                    if (c < (unsigned)stageCap_) { sPair[c] = (unsigned)(N + m) | ((unsigned)(N + m2) << 16); sInfo[c] = 17u; }
-                }
-                const float rwo = B2_POLYGON_RADIUS + objR[m];
-#pragma unroll
-                for (int wl = 0; wl < 4; ++wl) {
-                    float dist, nx, ny;
-                    wall_geom(p, wl, ax, ay, dist, nx, ny);
-                    if (dist * dist > rwo * rwo) continue;
-                    const unsigned c = atomicAdd(&misc[M_NCON], 1u);
-                    if (c < (unsigned)stageCap_) {
-                        sPair[c] = (unsigned)(WALL_CODE + wl) | ((unsigned)(N + m) << 16);
-                        sInfo[c] = (unsigned)(18 + wl) | (dist < 0.0f ? 0x80u : 0u);
-                    }
-                }
             }
         };
         bool big = p.solver_mode >= 3;
@@ -426,48 +431,22 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
             return -1.0f;   // accumulated impulses are >= 0
         };
         auto label_pass = [&](unsigned *sPair, unsigned *sInfo, float *sAcc) __attribute__((always_inline)) {
+            if (OBJ && wave == 0 && lane < NMC && mcTouch && mci(ox, MC_A, lane) < WALL_CODE) {   // object - object: one island
+                unsigned ra = (unsigned)mci(ox, MC_A, lane), rb = (unsigned)mci(ox, MC_B, lane);
+                for (;;) {
+                    while (true) { unsigned t = ((volatile unsigned *)parent)[ra]; if (t == ra) break; ra = t; }
+                    while (true) { unsigned t = ((volatile unsigned *)parent)[rb]; if (t == rb) break; rb = t; }
+                    if (ra == rb) break;
+                    if (ra < rb) { unsigned t = ra; ra = rb; rb = t; }
+                    if (atomicCAS(&parent[ra], ra, rb) == ra) break;
+                }
+            }
             for (int c = tid; c < ncon; c += nt) {
                 const unsigned pr = sPair[c], inf0 = sInfo[c];
                 const int k = inf0 & 31;
                 int cls, r, slot;
                 float acc;
-                if (k >= 18) {          // object - wall, owned by the object: sequential rank over (object, wall)
-                    const int mo = (int)(pr >> 16) - N, wl = k - 18;
-                    r = 0;
-                    for (int m2 = 0; m2 <= mo; ++m2) {
-                        const float rwo = B2_POLYGON_RADIUS + objR[m2];
-                        for (int w2 = 0; w2 < 4; ++w2) {
-                            if (m2 == mo && w2 >= wl) break;
-                            float dist, nx, ny;
-                            wall_geom(p, w2, pos[N + m2].x, pos[N + m2].y, dist, nx, ny);
-                            if (!(dist * dist > rwo * rwo)) r++;
-                        }
-                    }
-                    cls = CLS_OBJ_WALL | (int)(inf0 & 0x80u);
-                    slot = 8 + wl;
-                    acc = owsOld[mo * OWS + slot];
-                } else if (k == 17) {   // object - object, owned by the lower object: rank = pair index
-                    const int m1 = (int)(pr & 0xFFFF) - N, m2 = (int)(pr >> 16) - N;
-                    r = 0;
-                    for (int i1 = 0; i1 <= m1; ++i1)
-                        for (int i2 = i1 + 1; i2 < M; ++i2) {
-                            if (i1 == m1 && i2 >= m2) break;
-                            const float dx = pos[N + i2].x - pos[N + i1].x, dy = pos[N + i2].y - pos[N + i1].y;
-                            const float ro = objR[i1] + objR[i2];
-                            if (!(dx * dx + dy * dy > ro * ro)) r++;
-                        }
-                    cls = CLS_OBJ_OBJ;
-                    slot = m2;
-                    acc = owsOld[m1 * OWS + slot];
-                    unsigned ra = pr & 0xFFFF, rb = pr >> 16;
-                    for (;;) {
-                        while (true) { unsigned t = ((volatile unsigned *)parent)[ra]; if (t == ra) break; ra = t; }
-                        while (true) { unsigned t = ((volatile unsigned *)parent)[rb]; if (t == rb) break; rb = t; }
-                        if (ra == rb) break;
-                        if (ra < rb) { unsigned t = ra; ra = rb; rb = t; }
-                        if (atomicCAS(&parent[ra], ra, rb) == ra) break;
-                    }
-                } else if (k >= 9) {    // kilobot - object m, owned by the kilobot; all of them strictly sequential
+                if (k >= 9) {    // kilobot - object m, owned by the kilobot; all of them strictly sequential
                     const int a = pr & 0xFFFF, m = k - 9;
                     const float ax = pos[a].x, ay = pos[a].y;
                     r = 0;
@@ -484,11 +463,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                         wall_geom(p, w2, ax, ay, dist, nx, ny);
                         if (!(dist * dist > rw2)) slot++;
                     }
-                    for (int m2 = 0; m2 < m; ++m2) {
-                        const float dx = pos[N + m2].x - ax, dy = pos[N + m2].y - ay;
-                        const float ro = p.r_bot + objR[m2];
-                        if (!(dx * dx + dy * dy > ro * ro)) slot++;
-                    }
+                    slot += (int)((inf0 >> 8) & 15u);      // lower objects this kilobot touches (counted by the find pass)
                     cls = CLS_BOT_OBJ;
                     acc = ws_find(a, (unsigned)(OBJ_CODE + m));
                     unsigned ra = a, rb = N + m;
@@ -561,7 +536,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                     }
                 }
                 if (acc < 0.0f) acc = 0.0f;
-                if (slot >= S && k < 17) slot = 255;
+                if (slot >= S) slot = 255;
                 if (r > 255) { r = 255; atomicOr(&misc[M_STATUS], 4u); }
                 sInfo[c] = (unsigned)cls | ((unsigned)r << 8) | ((unsigned)slot << 16);
                 sAcc[c] = acc;
@@ -590,6 +565,17 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
         }
         const unsigned newTotal = block_scan_u8(wsCntNew, newOff, NP, wsum);   // (barriers inside)
         const bool newInLds = newTotal <= (unsigned)p.capL;
+        if (OBJ && wave == 0) {   // island of every manifold constraint; which wave sweeps it (slot nw: all of them)
+            unsigned root = 0;
+            const bool on = lane < NMC && mcTouch;
+            if (on) { root = parent[mci(ox, MC_B, lane)]; mci_set(ox, MC_ISL, lane, (int)root); }
+            for (int w = 0; w < nw; ++w) {
+                const unsigned long long mk = __ballot(on && (int)(root % (unsigned)nw) == w);
+                if (lane == 0) mcMask[w] = mk;
+            }
+            const unsigned long long all = __ballot(on);
+            if (lane == 0) mcMask[nw] = all;
+        }
         KB_STAMP(14);    // flatten roots + warm-start offset scan
         // per contact: island size (giant islands force the cooperative sweep) and contacts per wave
         auto census = [&](const unsigned *sPair) __attribute__((always_inline)) {
@@ -609,7 +595,45 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
         //   reg : every wave can hold its contacts in registers (<= KREG per lane) -> no contact arrays in the sweeps
         //   list: per-wave sweeps over the staged contact arrays
         const bool coop = misc[M_MAXISL] > (unsigned)GIANT_ISLAND || nw == 1 || p.solver_mode == 2 || p.solver_mode == 4;
-        const bool reg = !coop && !big && maxw <= 64u * KREG && p.solver_mode == 0;
+        const bool reg = !coop && !big && maxw <= 64u * KREG && p.solver_mode == 0 && !(OBJ && misc[M_POLY] != 0u);
+        // manifold constraints of one (virtual) wave, swept by its leader thread after the regular contacts of a sweep
+        auto mc_warm_pass = [&](unsigned long long mask, bool leader) __attribute__((always_inline)) {
+            if (leader) for (unsigned long long m_ = mask; m_; m_ &= m_ - 1) mc_warm_start(ox, __builtin_ctzll(m_));
+        };
+        auto mc_velocity_pass = [&](unsigned long long mask, bool leader) __attribute__((always_inline)) {
+            if (leader) for (unsigned long long m_ = mask; m_; m_ &= m_ - 1) mc_solve_velocity(ox, __builtin_ctzll(m_));
+        };
+        auto mc_position_pass = [&](unsigned long long mask, bool leader, const unsigned char *act, unsigned char *nxt) __attribute__((always_inline)) -> bool {
+            bool viol = false;
+            if (leader)
+                for (unsigned long long m_ = mask; m_; m_ &= m_ - 1) {
+                    const int t = __builtin_ctzll(m_);
+                    const int isl = mci(ox, MC_ISL, t);
+                    if (!act[isl]) continue;
+                    const float minSep = mc_solve_position(ox, t);
+                    if (minSep < -3.0f * B2_LINEAR_SLOP) { nxt[isl] = 1; viol = true; }
+                }
+            return viol;
+        };
+        auto mc_clear_flags = [&](unsigned long long mask, bool leader, unsigned char *act) __attribute__((always_inline)) {
+            if (leader) for (unsigned long long m_ = mask; m_; m_ &= m_ - 1) act[mci(ox, MC_ISL, __builtin_ctzll(m_))] = 0;
+        };
+        // StoreImpulses of the manifold constraints: candidate t owns entry (owner, column) of g.ows_acc
+        auto mc_store = [&]() __attribute__((always_inline)) {
+            if (OBJ && wave == 0 && lane < NMC) {
+                int owner, col;
+                mc_candidate(M, lane, owner, col);
+                float *dst = owsMine + (owner * KB_OWS_COLS + col) * KB_OWS_WORDS;
+                float o[KB_OWS_WORDS] = {-1.0f, -1.0f, -1.0f, -1.0f, -1.0f, -1.0f};
+                if (mcTouch) {
+                    const int cnt = (mci(ox, MC_TYPE, lane) >> 2) & 3, ids = mci(ox, MC_ID, lane);
+                    o[0] = (float)(ids & 255); o[1] = mcf(ox, MC_NI0, lane); o[2] = mcf(ox, MC_TI0, lane);
+                    if (cnt == 2) { o[3] = (float)((ids >> 8) & 255); o[4] = mcf(ox, MC_NI1, lane); o[5] = mcf(ox, MC_TI1, lane); }
+                }
+#pragma unroll
+                for (int k = 0; k < KB_OWS_WORDS; ++k) dst[k] = o[k];
+            }
+        };
         // ---- counting sort of the contacts by (wave, class, rank bucket): `order` lists every (virtual) wave's
         //      contacts key by key; bkList = its non-empty keys in canonical order ----
         auto bucket_sort = [&](const unsigned *sPair, const unsigned *sInfo, unsigned short *cbk,
@@ -802,6 +826,13 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                 wave_sync();                                                                        \
             }
 
+            // manifold constraints of this wave's islands (uniform mask)
+            unsigned long long myMc = 0ull;
+            if (OBJ) {
+                const unsigned long long mm = mcMask[wave];
+                myMc = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(mm >> 32)) << 32) |
+                       (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)mm);
+            }
             // b2ContactSolver::WarmStart
             KB_REG_ROUNDS({
                 const int a = ra[j], b = rb[j];
@@ -809,6 +840,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                 if (a < WALL_CODE) { vel[a].x -= R_IMA(j) * Px; vel[a].y -= R_IMA(j) * Py; }
                 vel[b].x += R_IMB(j) * Px; vel[b].y += R_IMB(j) * Py;
             })
+            if (OBJ && myMc) { mc_warm_pass(myMc, lane == 0); wave_sync(); }
             // SolveVelocityConstraints: friction 0, restitution 0, one manifold point.
             // Branch-free rounds: slots that are not part of the current depth level work on a scratch body, so
             // the LDS reads of all KREG slots are issued together (one LDS round trip per round).
@@ -849,9 +881,11 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                     }
                     wave_sync();
                 }
+                if (OBJ && myMc) { mc_velocity_pass(myMc, lane == 0); wave_sync(); }
             }
             __syncthreads();
             KB_STAMP(4);
+            mc_store();
 #ifdef KB_PROFILE
             if (tid == 0) prof_acc[9] += misc[M_PROF];   // deepest wave of the env (replaces the contacts-per-wave slot)
 #endif
@@ -862,7 +896,6 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                 if (!rvalid[j] || rslot[j] == 255) continue;
                 const int a = ra[j], b = rb[j];
                 const int owner = a < WALL_CODE ? a : b;
-                if (owner >= N) { owsNew[(owner - N) * OWS + rslot[j]] = racc[j]; continue; }   // object-owned contact
                 const unsigned key16 = a >= WALL_CODE ? (unsigned)a : (b >= N ? (unsigned)(OBJ_CODE + (b - N)) : (unsigned)b);
                 const unsigned pos = (unsigned)newOff[owner] + (unsigned)rslot[j];
                 if (pos >= (unsigned)p.cap) continue;
@@ -895,7 +928,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
             }
             if (tid < M) {   // objects: same integrator (b2Island writes the clamped velocity back to the body)
                 const int b = N + tid;
-                float vxx = vel[b].x, vyy = vel[b].y, ww = oww;
+                float vxx = vel[b].x, vyy = vel[b].y, ww = objW[tid];
                 const float tx = h * vxx, ty = h * vyy;
                 if (tx * tx + ty * ty > B2_MAX_TRANSLATION_SQ) {
                     const float ratio = B2_MAX_TRANSLATION / sqrtf(tx * tx + ty * ty);
@@ -903,9 +936,9 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                 }
                 const float rot = h * ww;
                 if (rot * rot > B2_MAX_ROTATION_SQ) ww *= B2_MAX_ROTATION / fabsf(rot);
-                vel[b].x = vxx; vel[b].y = vyy; oww = ww;
+                vel[b].x = vxx; vel[b].y = vyy; objW[tid] = ww;
                 pos[b].x += h * vxx; pos[b].y += h * vyy;
-                oth += h * ww;
+                objA[tid] += h * ww;
             }
             __syncthreads();
             KB_STAMP(5);
@@ -944,6 +977,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                         pos[b].x = bx + imb * Px; pos[b].y = by + imb * Py;
                     }
                 })
+                if (OBJ && myMc) { viol |= mc_position_pass(myMc, lane == 0, act, nxt); wave_sync(); }
 #ifdef KB_PROFILE
                 if (tid == 0) prof_acc[10] += 1;
 #endif
@@ -951,6 +985,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                 // the flags the next sweep sets must start cleared (only this wave's islands)
 #pragma unroll
                 for (int j = 0; j < KREG; ++j) if (rvalid[j]) act[risl[j]] = 0;
+                if (OBJ && myMc) mc_clear_flags(myMc, lane == 0, act);
                 wave_sync();
             }
 #undef KB_REG_ROUNDS
@@ -970,6 +1005,14 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                 const int lid = coop ? tid : lane;
                 const int stride = coop ? nt : 64;
                 const int nl = nList[myw];
+                // manifold constraints swept by this (virtual) wave; its leader thread runs them
+                unsigned long long myMc = 0ull;
+                if (OBJ) {
+                    const unsigned long long mm = mcMask[coop ? nw : wave];
+                    myMc = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(mm >> 32)) << 32) |
+                           (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)mm);
+                }
+                const bool leader = lid == 0;
 #define KB_ROUND_SYNC() do { if (coop) __syncthreads(); else wave_sync(); } while (0)
 #define KB_FOR_ROUNDS(...)                                                                          \
                 for (int li = 0; li < nl; ++li) {                                                   \
@@ -1010,19 +1053,51 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                     const unsigned pr = sPair[c];
                     const int a = pr & 0xFFFF, b = pr >> 16;
                     const bool flip = (sInfo[c] & 0x80) != 0;
+                    if (bpoly(b)) {   // kilobot a - polygon b: Box2D's A = the polygon, B = the kilobot
+                        const int m = b - N;
+                        const float *T = objTab + m * OT_WORDS;
+                        PolyCon pc;
+                        poly_contact_setup(T, pos[b].x, pos[b].y, objA[m], mk2(pos[a].x, pos[a].y), p.r_bot, p.im_bot, pc);
+                        const float acc = sAcc[c];
+                        const float Px = acc * pc.normal.x, Py = acc * pc.normal.y;
+                        objW[m] -= T[OT_II] * (pc.rA.x * Py - pc.rA.y * Px);
+                        vel[b].x -= T[OT_IM] * Px; vel[b].y -= T[OT_IM] * Py;
+                        vel[a].x += p.im_bot * Px; vel[a].y += p.im_bot * Py;
+                    } else {
                     KB_VEL_NORMAL(a, b, flip, nx, ny)
                     const float acc = sAcc[c];
                     const float Px = acc * nx, Py = acc * ny;
                     const float ima = bim(a), imb = bim(b);
                     if (a < WALL_CODE) { vel[a].x -= ima * Px; vel[a].y -= ima * Py; }
                     vel[b].x += imb * Px; vel[b].y += imb * Py;
+                    }
                 })
+                if (OBJ && myMc) { mc_warm_pass(myMc, leader); KB_ROUND_SYNC(); }
                 // SolveVelocityConstraints
                 for (int it = 0; it < p.vel_iters; ++it) {
                     KB_FOR_ROUNDS({
                         const unsigned pr = sPair[c];
                         const int a = pr & 0xFFFF, b = pr >> 16;
                         const bool flip = (sInfo[c] & 0x80) != 0;
+                        if (bpoly(b)) {   // kilobot a - polygon b: one point, friction sqrt(0 * f) = 0
+                            const int m = b - N;
+                            const float *T = objTab + m * OT_WORDS;
+                            PolyCon pc;
+                            poly_contact_setup(T, pos[b].x, pos[b].y, objA[m], mk2(pos[a].x, pos[a].y), p.r_bot, p.im_bot, pc);
+                            const float wA = objW[m];
+                            const float dvx = (vel[a].x - vel[b].x) - (-wA * pc.rA.y), dvy = (vel[a].y - vel[b].y) - (wA * pc.rA.x);
+                            const float vn = dvx * pc.normal.x + dvy * pc.normal.y;
+                            float lambda = -(pc.nmass * vn);
+                            const float accOld = sAcc[c];
+                            const float newimp = fmaxf(accOld + lambda, 0.0f);
+                            lambda = newimp - accOld;
+                            sAcc[c] = newimp;
+                            const float Px = lambda * pc.normal.x, Py = lambda * pc.normal.y;
+                            vel[b].x -= T[OT_IM] * Px; vel[b].y -= T[OT_IM] * Py;
+                            objW[m] = wA - T[OT_II] * (pc.rA.x * Py - pc.rA.y * Px);
+                            vel[a].x += p.im_bot * Px; vel[a].y += p.im_bot * Py;
+                            continue;
+                        }
                         KB_VEL_NORMAL(a, b, flip, nx, ny)
                         float vax = 0.0f, vay = 0.0f;
                         const float ima = bim(a), imb = bim(b);
@@ -1041,9 +1116,11 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                         if (a < WALL_CODE) { vel[a].x = vax - ima * Px; vel[a].y = vay - ima * Py; }
                         vel[b].x = vbx + imb * Px; vel[b].y = vby + imb * Py;
                     })
+                    if (OBJ && myMc) { mc_velocity_pass(myMc, leader); KB_ROUND_SYNC(); }
                 }
                 __syncthreads();
                 KB_STAMP(4);
+                mc_store();
                 // StoreImpulses -> packed warm-start list of the next substep
                 const bool last = sub == p.n_substeps - 1;
                 for (int c = tid; c < ncon; c += nt) {
@@ -1054,7 +1131,6 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                     const int a = pr & 0xFFFF, b = pr >> 16;
                     const int owner = a < WALL_CODE ? a : b;
                     const float acc = sAcc[c];
-                    if (owner >= N) { owsNew[(owner - N) * OWS + sl] = acc; continue; }   // object-owned contact
                     const unsigned key16 = a >= WALL_CODE ? (unsigned)a : (b >= N ? (unsigned)(OBJ_CODE + (b - N)) : (unsigned)b);
                     const unsigned pos = (unsigned)newOff[owner] + (unsigned)sl;
                     if (pos >= (unsigned)p.cap) continue;
@@ -1087,7 +1163,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                 }
                 if (tid < M) {   // objects
                     const int b = N + tid;
-                    float vxx = vel[b].x, vyy = vel[b].y, ww = oww;
+                    float vxx = vel[b].x, vyy = vel[b].y, ww = objW[tid];
                     const float tx = h * vxx, ty = h * vyy;
                     if (tx * tx + ty * ty > B2_MAX_TRANSLATION_SQ) {
                         const float ratio = B2_MAX_TRANSLATION / sqrtf(tx * tx + ty * ty);
@@ -1095,9 +1171,9 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                     }
                     const float rot = h * ww;
                     if (rot * rot > B2_MAX_ROTATION_SQ) ww *= B2_MAX_ROTATION / fabsf(rot);
-                    vel[b].x = vxx; vel[b].y = vyy; oww = ww;
+                    vel[b].x = vxx; vel[b].y = vyy; objW[tid] = ww;
                     pos[b].x += h * vxx; pos[b].y += h * vyy;
-                    oth += h * ww;
+                    objA[tid] += h * ww;
                 }
                 __syncthreads();
                 KB_STAMP(5);
@@ -1109,7 +1185,29 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                         const unsigned pr = sPair[c];
                         const int a = pr & 0xFFFF, b = pr >> 16;
                         const int isl = (int)parent[b];
-                        if (act[isl]) {
+                        if (act[isl] && bpoly(b)) {
+                            // b2PositionSolverManifold e_faceA, A = polygon b, B = kilobot a; the manifold is the one of
+                            // the start-of-substep poses
+                            const int m = b - N;
+                            const float *T = objTab + m * OT_WORDS;
+                            V2 ln, lp;
+                            collide_poly_circle(T, xf_make(start[b].x, start[b].y, objA0[m]), mk2(start[a].x, start[a].y), p.r_bot, ln, lp);
+                            const XF xo = xf_make(pos[b].x, pos[b].y, objA[m]);
+                            const V2 normal = rot_mul(xo, ln);
+                            const V2 planePoint = xf_mul(xo, lp);
+                            const V2 clipPoint = mk2(pos[a].x, pos[a].y);
+                            const float sep = v_dot(v_sub(clipPoint, planePoint), normal) - T[OT_RADIUS] - p.r_bot;
+                            const V2 rA = v_sub(clipPoint, mk2(pos[b].x, pos[b].y));
+                            if (sep < -3.0f * B2_LINEAR_SLOP) { nxt[isl] = 1; viol = true; }
+                            const float C = kb_clampf(B2_BAUMGARTE * (sep + B2_LINEAR_SLOP), -B2_MAX_LINEAR_CORRECTION, 0.0f);
+                            const float rnA = v_cross(rA, normal);
+                            const float K = T[OT_IM] + p.im_bot + T[OT_II] * rnA * rnA;
+                            const float imp = K > 0.0f ? -C / K : 0.0f;
+                            const V2 P = v_scale(imp, normal);
+                            pos[b].x -= T[OT_IM] * P.x; pos[b].y -= T[OT_IM] * P.y;
+                            objA[m] -= T[OT_II] * v_cross(rA, P);
+                            pos[a].x += p.im_bot * P.x; pos[a].y += p.im_bot * P.y;
+                        } else if (act[isl]) {
                             float nx, ny, sep;
                             const float ima = bim(a), imb = bim(b), rda = brad(a), rdb = brad(b);
                             const float bx = pos[b].x, by = pos[b].y;
@@ -1138,6 +1236,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                             pos[b].x = bx + imb * Px; pos[b].y = by + imb * Py;
                         }
                     })
+                    if (OBJ && myMc) { viol |= mc_position_pass(myMc, leader, act, nxt); KB_ROUND_SYNC(); }
                     bool any;
                     if (coop) {
                         if (viol) misc[M_ANY] = 1u;
@@ -1153,6 +1252,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                     {
                         const int s_ = (int)bkStart[myw * BK_PER_WAVE], e_ = (int)bkStart[(myw + 1) * BK_PER_WAVE];
                         for (int i_ = s_ + lid; i_ < e_; i_ += stride) act[parent[sPair[order[i_]] >> 16]] = 0;
+                        if (OBJ && myMc) mc_clear_flags(myMc, leader, act);
                     }
                     KB_ROUND_SYNC();
                 }
@@ -1187,9 +1287,9 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                 cand[q] = i;
                 lPair[i] = (unsigned)b; cTh0[i] = sth0[q]; cTh[i] = th[q]; cW[i] = bw[q];
             }
-            if (tid < M) {
+            if (tid < M && objTab[tid * OT_WORDS + OT_KIND] == 0.0f) {   // circles only: no continuous step for polygons
                 const int i = (int)atomicAdd(&misc[M_NCON], 1u);
-                if (i < p.capL / 2) { candObj = i; lPair[i] = (unsigned)(N + tid); cTh0[i] = oth0; cTh[i] = oth; cW[i] = oww; }
+                if (i < p.capL / 2) { candObj = i; lPair[i] = (unsigned)(N + tid); cTh0[i] = objA0[tid]; cTh[i] = objA[tid]; cW[i] = objW[tid]; }
                 else atomicOr(&misc[M_STATUS], 8u);
             }
             __syncthreads();
@@ -1197,7 +1297,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
             for (int i = tid; i < ncand; i += nt) {
                 const int b = (int)lPair[i];
                 const bool isObj = b >= N;
-                const float R = isObj ? objR[b - N] : p.r_bot, im = isObj ? objIm[b - N] : p.im_bot;
+                const float R = isObj ? objTab[(b - N) * OT_WORDS + OT_RADIUS] : p.r_bot, im = isObj ? objTab[(b - N) * OT_WORDS + OT_IM] : p.im_bot;
                 float x_ = pos[b].x, y_ = pos[b].y, a_ = cTh[i], vx_ = vel[b].x, vy_ = vel[b].y, w_ = cW[i];
                 kb_toi_walls_body(p, R, im, start[b].x, start[b].y, cTh0[i], x_, y_, a_, vx_, vy_, w_);
                 pos[b].x = x_; pos[b].y = y_; vel[b].x = vx_; vel[b].y = vy_; cTh[i] = a_; cW[i] = w_;
@@ -1206,11 +1306,10 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
 #pragma unroll
             for (int q = 0; q < BPT; ++q)
                 if (cand[q] >= 0) { th[q] = cTh[cand[q]]; bw[q] = cW[cand[q]]; }
-            if (candObj >= 0) { oth = cTh[candObj]; oww = cW[candObj]; }
+            if (candObj >= 0) { objA[tid] = cTh[candObj]; objW[tid] = cW[candObj]; }
         }
         // the new warm-start list becomes the old one
         for (int b = tid; b < NP; b += nt) { wsCnt[b] = wsCntNew[b]; wsOff[b] = newOff[b]; }
-        for (int k = tid; k < M * OWS; k += nt) owsOld[k] = owsNew[k];
         oldInLds = newInLds;
         oldTotal = newTotal;
         __syncthreads();
@@ -1230,10 +1329,9 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
     }
     if (tid < M && p.n_substeps > 0) {
         const size_t oi = (size_t)e * M + tid;
-        g.ox[oi] = pos[N + tid].x; g.oy[oi] = pos[N + tid].y; g.otheta[oi] = oth;
-        g.ovx[oi] = vel[N + tid].x; g.ovy[oi] = vel[N + tid].y; g.ow[oi] = oww;
+        g.ox[oi] = pos[N + tid].x; g.oy[oi] = pos[N + tid].y; g.otheta[oi] = objA[tid];
+        g.ovx[oi] = vel[N + tid].x; g.ovy[oi] = vel[N + tid].y; g.ow[oi] = objW[tid];
     }
-    if (p.n_substeps > 0) for (int k = tid; k < M * OWS; k += nt) g.ows_acc[(size_t)e * MAXOBJ * OWS + k] = owsOld[k];
     if (tid == 0) {
         if (LIGHT_TYPE == KB_LIGHT_CIRCULAR && p.light_action && drive) { g.light_x[e] = lx; g.light_y[e] = ly; }
         if (LGEN && p.light_action && drive) {

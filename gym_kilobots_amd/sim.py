@@ -70,7 +70,7 @@ class KilobotSim:
         if M > 0:
             self.ox, self.oy, self.otheta = f(E, M), f(E, M), f(E, M)
             self.ovx, self.ovy, self.ow = f(E, M), f(E, M), f(E, M)
-            self.ows_acc = torch.full((E, nat.MAX_OBJECTS, 12), -1.0, dtype=torch.float32, device=dev)
+            self.ows_acc = torch.full((E, nat.MAX_OBJECTS, nat.OWS_COLS, nat.OWS_WORDS), -1.0, dtype=torch.float32, device=dev)
         self.light_value = self.light_gx = self.light_gy = None
         self.cmd_vx = self.cmd_vy = self.cmd_w = None
         if debug_outputs:

@@ -65,11 +65,17 @@ enum kb_light_type {
                                        KilobotsEnv._step_world, kilobots_env.py:217-219 */
 
 #define KB_MAX_OBJECTS 8
+#define KB_MAX_POLY_VERTS 4
+/* fixture of a pushable object (body.py): Circle :181-192, Quad / CornerQuad :129-178 (b2PolygonShape::SetAsBox),
+ * single-fixture convex Polygon :217-262 (b2PolygonShape::Set) */
+enum kb_shape { KB_SHAPE_CIRCLE = 0, KB_SHAPE_BOX = 1, KB_SHAPE_POLYGON = 2 };
+#define KB_OWS_COLS 12      /* object warm-start table: column = partner object 0..7, or 8 + wall */
+#define KB_OWS_WORDS 6      /* per entry: (feature id, normal impulse, tangent impulse) of <= 2 manifold points; id < 0 = none */
 #define KB_MAX_BOTS 1024
 
 /* Scene constants.  Defaults of the reference are given in brackets. */
 typedef struct kb_config {
-    int32_t num_envs, num_bots, num_objects;    /* num_objects: 0..8 circular pushable bodies per env */
+    int32_t num_envs, num_bots, num_objects;    /* num_objects: 0..8 pushable bodies per env (the same shapes in every env) */
     float world_width, world_height;            /* metres [2.0, 1.5]   kilobots_env.py:19 */
     float dt;                                   /* [0.1]               kilobots_env.py:25,32 */
     int32_t vel_iters, pos_iters;               /* [10, 10]            kilobots_env.py:26-27 */
@@ -83,7 +89,7 @@ typedef struct kb_config {
     float light_max_velocity;                   /* MomentumLight.max_velocity, light.py:289-292 */
     int32_t ws_slots;                           /* warm-start slots per bot [8] */
     float obj_radius[KB_MAX_OBJECTS];           /* metres; Circle(radius=...), body.py:181-192 */
-    float obj_density, obj_friction;            /* [2, 0.01] body.py:11-12; friction is not modelled */
+    float obj_density, obj_friction;            /* [2, 0.01] body.py:11-12 */
     float obj_linear_damping, obj_angular_damping; /* [0.8, 0.8] body.py:15-16 */
     int32_t toi_walls;                          /* [1] b2World::SolveTOI against the static walls (continuousPhysics) */
     int32_t solver_mode;                        /* 0 = automatic.  Test knobs (results are identical in every mode):
@@ -95,6 +101,13 @@ typedef struct kb_config {
     float lightc_radius[KB_MAX_LIGHTS], lightc_max_velocity[KB_MAX_LIGHTS];
     float lightc_lo[KB_MAX_LIGHTS][2], lightc_hi[KB_MAX_LIGHTS][2];
     float lightc_act_lo[KB_MAX_LIGHTS][2], lightc_act_hi[KB_MAX_LIGHTS][2];
+    /* objects other than circles */
+    int32_t obj_shape[KB_MAX_OBJECTS];          /* enum kb_shape [circle] */
+    int32_t obj_nverts[KB_MAX_OBJECTS];         /* KB_SHAPE_POLYGON: 3..KB_MAX_POLY_VERTS */
+    float obj_verts[KB_MAX_OBJECTS][KB_MAX_POLY_VERTS][2]; /* metres, body frame.  BOX: [0] = (width / 2, height / 2)
+                                                   (Quad, body.py:136-137).  POLYGON: counter-clockwise hull in
+                                                   b2PolygonShape::Set order, centred on its centroid (body.py:226-241) */
+    float wall_friction;                        /* [0.2] b2FixtureDef default of the arena chain, kilobots_env.py:46-51 */
 } kb_config;
 
 /* Device buffers of one handle.  NULL is allowed for buffers the configuration never touches
@@ -124,8 +137,10 @@ typedef struct kb_buffers {
                                            bit3 more than 512 bodies near the walls in one substep (TOI skipped for the rest) */
     void *scratch;                      /* required: kb_scratch_bytes() bytes; contact staging of envs whose
                                            contacts do not fit the LDS staging area (contents are transient) */
-    float *ows_acc;                     /* objects: [num_envs][8][12] warm-start impulses of object-object (column =
-                                           partner) and object-wall (column 8 + wall) contacts; < 0 = none */
+    float *ows_acc;                     /* objects: [num_envs][8][KB_OWS_COLS][KB_OWS_WORDS] manifold impulses of the
+                                           object-object (column = higher partner) and object-wall (column 8 + wall)
+                                           contacts: b2ManifoldPoint id / normalImpulse / tangentImpulse; fill with -1
+                                           to forget them */
 } kb_buffers;
 
 typedef struct kb_sim kb_sim;

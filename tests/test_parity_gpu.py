@@ -414,6 +414,105 @@ def test_cfg4_slice_1024_bots_4_objects():
     assert int(cpu(gsim.status).max()) == 0
 
 
+
+# ---- boxes / polygons with friction and rotation -----------------------------------------------
+def _shape_kw(shapes):
+    """shapes: list of ('box', w, h) | ('circle', r) | ('poly', [(x, y), ...]) -> config keywords (metres)."""
+    kw = dict(obj_shape=[], obj_verts=[], obj_radius=[], obj_nverts=[])
+    for sh in shapes:
+        if sh[0] == 'box':
+            kw['obj_shape'].append(O.SHAPE_BOX); kw['obj_verts'].append([[sh[1] / 2, sh[2] / 2]]); kw['obj_radius'].append(0.0); kw['obj_nverts'].append(4)
+        elif sh[0] == 'circle':
+            kw['obj_shape'].append(O.SHAPE_CIRCLE); kw['obj_verts'].append([[0.0, 0.0]]); kw['obj_radius'].append(sh[1]); kw['obj_nverts'].append(0)
+        else:
+            kw['obj_shape'].append(O.SHAPE_POLYGON); kw['obj_verts'].append([list(v) for v in sh[1]]); kw['obj_radius'].append(0.0); kw['obj_nverts'].append(len(sh[1]))
+    return kw
+
+
+TRIANGLE = [(0.05, -0.05), (0.05, 0.10), (-0.10, -0.05)]      # body.py:265-275 scaled to 0.15 x 0.15, recentred
+MIXED_SHAPES = [('box', 0.15, 0.15), ('circle', 0.06), ('box', 0.2, 0.1), ('poly', TRIANGLE)]
+
+
+@pytest.mark.parametrize('mode', [0, 1, 2, 3, 4])
+def test_boxes_pushed_by_a_crowd(mode):
+    """Two boxes, a disc and a triangle at the cfg4 positions inside a 256-bot crowd: kilobot-polygon contacts with
+    lever arms, object rotation, every solver path."""
+    E, N = 3, 256
+    xy, th = scenes.gaussian_spawn(E, N, sigma=0.3, seed=62)
+    th = scenes.toward_objects_theta(xy)
+    objs = np.tile(scenes.CFG4_OBJECTS[None], (E, 1, 1))
+    oth = np.tile(np.array([0.3, 0.0, -0.7, 1.1])[None], (E, 1))
+    osim, gsim = make_pair(E, N, xy=xy, th=th, solver_mode=mode, num_objects=4, **_shape_kw(MIXED_SHAPES))
+    osim.set_objects_m(objs, oth)
+    gsim.set_objects_m(objs, oth)
+    a = np.zeros((E, N, 2), np.float32)
+    a[..., 0] = 0.01
+    for k in range(6):
+        osim.set_actions(a)
+        osim.step(10)
+        gsim.step(10, actions=dev(a))
+        assert_same(osim, gsim, 'boxes mode %d step %d' % (mode, k), OBJ_FIELDS)
+        assert_ws_same(osim, gsim, 'boxes mode %d step %d' % (mode, k))
+    assert osim.count_contacts(0, True)[2] > 3
+    assert int(cpu(gsim.status).max()) == 0
+    assert np.abs(osim.objects_m()[..., 2] - oth).max() > 1e-4           # something was turned
+
+
+def test_box_wall_box_box_and_disc_manifolds():
+    """Objects shoved into each other and into the walls by their own initial velocity: two-point manifolds, block
+    solver, friction, feature-id warm starting; bit-exact every substep."""
+    E, N = 4, 4
+    xy = np.tile(np.array([[-0.9, 0.7], [-0.85, 0.7], [-0.8, 0.7], [-0.75, 0.7]])[None], (E, 1, 1))
+    shapes = [('box', 0.15, 0.15), ('box', 0.2, 0.1), ('circle', 0.05), ('poly', TRIANGLE), ('box', 0.1, 0.1)]
+    osim, gsim = make_pair(E, N, xy=xy, th=np.zeros((E, N)), num_objects=5, **_shape_kw(shapes))
+    rng = np.random.default_rng(9)
+    objs = np.tile(np.array([[0.7, 0.0], [0.45, 0.02], [0.3, -0.05], [0.6, 0.3], [0.8, -0.5]])[None], (E, 1, 1))
+    objs = objs + rng.uniform(-0.01, 0.01, objs.shape)
+    oth = rng.uniform(-1.0, 1.0, (E, 5))
+    oth[0] = 0.0                                                         # env 0: everything axis-aligned
+    osim.set_objects_m(objs, oth)
+    gsim.set_objects_m(objs, oth)
+    v0 = np.zeros((E, 5), np.float32)
+    v0[:] = [6.0, 9.0, 12.0, 5.0, 7.0]
+    vy0 = np.tile(np.array([0.0, 0.2, 0.5, -3.0, -6.0], np.float32)[None], (E, 1))
+    osim.ovx[...] = v0; osim.ovy[...] = vy0
+    gsim.ovx.copy_(dev(v0)); gsim.ovy.copy_(dev(vy0))
+    two_point = False
+    for k in range(60):
+        osim.step(1)
+        gsim.step(1)
+        assert_same(osim, gsim, 'manifolds substep %d' % k, OBJ_FIELDS)
+        two_point |= bool((osim.ows_acc[..., 3] >= 0).any())
+    assert two_point, 'no two-point manifold occurred'
+    assert int(cpu(gsim.status).max()) == 0
+    osim.step(40)
+    gsim.step(40)                                                         # fused launch, resting contacts
+    assert_same(osim, gsim, 'manifolds fused', OBJ_FIELDS)
+
+
+def test_1024_bots_with_boxes():
+    E, N = 2, 1024
+    xy, th = scenes.lattice_spawn(E, N, seed=72)
+    th = scenes.toward_objects_theta(xy)
+    objs = np.tile(scenes.CFG4_OBJECTS[None], (E, 1, 1))
+    osim, gsim = make_pair(E, N, xy=xy, th=th, num_objects=4, **_shape_kw(MIXED_SHAPES))
+    osim.set_objects_m(objs)
+    gsim.set_objects_m(objs)
+    osim.step(1, flags=O.STEP_NO_DRIVE)
+    gsim.step(1, flags=O.STEP_NO_DRIVE)
+    assert_same(osim, gsim, 'boxes resolve', OBJ_FIELDS)
+    for k in range(3):
+        a = scenes.random_actions(E, N, seed=90 + k)
+        a[:, ::2, 0] = 0.01
+        a[:, ::2, 1] = 0.0
+        osim.set_actions(a)
+        osim.step(10)
+        gsim.step(10, actions=dev(a))
+        assert_same(osim, gsim, '1024 + boxes step %d' % k, OBJ_FIELDS)
+        assert_ws_same(osim, gsim, '1024 + boxes step %d' % k)
+    assert int(cpu(gsim.status).max()) == 0
+
+
 # ---- size-independent properties on the HIP path --------------------------------------------------
 def test_fused_launch_equals_single_substep_launches():
     """kb_step(10) == 10 x kb_step(1), bit for bit (state incl. warm-start cache is complete)."""
