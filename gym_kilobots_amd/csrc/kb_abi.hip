@@ -198,7 +198,7 @@ int kb_create(const kb_config *cfg, kb_sim **out) {
         } else {
             int n;
             if (kind == KB_SHAPE_BOX) {                   // b2PolygonShape::SetAsBox
-                const float hx = cfg->obj_verts[m][0][0] * WORLD_SCALE, hy = cfg->obj_verts[m][0][1] * WORLD_SCALE;
+                const float hx = cfg->obj_verts[m][0][0], hy = cfg->obj_verts[m][0][1];
                 n = 4;
                 const float vx[4] = {-hx, hx, hx, -hx}, vy[4] = {-hy, -hy, hy, hy};
                 const float nx[4] = {0.0f, 1.0f, 0.0f, -1.0f}, ny[4] = {-1.0f, 0.0f, 1.0f, 0.0f};
@@ -209,8 +209,8 @@ int kb_create(const kb_config *cfg, kb_sim **out) {
             } else {                                      // b2PolygonShape::Set on an ordered hull
                 n = cfg->obj_nverts[m];
                 for (int i = 0; i < n; ++i) {
-                    T[OT_VERTS + 2 * i] = cfg->obj_verts[m][i][0] * WORLD_SCALE;
-                    T[OT_VERTS + 2 * i + 1] = cfg->obj_verts[m][i][1] * WORLD_SCALE;
+                    T[OT_VERTS + 2 * i] = cfg->obj_verts[m][i][0];
+                    T[OT_VERTS + 2 * i + 1] = cfg->obj_verts[m][i][1];
                 }
                 for (int i = 0; i < n; ++i) {
                     const V2 edge = v_sub(ot_v(T, i + 1 < n ? i + 1 : 0), ot_v(T, i));

@@ -200,10 +200,14 @@ class KilobotsEnv(object):
         kbs = self._kilobots
         if len(kbs) == 0:
             raise ValueError('the configured scene has no kilobots')
-        from ..lib.body import Circle
+        specs = []
         for ob in self._objects:
-            if not isinstance(ob, Circle) or isinstance(ob, Kilobot):
-                raise UnknownObjectException('only circular pushable objects (lib.Circle) run on the device in this version')
+            if isinstance(ob, Kilobot) or not hasattr(ob, '_shape_spec'):
+                raise UnknownObjectException('pushable objects must be lib.Circle, lib.Quad / CornerQuad or a single-fixture lib.Polygon')
+            try:
+                specs.append(ob._shape_spec())
+            except NotImplementedError as err:
+                raise UnknownObjectException(str(err))
         if len(self._objects) > nat.MAX_OBJECTS:
             raise UnknownObjectException('at most %d objects per env' % nat.MAX_OBJECTS)
         kinds = {type(k).drive_mode for k in kbs}
@@ -221,8 +225,14 @@ class KilobotsEnv(object):
                          bot_angular_damping=float(type(kbs[0])._angular_damping))
         if self._objects:
             ob0 = type(self._objects[0])
-            radii = [float(ob._radius) for ob in self._objects] + [0.075] * (nat.MAX_OBJECTS - len(self._objects))
-            overrides.update(num_objects=len(self._objects), obj_radius=radii, obj_density=float(ob0._density),
+            pad = nat.MAX_OBJECTS - len(self._objects)
+            radii = [sp[1] for sp in specs] + [0.075] * pad
+            verts = [[list(v) for v in sp[2]] + [[0.0, 0.0]] * (nat.MAX_POLY_VERTS - len(sp[2])) for sp in specs]
+            overrides.update(num_objects=len(self._objects), obj_radius=radii,
+                             obj_shape=[sp[0] for sp in specs] + [0] * pad,
+                             obj_nverts=[len(sp[2]) for sp in specs] + [0] * pad,
+                             obj_verts=verts + [[[0.0, 0.0]] * nat.MAX_POLY_VERTS] * pad,
+                             obj_density=float(ob0._density),
                              obj_friction=float(ob0._friction), obj_linear_damping=float(ob0._linear_damping),
                              obj_angular_damping=float(ob0._angular_damping))
         if self._light is not None:

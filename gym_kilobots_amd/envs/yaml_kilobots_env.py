@@ -3,8 +3,8 @@
 Drop-in for the reference's `YamlKilobotsEnv` / `EnvConfiguration`
 (gym_kilobots/envs/yaml_kilobots_env.py): the same YAML tags (`!EvalEnv`, `!ObjectConf`, `!LightConf`,
 `!KilobotsConf`), the same constructor (`YamlKilobotsEnv(configuration=conf)`), the same spaces and
-random-initialisation rules.  What runs on the GPU today: every light model, kilobots of any drive law,
-circular objects.  Box / polygon objects raise `UnknownObjectException` at reset().
+random-initialisation rules.  What runs on the GPU: every light model, kilobots of any drive law, circular, box and
+triangular objects.  The multi-fixture shapes (`l_shape`, `t_shape`, `c_shape`) raise `UnknownObjectException` at reset().
 """
 import random
 
@@ -12,7 +12,8 @@ import numpy as np
 import yaml
 
 from .. import lib as kb_lib
-from ..lib import Circle, CircularGradientLight, CompositeLight, GradientLight, MomentumLight, SinglePositionLight
+from ..lib import (CForm, Circle, CircularGradientLight, CompositeLight, CornerQuad, GradientLight, LForm, MomentumLight,
+                   Quad, SinglePositionLight, TForm, Triangle)
 from ..spaces import Box
 from .kilobots_env import KilobotsEnv, UnknownLightTypeException, UnknownObjectException
 
@@ -66,8 +67,8 @@ def rot_matrix(alpha):
 
 
 # shape strings of the reference's object factory (yaml_kilobots_env.py:216-245)
-_BOX_SHAPES = ('square', 'quad', 'rect', 'corner_quad', 'corner-quad')
-_POLY_SHAPES = ('triangle', 'l_shape', 't_shape', 'c_shape')
+_SHAPE_CLASSES = {'square': Quad, 'quad': Quad, 'rect': Quad, 'corner_quad': CornerQuad, 'corner-quad': CornerQuad,
+                  'triangle': Triangle, 'l_shape': LForm, 't_shape': TForm, 'c_shape': CForm}
 
 
 class YamlKilobotsEnv(KilobotsEnv):
@@ -140,8 +141,9 @@ class YamlKilobotsEnv(KilobotsEnv):
         if object_shape == 'circle':
             # note: the reference passes the configured *width* as the radius (yaml_kilobots_env.py:229-231)
             obj = Circle(radius=object_width, position=object_init[:2], orientation=object_init[2], world=self.world)
-        elif object_shape in _BOX_SHAPES or object_shape in _POLY_SHAPES:
-            raise UnknownObjectException('Shape of form {} does not run on the device yet (circles do).'.format(object_shape))
+        elif object_shape in _SHAPE_CLASSES:
+            obj = _SHAPE_CLASSES[object_shape](width=object_width, height=object_height, position=object_init[:2],
+                                               orientation=object_init[2], world=self.world)
         else:
             raise UnknownObjectException('Shape of form {} not known.'.format(object_shape))
         if object_color:

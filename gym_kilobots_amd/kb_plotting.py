@@ -19,8 +19,20 @@ def snapshot(sim, env_index=0):
     return kb, objs, light
 
 
-def plot_env(sim, env_index=0, axes=None, world_size=(2.0, 1.5), object_radii=None, light_radii=None, title=None):
-    """Draw env `env_index` of `sim` (a KilobotSim or anything with the same poses()/object_poses() API)."""
+def plot_body(axes, body, **kwargs):
+    """Body.plot of the reference (kb_plotting.py:44-145 plot_rect / plot_polygon / plot_circle): one object view."""
+    from matplotlib.patches import Circle as MplCircle, Polygon as MplPolygon
+    kwargs.setdefault('facecolor', tuple(np.asarray(body.color) / 255.0))
+    kwargs.setdefault('edgecolor', 'k')
+    if hasattr(body, 'get_radius'):
+        return axes.add_patch(MplCircle(tuple(body.get_position()), body.get_radius(), **kwargs))
+    return [axes.add_patch(MplPolygon(np.asarray(vs), closed=True, **kwargs)) for vs in body.vertices]
+
+
+def plot_env(sim, env_index=0, axes=None, world_size=(2.0, 1.5), object_radii=None, light_radii=None, title=None,
+             object_vertices=None):
+    """Draw env `env_index` of `sim` (a KilobotSim or anything with the same poses()/object_poses() API).
+    object_vertices: per object None (circle of object_radii) or its body-frame polygon [[x, y], ...] in metres."""
     import matplotlib
     if axes is None:
         matplotlib.use('Agg', force=False)
@@ -37,7 +49,14 @@ def plot_env(sim, env_index=0, axes=None, world_size=(2.0, 1.5), object_radii=No
             axes.add_patch(MplCircle((lx, ly), r, facecolor=(1.0, 1.0, 0.12, 0.35), edgecolor='none'))
     if objs is not None:
         radii = object_radii if object_radii is not None else [0.075] * len(objs)
-        for (x, y, th), r in zip(objs, radii):
+        polys = object_vertices if object_vertices is not None else [None] * len(objs)
+        for (x, y, th), r, vs in zip(objs, radii, polys):
+            if vs is not None:
+                from matplotlib.patches import Polygon as MplPolygon
+                c, s_ = np.cos(th), np.sin(th)
+                vw = [(c * vx - s_ * vy + x, s_ * vx + c * vy + y) for vx, vy in vs]
+                axes.add_patch(MplPolygon(vw, closed=True, facecolor=(93 / 255, 133 / 255, 195 / 255), edgecolor='k', linewidth=0.5))
+                continue
             axes.add_patch(MplCircle((x, y), r, facecolor=(93 / 255, 133 / 255, 195 / 255), edgecolor='k', linewidth=0.5))
             axes.plot([x, x + r * np.cos(th)], [y, y + r * np.sin(th)], color='k', linewidth=0.5)
     for x, y, th in kb:

@@ -176,6 +176,10 @@ class Circle(Body):
     def _arrays(self):
         return ('ox', 'oy', 'otheta')
 
+    def _shape_spec(self):
+        """(kb_shape, radius [m], vertices [world units]) as the device configuration takes it."""
+        return 0, float(self._radius), []
+
     @property
     def width(self):
         return 2 * self._radius
@@ -190,3 +194,180 @@ class Circle(Body):
 
     def get_radius(self):
         return self._radius
+
+
+class Quad(Body):
+    """Box of width x height centred on the body origin (reference body.py:129-163: b2PolygonShape::SetAsBox)."""
+
+    def __init__(self, width, height, **kwargs):
+        super().__init__(**kwargs)
+        self._width = width
+        self._height = height
+
+    def _arrays(self):
+        return ('ox', 'oy', 'otheta')
+
+    def _shape_spec(self):
+        return 1, 0.0, [[self._width / 2 * _world_scale, self._height / 2 * _world_scale]]      # body.py:137
+
+    @property
+    def width(self):
+        return self._width
+
+    @property
+    def height(self):
+        return self._height
+
+    def get_width(self):
+        return self._width
+
+    def get_height(self):
+        return self._height
+
+    @property
+    def local_vertices(self):
+        hx, hy = self._width / 2, self._height / 2
+        return np.array([[(-hx, -hy), (hx, -hy), (hx, hy), (-hx, hy)]])          # SetAsBox order
+
+    @property
+    def vertices(self):
+        return np.array([[self.get_world_point(v) for v in self.local_vertices[0]]])
+
+    def plot(self, axes, **kwargs):
+        from ..kb_plotting import plot_body
+        return plot_body(axes, self, **kwargs)
+
+
+class CornerQuad(Quad):
+    """A Quad whose first three vertices are drawn highlighted (reference body.py:166-178); same physics."""
+
+
+def _hull_order(points):
+    """Vertex order b2PolygonShape::Set produces: gift wrapping, counter-clockwise, starting at the lowest of the
+    right-most points (fp32 like Box2D)."""
+    ps = [np.asarray(p, np.float32) for p in points]
+    i0 = 0
+    for i in range(1, len(ps)):
+        if ps[i][0] > ps[i0][0] or (ps[i][0] == ps[i0][0] and ps[i][1] < ps[i0][1]):
+            i0 = i
+    hull, ih = [], i0
+    while True:
+        hull.append(ih)
+        ie = 0
+        for j in range(1, len(ps)):
+            if ie == ih:
+                ie = j
+                continue
+            r, v = ps[ie] - ps[hull[-1]], ps[j] - ps[hull[-1]]
+            c = np.float32(r[0] * v[1]) - np.float32(r[1] * v[0])
+            if c < 0 or (c == 0 and float(v @ v) > float(r @ r)):
+                ie = j
+        ih = ie
+        if ie == i0:
+            break
+    return [points[i] for i in hull]
+
+
+class Polygon(Body):
+    """Polygon bodies of the reference (body.py:217-262): `_shape_vertices()` lists convex sub-polygons that are
+    scaled to width x height and recentred on the area-weighted mean of their vertex means.  Bodies made of ONE
+    convex polygon with at most 4 vertices run on the device; multi-fixture shapes do not yet."""
+
+    def __init__(self, width, height, **kwargs):
+        super().__init__(**kwargs)
+        self._width = width
+        self._height = height
+        vertices = np.array(self._shape_vertices(), dtype=np.float64)
+        v_size = np.amax(vertices, (0, 1)) - np.amin(vertices, (0, 1))
+        vertices /= v_size
+        vertices *= np.array((width, height))
+        centroid = np.zeros(2)
+        area = .0
+        for vs in vertices:
+            a = 0.5 * np.abs(np.dot(vs[:, 0], np.roll(vs[:, 1], 1)) - np.dot(vs[:, 1], np.roll(vs[:, 0], 1)))
+            area += a
+            centroid += vs.mean(axis=0) * a
+        centroid /= area
+        self._local_vertices = vertices - centroid
+        self._local_vertices.setflags(write=False)
+
+    def _arrays(self):
+        return ('ox', 'oy', 'otheta')
+
+    def _shape_spec(self):
+        if len(self._local_vertices) != 1 or not 3 <= len(self._local_vertices[0]) <= 4:
+            raise NotImplementedError('%s: bodies with several fixtures do not run on the device yet'
+                                      % type(self).__name__)
+        return 2, 0.0, [[float(x), float(y)] for x, y in _hull_order([tuple(v) for v in self._local_vertices[0] * _world_scale])]
+
+    @property
+    def width(self):
+        return self._width
+
+    @property
+    def height(self):
+        return self._height
+
+    @property
+    def local_vertices(self):
+        return self._local_vertices
+
+    @property
+    def vertices(self):
+        return np.array([[self.get_world_point(v) for v in vs] for vs in self._local_vertices])
+
+    @property
+    def plot_vertices(self):
+        raise NotImplementedError
+
+    @staticmethod
+    def _shape_vertices():
+        raise NotImplementedError
+
+    def plot(self, axes, **kwargs):
+        from ..kb_plotting import plot_body
+        return plot_body(axes, self, **kwargs)
+
+
+class Triangle(Polygon):
+    @staticmethod
+    def _shape_vertices():
+        return np.array([[(-0.5, 0.0), (0.0, 0.0), (0.0, 1.0)]])
+
+    @property
+    def plot_vertices(self):
+        return self.vertices.reshape((-1, 2))
+
+
+class LForm(Polygon):
+    @staticmethod
+    def _shape_vertices():
+        return np.array([[(-0.05, 0.0), (0.1, 0.0), (0.1, 0.3), (-0.05, 0.3)],
+                         [(0.1, 0.0), (0.1, -0.15), (-0.2, -0.15), (-0.2, 0.0)]])
+
+    @property
+    def plot_vertices(self):
+        return self.vertices.reshape((-1, 2))[[0, 7, 6, 5, 2, 3], :]
+
+
+class TForm(Polygon):
+    @staticmethod
+    def _shape_vertices():
+        return np.array([[(0.0, 0.15), (0.2, 0.15), (0.2, -0.15), (0.0, -0.15)],
+                         [(0.0, 0.05), (0.0, -0.05), (-0.2, -0.05), (-0.2, 0.05)]])
+
+    @property
+    def plot_vertices(self):
+        return self.vertices.reshape((-1, 2))[[0, 1, 2, 3, 5, 6, 7, 4], :]
+
+
+class CForm(Polygon):
+    @staticmethod
+    def _shape_vertices():
+        return np.array([[(0.09, 0.15), (0.09, -0.15), (-0.01, -0.15), (-0.01, 0.15,)],
+                         [(-0.01, -0.15), (-0.11, -0.15), (-0.11, -0.08), (-0.01, -0.05)],
+                         [(-0.01, 0.15), (-0.11, 0.15), (-0.11, 0.08), (-0.01, 0.05)]])
+
+    @property
+    def plot_vertices(self):
+        return self.vertices.reshape((-1, 2))[[0, 1, 5, 6, 7, 11, 10, 9], :]

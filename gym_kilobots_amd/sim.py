@@ -147,7 +147,9 @@ class KilobotSim:
 
     def object_poses(self):
         """[num_envs, num_objects, 3] float32 (x [m], y [m], theta): get_state()['objects'] of every env."""
-        return torch.stack([self.ox / WORLD_SCALE, self.oy / WORLD_SCALE, self.otheta], -1)
+        # tensor / tensor: a true IEEE division like Body.get_pose (torch multiplies by the reciprocal for tensor / scalar)
+        scale = torch.full_like(self.ox, WORLD_SCALE)
+        return torch.stack([torch.div(self.ox, scale), torch.div(self.oy, scale), self.otheta], -1)
 
     def poses(self):
         """[num_envs, num_bots, 3] float32 (x [m], y [m], theta): get_state()['kilobots'] of every env."""

@@ -104,9 +104,11 @@ typedef struct kb_config {
     /* objects other than circles */
     int32_t obj_shape[KB_MAX_OBJECTS];          /* enum kb_shape [circle] */
     int32_t obj_nverts[KB_MAX_OBJECTS];         /* KB_SHAPE_POLYGON: 3..KB_MAX_POLY_VERTS */
-    float obj_verts[KB_MAX_OBJECTS][KB_MAX_POLY_VERTS][2]; /* metres, body frame.  BOX: [0] = (width / 2, height / 2)
-                                                   (Quad, body.py:136-137).  POLYGON: counter-clockwise hull in
-                                                   b2PolygonShape::Set order, centred on its centroid (body.py:226-241) */
+    float obj_verts[KB_MAX_OBJECTS][KB_MAX_POLY_VERTS][2]; /* body frame, Box2D WORLD UNITS: metres x 25 evaluated in double and
+                                                   then rounded, exactly what body.py:137,246 hands to Box2D.
+                                                   BOX: [0] = (width / 2, height / 2) x 25 (Quad, body.py:136-137).
+                                                   POLYGON: counter-clockwise hull in b2PolygonShape::Set order, centred on
+                                                   its centroid (body.py:226-241) */
     float wall_friction;                        /* [0.2] b2FixtureDef default of the arena chain, kilobots_env.py:46-51 */
 } kb_config;
 

@@ -217,13 +217,13 @@ static void derive(const kbo_config *c, derived_t *d) {
             io = mo * (0.5f * d->r_obj[k] * d->r_obj[k]);                /* I = mass * (0.5 r^2 + |p|^2), p = 0 */
         } else {
             if (sh->kind == KBO_SHAPE_BOX) {                               /* b2PolygonShape::SetAsBox */
-                float hx = c->obj_verts[k][0][0] * WORLD_SCALE, hy = c->obj_verts[k][0][1] * WORLD_SCALE;
+                float hx = c->obj_verts[k][0][0], hy = c->obj_verts[k][0][1];
                 sh->n = 4;
                 sh->v[0] = V2(-hx, -hy); sh->v[1] = V2(hx, -hy); sh->v[2] = V2(hx, hy); sh->v[3] = V2(-hx, hy);
                 sh->nrm[0] = V2(0.0f, -1.0f); sh->nrm[1] = V2(1.0f, 0.0f); sh->nrm[2] = V2(0.0f, 1.0f); sh->nrm[3] = V2(-1.0f, 0.0f);
             } else {                                                       /* b2PolygonShape::Set on an ordered hull */
                 sh->n = c->obj_nverts[k] < 3 ? 3 : (c->obj_nverts[k] > KBO_MAX_POLY_VERTS ? KBO_MAX_POLY_VERTS : c->obj_nverts[k]);
-                for (int i = 0; i < sh->n; ++i) sh->v[i] = V2(c->obj_verts[k][i][0] * WORLD_SCALE, c->obj_verts[k][i][1] * WORLD_SCALE);
+                for (int i = 0; i < sh->n; ++i) sh->v[i] = V2(c->obj_verts[k][i][0], c->obj_verts[k][i][1]);
                 for (int i = 0; i < sh->n; ++i) {
                     v2 edge = v_sub(sh->v[i + 1 < sh->n ? i + 1 : 0], sh->v[i]);
                     sh->nrm[i] = v_normalize(v_cross_vs(edge, 1.0f));

@@ -5,7 +5,8 @@ import numpy as np
 import pytest
 import torch
 
-from gym_kilobots_amd.envs import KilobotsEnv, DirectControlKilobotsEnv, BatchedKilobotsEnv, UnknownLightTypeException
+from gym_kilobots_amd.envs import (KilobotsEnv, DirectControlKilobotsEnv, BatchedKilobotsEnv, UnknownLightTypeException,
+                                    UnknownObjectException)
 from gym_kilobots_amd.lib import (SimpleVelocityControlKilobot, SimpleAccelerationControlKilobot, PhototaxisKilobot,
                                   SimplePhototaxisKilobot, CircularGradientLight, Body, Circle, Light)
 from gym_kilobots_amd import dist as kdist
@@ -149,6 +150,51 @@ def test_env_with_pushable_circles():
     assert env.kilobots[2].collides_with(env.objects[0]) in (True, None)
 
 
+def test_env_with_a_pushable_box_and_triangle():
+    from gym_kilobots_amd.lib import CornerQuad, Quad, Triangle, LForm
+
+    class BoxEnv(DirectControlKilobotsEnv):
+        def _configure_environment(self):
+            # the reference's QuadPushingEnv object (kilobots_test_envs.py:11-21): a 0.15 m box
+            self._add_object(CornerQuad(world=self.world, width=.15, height=.15, position=(.1, .02)))
+            self._add_object(Triangle(world=self.world, width=.15, height=.15, position=(-.4, .3), orientation=0.3))
+            for i in range(6):
+                self._add_kilobot(SimpleVelocityControlKilobot(self.world, position=(-0.02, 0.035 * (i - 1)), velocity=[0.0, 0.0]))
+
+        def get_reward(self, state, action, new_state):
+            return float(new_state['objects'][0, 0] - state['objects'][0, 0])
+
+    env = BoxEnv(sim_factory=OracleBackend)
+    obs = env.reset()
+    assert obs['objects'].shape == (2, 3)
+    box, tri = env.objects
+    assert isinstance(box, Quad) and box.width == .15 and box.get_height() == .15
+    np.testing.assert_allclose(box.vertices[0][2], np.array([.1, .02]) + .075, atol=1e-6)      # SetAsBox order
+    # Polygon bodies are recentred on their centroid (body.py:226-241): vertex mean of a triangle is the origin
+    np.testing.assert_allclose(tri.local_vertices[0].mean(0), 0.0, atol=1e-12)
+    spec = tri._shape_spec()
+    assert spec[0] == 2 and len(spec[2]) == 3
+    hull = np.array(spec[2])
+    assert np.allclose(hull[0], hull[hull[:, 0].argmax()])                  # starts at the right-most (lowest) vertex
+    e1, e2 = hull[1] - hull[0], hull[2] - hull[1]
+    assert e1[0] * e2[1] - e1[1] * e2[0] > 0                                # counter-clockwise
+    total = 0.0
+    for _ in range(25):
+        obs, r, done, info = env.step(np.tile([0.01, 0.0], (6, 1)))
+        total += r
+    assert total > 0.01 and obs['objects'][0, 0] > 0.11                     # pushed along +x ...
+    assert abs(obs['objects'][0, 2]) > 1e-4                                 # ... and turned (off-centre crowd)
+    np.testing.assert_allclose(box.get_pose(), obs['objects'][0], atol=1e-6)
+
+    class LEnv(BoxEnv):
+        def _configure_environment(self):
+            self._add_object(LForm(world=self.world, width=.15, height=.15, position=(.3, .0)))
+            self._add_kilobot(SimpleVelocityControlKilobot(self.world, position=(0, 0), velocity=[0.0, 0.0]))
+
+    with pytest.raises(UnknownObjectException):
+        LEnv(sim_factory=OracleBackend).reset()
+
+
 def test_unsupported_scenes_fail_loudly():
     class MixedEnv(KilobotsEnv):
         def _configure_environment(self):
@@ -287,9 +333,17 @@ def test_yaml_env_f3():
         assert type(env.kilobots[0]).__name__ == 'PhototaxisKilobot'
     finally:
         YamlKilobotsEnv.honour_kilobot_type = False
+    # boxes and triangles run on the device; the multi-fixture shapes fail loudly
     conf.objects[0].shape = 'quad'
+    conf.objects[1].shape = 'triangle'
+    env2 = YamlKilobotsEnv(configuration=conf, sim_factory=OracleBackend)
+    o3 = env2.reset()
+    assert type(env2.objects[0]).__name__ == 'Quad' and type(env2.objects[1]).__name__ == 'Triangle'
+    assert o3['objects'].shape == (2, 3) and env2.objects[0].vertices.shape == (1, 4, 2)
+    env2.step(np.array([0.0, 0.0, 0.0, 0.0]))
+    conf.objects[0].shape = 'l_shape'
     with pytest.raises(UnknownObjectException):
-        YamlKilobotsEnv(configuration=conf, sim_factory=OracleBackend)
+        YamlKilobotsEnv(configuration=conf, sim_factory=OracleBackend).reset()
 
 
 def test_debug_view_f4(tmp_path):

@@ -69,3 +69,44 @@ def test_batched_env_on_gpu():
         obs, r, done, info = env.step(a)
     assert (r > 0).all() and torch.isfinite(obs).all()
     assert env.gather_episode_returns().shape == (32,)
+
+
+YAML_BOXES = """
+!EvalEnv
+width: 1.0
+height: 0.8
+resolution: 600
+objects:
+    - !ObjectConf {idx: 0, shape: square, width: 0.15, height: 0.15, init: [0.05, 0.0, 0.2], color: [10, 20, 255], symmetry: 4}
+    - !ObjectConf {idx: 1, shape: corner_quad, width: 0.1, height: 0.2, init: [0.3, 0.1, -0.4], color: ~, symmetry: 1}
+    - !ObjectConf {idx: 2, shape: triangle, width: 0.15, height: 0.15, init: [-0.2, -0.2, 1.0], color: ~, symmetry: 1}
+    - !ObjectConf {idx: 3, shape: circle, width: 0.05, height: 0.05, init: [0.42, -0.3, 0.0], color: ~, symmetry: 1}
+light: !LightConf {type: circular, init: [0.3, 0.0], radius: 0.4}
+kilobots: !KilobotsConf {num: 40, mean: [-0.05, 0.0], std: 0.04}
+"""
+
+
+def test_yaml_scene_with_boxes_on_gpu_equals_oracle_env():
+    """The reference's object-pushing set-up (yaml_kilobots_env.py:216-242): a light drags the swarm into boxes; the
+    env on the HIP path and the oracle-backed env see identical observations."""
+    import yaml
+    from gym_kilobots_amd.envs import YamlKilobotsEnv
+    conf = yaml.load(YAML_BOXES, Loader=yaml.Loader)
+    g = YamlKilobotsEnv(configuration=conf)
+    o = YamlKilobotsEnv(configuration=conf, sim_factory=OracleBackend)
+    np.random.seed(11)
+    og = g.reset()
+    np.random.seed(11)                                        # same random spawn for both
+    oo = o.reset()
+    assert np.array_equal(og['kilobots'], oo['kilobots']) and np.array_equal(og['objects'], oo['objects'])
+    start = og['objects'].copy()
+    for k in range(40):
+        a = np.array([0.01, 0.002 * np.sin(0.3 * k)])
+        og, *_ = g.step(a)
+        oo, *_ = o.step(a)
+        assert np.array_equal(og['kilobots'], oo['kilobots']), k
+        assert np.array_equal(og['objects'], oo['objects']), k
+    assert type(g.sim).__name__ == 'KilobotSim'
+    assert int(g.sim.status.max().item()) == int(o.sim.status.max().item())     # (dense spawn: warm-start slots may overflow)
+    assert np.abs(og['objects'] - start).max() > 1e-3          # the swarm moved something
+    g.close()

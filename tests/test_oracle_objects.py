@@ -18,11 +18,11 @@ def _sim(num_bots=1, shapes=('box',), sizes=None, **kw):
     obj_shape, obj_verts, obj_radius, obj_nverts = [], [], [], []
     for sh, sz in zip(shapes, sizes):
         if sh == 'box':
-            obj_shape.append(O.SHAPE_BOX); obj_verts.append([[sz[0] / 2, sz[1] / 2]]); obj_radius.append(0.0); obj_nverts.append(4)
+            obj_shape.append(O.SHAPE_BOX); obj_verts.append([[sz[0] / 2 * W, sz[1] / 2 * W]]); obj_radius.append(0.0); obj_nverts.append(4)
         elif sh == 'circle':
             obj_shape.append(O.SHAPE_CIRCLE); obj_verts.append([[0, 0]]); obj_radius.append(sz[0]); obj_nverts.append(0)
         else:                                   # explicit counter-clockwise polygon
-            obj_shape.append(O.SHAPE_POLYGON); obj_verts.append(list(sz)); obj_radius.append(0.0); obj_nverts.append(len(sz))
+            obj_shape.append(O.SHAPE_POLYGON); obj_verts.append([(x * W, y * W) for x, y in sz]); obj_radius.append(0.0); obj_nverts.append(len(sz))
     cfg = O.default_config(1, num_bots, O.DRIVE_VELOCITY, num_objects=M, obj_shape=obj_shape, obj_verts=obj_verts,
                            obj_radius=obj_radius, obj_nverts=obj_nverts, **kw)
     return O.OracleSim(cfg)
@@ -218,7 +218,7 @@ def test_rotated_box_hits_a_wall_corner_first_and_stays_inside():
 def test_threads_do_not_change_results():
     def run(threads):
         cfg = O.default_config(6, 8, O.DRIVE_VELOCITY, num_objects=2, obj_shape=[O.SHAPE_BOX, O.SHAPE_CIRCLE],
-                               obj_verts=[[[0.075, 0.05]], [[0, 0]]], obj_radius=[0.0, 0.06])
+                               obj_verts=[[[0.075 * W, 0.05 * W]], [[0, 0]]], obj_radius=[0.0, 0.06])
         sim = O.OracleSim(cfg)
         rng = np.random.default_rng(5)
         sim.set_poses_m(rng.uniform(-0.25, 0.25, (6, 8, 2)), rng.uniform(-3, 3, (6, 8)))

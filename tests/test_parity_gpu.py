@@ -421,11 +421,11 @@ def _shape_kw(shapes):
     kw = dict(obj_shape=[], obj_verts=[], obj_radius=[], obj_nverts=[])
     for sh in shapes:
         if sh[0] == 'box':
-            kw['obj_shape'].append(O.SHAPE_BOX); kw['obj_verts'].append([[sh[1] / 2, sh[2] / 2]]); kw['obj_radius'].append(0.0); kw['obj_nverts'].append(4)
+            kw['obj_shape'].append(O.SHAPE_BOX); kw['obj_verts'].append([[sh[1] / 2 * 25.0, sh[2] / 2 * 25.0]]); kw['obj_radius'].append(0.0); kw['obj_nverts'].append(4)
         elif sh[0] == 'circle':
             kw['obj_shape'].append(O.SHAPE_CIRCLE); kw['obj_verts'].append([[0.0, 0.0]]); kw['obj_radius'].append(sh[1]); kw['obj_nverts'].append(0)
         else:
-            kw['obj_shape'].append(O.SHAPE_POLYGON); kw['obj_verts'].append([list(v) for v in sh[1]]); kw['obj_radius'].append(0.0); kw['obj_nverts'].append(len(sh[1]))
+            kw['obj_shape'].append(O.SHAPE_POLYGON); kw['obj_verts'].append([[v[0] * 25.0, v[1] * 25.0] for v in sh[1]]); kw['obj_radius'].append(0.0); kw['obj_nverts'].append(len(sh[1]))
     return kw
 
 
