@@ -37,6 +37,7 @@ def main():
     ap.add_argument('--bots', type=int, default=1024)
     ap.add_argument('--threads', type=int, default=0, help='workgroup size override')
     ap.add_argument('--objects', type=int, default=0, help='cfg4: 4 pushable discs per env (not the headline workload)')
+    ap.add_argument('--boxes', action='store_true', help='with --objects: 0.15 m boxes (Quad) instead of discs')
     ap.add_argument('--no-toi', action='store_true', help='disable the continuous step against the walls (A/B only)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-envs', type=int, default=64)
@@ -67,7 +68,10 @@ def main():
     reps = (E + base - 1) // base
     xy = np.tile(xy1, (reps, 1, 1))[:E]
     th = np.tile(th1, (reps, 1))[:E]
-    sim = KilobotSim(E, N, device=dev, num_objects=args.objects, toi_walls=0 if args.no_toi else 1)
+    okw = {}
+    if args.objects and args.boxes:      # reference Quad(width=.15, height=.15): half extents in world units
+        okw = dict(obj_shape=[1] * args.objects, obj_nverts=[4] * args.objects, obj_verts=[[[0.075 * 25.0, 0.075 * 25.0]]] * args.objects)
+    sim = KilobotSim(E, N, device=dev, num_objects=args.objects, toi_walls=0 if args.no_toi else 1, **okw)
     if args.threads:
         sim.block_threads = args.threads
     sim.set_poses_m(xy, th)
@@ -150,7 +154,7 @@ def main():
         'metric': 'kilobot-steps/sec', 'value': value, 'unit': 'kilobot-steps/s', 'n_gpus': world,
         'steps': K, 'warmup': args.warmup, 'ms_per_step': elapsed / K * 1e3, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': ('cfg4 (+%d pushable discs): ' % args.objects if args.objects else '') + 'cfg3: %d envs x %d kilobots per GPU, empty arena 2.0x1.5 m, jittered lattice spawn, '
+        'config': {'workload': ('cfg4 (+%d pushable %s): ' % (args.objects, 'boxes' if args.boxes else 'discs') if args.objects else '') + 'cfg3: %d envs x %d kilobots per GPU, empty arena 2.0x1.5 m, jittered lattice spawn, '
                                'random velocity-control actions every substep; 1 step = 1 world substep (dt 0.1 s) in 1 launch'
                                % (E, N),
                    'envs_per_gpu': E, 'bots': N, 'total_envs': total_envs, 'substeps_per_launch': 1,

@@ -227,7 +227,8 @@ __device__ inline void collide_polygons(Manifold &m, const float *TA, const XF &
 }
 
 // wall w: a point on it (vertex v1 of its chain edge, kilobots_env.py:48-51) and its normal into the arena
-__device__ __forceinline__ V2 wall_point(const Params &p, int wl) {
+struct Arena { float xmin, ymin, xmax, ymax; };
+__device__ __forceinline__ V2 wall_point(const Arena &p, int wl) {
     switch (wl) {
     case 0: return mk2(p.xmin, p.ymax);
     case 1: return mk2(p.xmin, p.ymin);
@@ -247,7 +248,7 @@ __device__ __forceinline__ V2 wall_normal(int wl) {
 // b2CollideEdgeAndPolygon for a long two-sided edge with the polygon on its inner side: the edge is the reference
 // face, the incident edge is the polygon edge most anti-parallel to the wall normal; both of its vertices are
 // candidates (the side planes of a long edge never clip), kept when within 2 * polygonRadius
-__device__ inline void collide_wall_poly(Manifold &m, const Params &p, int wl, const float *T, const XF &xfB) {
+__device__ inline void collide_wall_poly(Manifold &m, const Arena &p, int wl, const float *T, const XF &xfB) {
     m.count = 0;
     const int n = ot_n(T);
     const V2 nw = wall_normal(wl), v1 = wall_point(p, wl);
@@ -344,7 +345,7 @@ KB_DI void mc_candidate(int M, int t, int &owner, int &col) {
 
 // Manifold of candidate t at the current poses + impulses of the same features in the previous substep
 // (b2Contact::Update) + b2ContactSolver::InitializeVelocityConstraints; writes record t.  False: not touching.
-__device__ inline bool mc_detect(const ObjCtx &x, const Params &p, int M, int t, const float *owsOld) {
+__device__ __noinline__ bool mc_detect(const ObjCtx &x, const Arena &p, int M, int t, const float *owsOld) {
     int owner, col;
     mc_candidate(M, t, owner, col);
     Manifold mf;
@@ -381,7 +382,12 @@ __device__ inline bool mc_detect(const ObjCtx &x, const Params &p, int M, int t,
         a = WALL_CODE + wl; b = N + m;
         if (ot_kind(T) == KB_SHAPE_CIRCLE) {                // b2CollideEdgeAndCircle, region AB
             float dist, nx, ny;
-            wall_geom(p, wl, x.pos[b].x, x.pos[b].y, dist, nx, ny);
+            switch (wl) {       // wall_geom
+            case 0: nx = 1.0f; ny = 0.0f; dist = x.pos[b].x - p.xmin; break;
+            case 1: nx = 0.0f; ny = 1.0f; dist = x.pos[b].y - p.ymin; break;
+            case 2: nx = -1.0f; ny = 0.0f; dist = p.xmax - x.pos[b].x; break;
+            default: nx = 0.0f; ny = -1.0f; dist = p.ymax - x.pos[b].y; break;
+            }
             const float rwo = B2_POLYGON_RADIUS + T[OT_RADIUS];
             if (dist * dist > rwo * rwo) return false;
             if (dist < 0.0f) { nx = -nx; ny = -ny; }
@@ -491,7 +497,7 @@ KB_DI V2 mc_dv(const BState &A, const BState &B, V2 rA, V2 rB) {
 }
 
 // b2ContactSolver::WarmStart of record t
-__device__ inline void mc_warm_start(const ObjCtx &x, int t) {
+__device__ __noinline__ void mc_warm_start(const ObjCtx &x, int t) {
     const int a = mci(x, MC_A, t), b = mci(x, MC_B, t), vcount = (mci(x, MC_TYPE, t) >> 4) & 3;
     BState A = body_get(x, a), B = body_get(x, b);
     const V2 normal = mk2(mcf(x, MC_NX, t), mcf(x, MC_NY, t)), tangent = v_cross_vs(normal, 1.0f);
@@ -506,7 +512,7 @@ __device__ inline void mc_warm_start(const ObjCtx &x, int t) {
 }
 
 // b2ContactSolver::SolveVelocityConstraints of record t
-__device__ inline void mc_solve_velocity(const ObjCtx &x, int t) {
+__device__ __noinline__ void mc_solve_velocity(const ObjCtx &x, int t) {
     const int a = mci(x, MC_A, t), b = mci(x, MC_B, t), vcount = (mci(x, MC_TYPE, t) >> 4) & 3;
     BState A = body_get(x, a), B = body_get(x, b);
     const V2 normal = mk2(mcf(x, MC_NX, t), mcf(x, MC_NY, t)), tangent = v_cross_vs(normal, 1.0f);
@@ -570,7 +576,7 @@ __device__ inline void mc_solve_velocity(const ObjCtx &x, int t) {
 }
 
 // b2ContactSolver::SolvePositionConstraints of record t; returns its minimum separation
-__device__ inline float mc_solve_position(const ObjCtx &x, int t) {
+__device__ __noinline__ float mc_solve_position(const ObjCtx &x, int t) {
     const int a = mci(x, MC_A, t), b = mci(x, MC_B, t);
     const int tc = mci(x, MC_TYPE, t), type = tc & 3, count = (tc >> 2) & 3;
     BState A = body_get(x, a), B = body_get(x, b);

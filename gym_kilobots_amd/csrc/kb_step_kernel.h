@@ -316,7 +316,9 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
             mcTouch = false;
             if (lane < NMC) {
                 owsMine = g.ows_acc + (size_t)e * (MAXOBJ * KB_OWS_COLS * KB_OWS_WORDS);
-                mcTouch = mc_detect(ox, p, M, lane, owsMine);
+                Arena ar;
+                ar.xmin = p.xmin; ar.ymin = p.ymin; ar.xmax = p.xmax; ar.ymax = p.ymax;
+                mcTouch = mc_detect(ox, ar, M, lane, owsMine);
             }
         }
 
