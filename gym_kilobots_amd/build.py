@@ -69,5 +69,24 @@ def build_profile(verbose=False):
     return _build(PROF_LIB, ['-DKB_PROFILE'], 'prof', verbose)
 
 
+def build_variant(name, defines, only=None, verbose=False):
+    """Experiment build: libkilobots_hip_<name>.so with extra -D flags (select it with KB_HIP_LIB=...).
+    only: restrict the drive-law units that are compiled (e.g. ['d0']) to save time; the others come from the release build."""
+    lib = os.path.join(HERE, 'libkilobots_hip_%s.so' % name)
+    objdir = os.path.join(HERE, '_obj', name)
+    os.makedirs(objdir, exist_ok=True)
+    jobs, reuse = [], []
+    for s in sources():
+        base = os.path.basename(s)[:-4]
+        if only is not None and base != 'kb_abi' and not any(base.endswith(o) for o in only):
+            reuse.append(os.path.join(HERE, '_obj', 'rel', base + '.o'))
+            continue
+        jobs.append((s, os.path.join(objdir, base + '.o'), list(defines), verbose))
+    with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
+        objs = list(ex.map(_compile, jobs))
+    subprocess.check_call([os.environ.get('HIPCC', 'hipcc'), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + objs + reuse)
+    return lib
+
+
 if __name__ == '__main__':
     print(build(force='--force' in sys.argv, verbose=True))

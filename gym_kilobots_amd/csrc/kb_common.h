@@ -59,6 +59,7 @@ constexpr int MAX_BUCKETS = MAX_WAVES * BK_PER_WAVE;
 constexpr int BPT = KB_BPT;                // bots per thread (max): N <= BPT * blockDim.x
 constexpr int KB_LIGHT_GENERAL = 99;   // kernel template value: any light model other than NONE / single CIRCULAR
 constexpr int GIANT_ISLAND = 256;     // contacts; larger islands are swept by the whole workgroup
+constexpr int BIG_ISLAND = 16;        // contacts; islands from this size on are placed on waves one by one when the hash placement overloads a wave
 constexpr int KREG = KB_KREG;               // contacts a lane can keep in registers (register-resident solver)
 constexpr int CAP_LDS = 1024;         // contacts staged in LDS; denser envs stage in the global scratch slice
 
@@ -98,7 +99,8 @@ __host__ __device__ inline int con16(int NB, int capL, int k) { return con32(NB,
 __host__ __device__ inline int bot16(int NB, int capL, int NP, int k) { return con16(NB, capL, CON16_COUNT) + 2 * NP * k; }
 __host__ __device__ inline int bot8(int NB, int capL, int NP, int k) { return bot16(NB, capL, NP, BOT16_COUNT) + NP * k; }
 __host__ __device__ inline int active(int NB, int capL, int NP) { return bot8(NB, capL, NP, BOT8_COUNT); }
-__host__ __device__ inline int head(int NB, int capL, int NP) { return (active(NB, capL, NP) + 2 * NB + 15) & ~15; }
+__host__ __device__ inline int islwave(int NB, int capL, int NP) { return active(NB, capL, NP) + 2 * NB; }   // u8 per body: wave that sweeps its island
+__host__ __device__ inline int head(int NB, int capL, int NP) { return (islwave(NB, capL, NP) + NB + 15) & ~15; }
 __host__ __device__ inline int mcarea(int NB, int capL, int NP, int ncell) { return (head(NB, capL, NP) + 2 * ncell + 4 + 15) & ~15; }
 // manifold-constraint records (objects only): MC_FIELDS words x nmc candidates, field-major
 __host__ __device__ inline int total(int NB, int capL, int NP, int ncell, int nmc) { return (mcarea(NB, capL, NP, ncell) + 4 * MC_FIELDS_C * nmc + 15) & ~15; }

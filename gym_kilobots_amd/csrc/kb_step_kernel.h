@@ -32,6 +32,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
     unsigned short *nextb = (unsigned short *)(smem + lds::bot16(NB, capL_, NP, 2)), *cellOf = (unsigned short *)(smem + lds::bot16(NB, capL_, NP, 3));
     unsigned char *wsCnt = smem + lds::bot8(NB, capL_, NP, 0), *wsCntNew = smem + lds::bot8(NB, capL_, NP, 1);
     unsigned char *active = smem + lds::active(NB, capL_, NP);
+    unsigned char *islWave = smem + lds::islwave(NB, capL_, NP);   // wave that sweeps the island rooted at body b
     unsigned short *head = (unsigned short *)(smem + lds::head(NB, capL_, NP));   // per-cell list heads (EMPTY16 = empty)
     unsigned *misc = (unsigned *)(smem + lds::MISC), *wsum = (unsigned *)(smem + lds::WSUM);
     unsigned *bkStart = (unsigned *)(smem + lds::BKSTART), *bkFill = (unsigned *)(smem + lds::BKFILL);
@@ -404,10 +405,12 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
             find_pass(lPair, lInfo, p.capL);
             __syncthreads();
             big = (int)misc[M_NCON] > p.capL;    // does not fit the LDS staging area: redo into the global scratch slice
-            __syncthreads();
-            if (big && tid == 0) misc[M_NCON] = 0;
-            if (big && tid < M) objCnt[tid] = 0;
-            if (big) __syncthreads();
+            if (big) {
+                __syncthreads();
+                if (tid == 0) misc[M_NCON] = 0;
+                if (tid < M) objCnt[tid] = 0;
+                __syncthreads();
+            }
         }
         if (big) {
             find_pass(gPair, gInfo, p.cap);
@@ -554,6 +557,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
             while (true) { unsigned t = ((volatile unsigned *)parent)[r]; if (t == r) break; r = t; }
             parent[b] = r;   // only ever replaces an ancestor by an older ancestor: concurrent walks stay valid
             islCnt[b] = 0;
+            islWave[b] = (unsigned char)((unsigned)b % (unsigned)nw);
             head[cellOf[b]] = EMPTY16;
             active[b] = 1; active[NB + b] = 0;
         }
@@ -563,20 +567,15 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
             while (true) { unsigned t = ((volatile unsigned *)parent)[r]; if (t == r) break; r = t; }
             parent[b] = r;
             islCnt[b] = 0;
+            islWave[b] = (unsigned char)((unsigned)b % (unsigned)nw);
             active[b] = 1; active[NB + b] = 0;
         }
         const unsigned newTotal = block_scan_u8(wsCntNew, newOff, NP, wsum);   // (barriers inside)
         const bool newInLds = newTotal <= (unsigned)p.capL;
-        if (OBJ && wave == 0) {   // island of every manifold constraint; which wave sweeps it (slot nw: all of them)
+        if (OBJ && wave == 0) {   // island of every manifold constraint
             unsigned root = 0;
             const bool on = lane < NMC && mcTouch;
             if (on) { root = parent[mci(ox, MC_B, lane)]; mci_set(ox, MC_ISL, lane, (int)root); }
-            for (int w = 0; w < nw; ++w) {
-                const unsigned long long mk = __ballot(on && (int)(root % (unsigned)nw) == w);
-                if (lane == 0) mcMask[w] = mk;
-            }
-            const unsigned long long all = __ballot(on);
-            if (lane == 0) mcMask[nw] = all;
         }
         KB_STAMP(14);    // flatten roots + warm-start offset scan
         // per contact: island size (giant islands force the cooperative sweep) and contacts per wave
@@ -585,7 +584,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                 const unsigned root = parent[sPair[c] >> 16];
                 const unsigned n = atomicAdd(&islCnt[root], 1u) + 1u;
                 if (n > (unsigned)GIANT_ISLAND) atomicMax(&misc[M_MAXISL], n);
-                atomicAdd(&misc[M_WCNT + (root % (unsigned)nw)], 1u);
+                atomicAdd(&misc[M_WCNT + islWave[root]], 1u);
             }
         };
         if (big) census(gPair); else census(lPair);
@@ -597,7 +596,64 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
         //   reg : every wave can hold its contacts in registers (<= KREG per lane) -> no contact arrays in the sweeps
         //   list: per-wave sweeps over the staged contact arrays
         const bool coop = misc[M_MAXISL] > (unsigned)GIANT_ISLAND || nw == 1 || p.solver_mode == 2 || p.solver_mode == 4;
-        const bool reg = !coop && !big && maxw <= 64u * KREG && p.solver_mode == 0 && !(OBJ && misc[M_POLY] != 0u);
+        bool reg = !coop && !big && maxw <= 64u * KREG && p.solver_mode == 0 && !(OBJ && misc[M_POLY] != 0u);
+        if (!coop && !big && maxw > 64u * KREG && p.solver_mode == 0 && !(OBJ && misc[M_POLY] != 0u)) {
+            // The default placement (root id mod #waves) overloads a wave.  Place the islands of BIG_ISLAND contacts or
+            // more one by one, largest first, each on the wave with the least load (ties: lowest root / lowest wave);
+            // the small ones stay where they are.  Results do not depend on the placement, only the time does.
+            unsigned short *bigList = bkList;           // (idle until the bucket sort)
+            __syncthreads();
+            if (tid < nw) misc[M_WCNT + tid] = 0;
+            if (tid == 0) misc[M_TOTAL] = 0;
+            __syncthreads();
+            for (int b = tid; b < N + M; b += nt) {
+                if (parent[b] != (unsigned)b) continue;
+                const unsigned cnt_ = islCnt[b];
+                if (cnt_ == 0) continue;
+                unsigned slot_ = 64u;
+                if (cnt_ >= (unsigned)BIG_ISLAND) slot_ = atomicAdd(&misc[M_TOTAL], 1u);
+                if (slot_ < 64u) bigList[slot_] = (unsigned short)b;
+                else atomicAdd(&misc[M_WCNT + islWave[b]], cnt_);
+            }
+            __syncthreads();
+            if (wave == 0) {
+                const int nb = (int)min(misc[M_TOTAL], 64u);
+                const unsigned root = lane < nb ? (unsigned)bigList[lane] : 0u;
+                const unsigned size = lane < nb ? islCnt[root] : 0u;
+                int rank = 0;
+                for (int j = 0; j < nb; ++j) {
+                    const unsigned sj = __shfl(size, j), rj = __shfl(root, j);
+                    if (sj > size || (sj == size && rj < root)) rank++;
+                }
+                unsigned load = lane < nw ? misc[M_WCNT + lane] : 0u;
+                int myWave = 0;
+                for (int r = 0; r < nb; ++r) {
+                    const int src = __builtin_ctzll(__ballot(lane < nb && rank == r));
+                    const unsigned sz = __shfl(size, src);
+                    unsigned key = lane < nw ? ((load << 4) | (unsigned)lane) : 0xFFFFFFFFu;
+                    for (int d = 8; d >= 1; d >>= 1) key = min(key, __shfl_xor(key, d));
+                    const int wmin = (int)(__shfl(key, 0) & 15u);
+                    if (lane == wmin) load += sz;
+                    if (lane == src) myWave = wmin;
+                }
+                if (lane < nb) islWave[root] = (unsigned char)myWave;
+                if (lane < nw) misc[M_WCNT + lane] = load;
+            }
+            __syncthreads();
+            maxw = 0;
+            for (int w = 0; w < nw; ++w) maxw = max(maxw, misc[M_WCNT + w]);
+            reg = maxw <= 64u * KREG;
+        }
+        if (OBJ && wave == 0) {   // which wave sweeps which manifold constraint (slot nw: all of them)
+            const bool on = lane < NMC && mcTouch;
+            const unsigned w_ = on ? (unsigned)islWave[mci(ox, MC_ISL, lane)] : 0u;
+            for (int w = 0; w < nw; ++w) {
+                const unsigned long long mk = __ballot(on && (int)w_ == w);
+                if (lane == 0) mcMask[w] = mk;
+            }
+            const unsigned long long all = __ballot(on);
+            if (lane == 0) mcMask[nw] = all;
+        }
         // manifold constraints of one (virtual) wave, swept by its leader thread after the regular contacts of a sweep
         auto mc_warm_pass = [&](unsigned long long mask, bool leader) __attribute__((always_inline)) {
             if (leader) for (unsigned long long m_ = mask; m_; m_ &= m_ - 1) mc_warm_start(ox, __builtin_ctzll(m_));
@@ -648,7 +704,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
             __syncthreads();
             for (int c = tid; c < ncon; c += nt) {
                 const unsigned root = parent[sPair[c] >> 16];
-                const int w = coop ? 0 : (int)(root % (unsigned)nw);
+                const int w = coop ? 0 : (int)islWave[root];
                 const unsigned inf = sInfo[c];
                 const int cls = inf & 0x7F, r = (inf >> 8) & 0xFF;
                 const int bk = (w * NUM_CLS + cls) * RK + (r < RK - 1 ? r : RK - 1);
@@ -691,7 +747,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
             for (int b = tid; b < N + M; b += nt) islCnt[b] = 0;   // reused as per-body dependency depth
             if (tid < nw * NUM_CLS) bkMaxRank[tid] = 0;
             for (int c = tid; c < ncon; c += nt) {
-                const unsigned w = parent[lPair[c] >> 16] % (unsigned)nw;
+                const unsigned w = islWave[parent[lPair[c] >> 16]];
                 unsigned base = 0;
                 for (unsigned w2 = 0; w2 < w; ++w2) base += misc[M_WCNT + w2];
                 lOrder[base + atomicAdd(&misc[M_WFILL + w], 1u)] = (unsigned short)c;
@@ -703,7 +759,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
 
         if (reg) {
             // =========================== register-resident solver ===========================
-            // wave w owns the contacts of the islands with root % nw == w; lane l holds contacts l, l+64, ...
+            // wave w owns the contacts of the islands placed on it (islWave); lane l holds contacts l, l+64, ...
             unsigned mybase = 0;
             for (int w = 0; w < wave; ++w) mybase += misc[M_WCNT + w];
             const unsigned mycnt = misc[M_WCNT + wave];

@@ -27,16 +27,29 @@ def main():
     ap.add_argument('--warm', type=int, default=60)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--fused', type=int, default=1)
+    ap.add_argument('--objects', type=int, default=0, help='cfg4: pushable objects per env')
+    ap.add_argument('--boxes', action='store_true')
     args = ap.parse_args()
     E, N = args.envs, args.bots
     assert 'prof' in os.environ.get('KB_HIP_LIB', ''), 'run with KB_HIP_LIB=.../libkilobots_hip_prof.so'
-    sim = KilobotSim(E, N)
+    okw = {}
+    if args.objects and args.boxes:
+        okw = dict(obj_shape=[1] * args.objects, obj_nverts=[4] * args.objects, obj_verts=[[[0.075 * 25.0, 0.075 * 25.0]]] * args.objects)
+    sim = KilobotSim(E, N, num_objects=args.objects, **okw)
     sim.status = torch.zeros(E + 16 * E, dtype=torch.int32, device=sim.device)   # status + stamp area
     sim._bind()
     xy1, th1 = scenes.lattice_spawn(8, N, seed=1000)
     reps = (E + 7) // 8
     sim.set_poses_m(np.tile(xy1, (reps, 1, 1))[:E], np.tile(th1, (reps, 1))[:E])
-    acts = [torch.from_numpy(np.tile(scenes.random_actions(8, N, seed=2000 + k), (reps, 1, 1))[:E].copy()).cuda() for k in range(8)]
+    if args.objects:
+        sim.set_objects_m(np.tile(scenes.CFG4_OBJECTS[None, :args.objects], (E, 1, 1)))
+    acts = []
+    for k in range(8):
+        a1 = scenes.random_actions(8, N, seed=2000 + k)
+        if args.objects:
+            a1[:, ::2, 0] = 0.01
+            a1[:, ::2, 1] = 0.0
+        acts.append(torch.from_numpy(np.tile(a1, (reps, 1, 1))[:E].copy()).cuda())
     for k in range(args.warm):
         sim.step(1, actions=acts[k % 8])
     torch.cuda.synchronize()
