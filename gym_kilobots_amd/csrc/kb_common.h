@@ -63,7 +63,7 @@ constexpr int BIG_ISLAND = 16;        // contacts; islands from this size on are
 constexpr int KREG = KB_KREG;               // contacts a lane can keep in registers (register-resident solver)
 constexpr int CAP_LDS = 1024;         // contacts staged in LDS; denser envs stage in the global scratch slice
 
-enum { M_NCON = 0, M_TOTAL = 1, M_ANY = 2, M_STATUS = 3, M_MAXISL = 4, M_PROF = 5, M_POLY = 6, M_WCNT = 8, M_WFILL = 8 + MAX_WAVES, M_COUNT = 8 + 2 * MAX_WAVES };
+enum { M_NCON = 0, M_TOTAL = 1, M_ANY = 2, M_STATUS = 3, M_MAXISL = 4, M_PROF = 5, M_WCNT = 8, M_WFILL = 8 + MAX_WAVES, M_COUNT = 8 + 2 * MAX_WAVES };
 static_assert(M_COUNT <= 64, "misc area");
 
 // ---- LDS layout ----------------------------------------------------------------------------------

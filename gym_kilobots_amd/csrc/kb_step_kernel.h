@@ -385,7 +385,6 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                     if (T[OT_KIND] != 0.0f) {
                         V2 ln, lp;
                         if (!collide_poly_circle(T, xf_make(pos[N + m].x, pos[N + m].y, objA[m]), mk2(ax, ay), p.r_bot, ln, lp)) continue;
-                        misc[M_POLY] = 1u;
                     }
                     mine++;
                     const unsigned pos = atomicAdd(&objCnt[m], 1u);
@@ -596,8 +595,8 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
         //   reg : every wave can hold its contacts in registers (<= KREG per lane) -> no contact arrays in the sweeps
         //   list: per-wave sweeps over the staged contact arrays
         const bool coop = misc[M_MAXISL] > (unsigned)GIANT_ISLAND || nw == 1 || p.solver_mode == 2 || p.solver_mode == 4;
-        bool reg = !coop && !big && maxw <= 64u * KREG && p.solver_mode == 0 && !(OBJ && misc[M_POLY] != 0u);
-        if (!coop && !big && maxw > 64u * KREG && p.solver_mode == 0 && !(OBJ && misc[M_POLY] != 0u)) {
+        bool reg = !coop && !big && maxw <= 64u * KREG && p.solver_mode == 0;
+        if (!coop && !big && maxw > 64u * KREG && p.solver_mode == 0) {
             // The default placement (root id mod #waves) overloads a wave.  Place the islands of BIG_ISLAND contacts or
             // more one by one, largest first, each on the wave with the least load (ties: lowest root / lowest wave);
             // the small ones stay where they are.  Results do not depend on the placement, only the time does.
@@ -766,6 +765,9 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
             int ra[KREG], rb[KREG], rkey[KREG], rrank[KREG], rslot[KREG], risl[KREG], rc[KREG], rdepth[KREG];
             float racc[KREG], rnx[KREG], rny[KREG], rima[KREG], rimb[KREG], rra[KREG], rrb[KREG], rnm[KREG];
             bool rvalid[KREG], rflip[KREG];
+            // kilobot - polygon contacts (objects only): lever arm on the polygon, manifold in the polygon's frame
+            bool rpoly[KREG];
+            float rrAx[KREG], rrAy[KREG], rlnx[KREG], rlny[KREG], rlpx[KREG], rlpy[KREG];
             unsigned mlo = 0, mhi = 0;
             // without objects the masses / radii of a contact follow from "is A a wall": no registers needed
             const float kbb_ = p.im_bot + p.im_bot, kwb_ = 0.0f + p.im_bot;
@@ -843,6 +845,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                 ra[j] = 0; rb[j] = 0; rslot[j] = 255; risl[j] = 0;
                 racc[j] = 0.0f; rnx[j] = 1.0f; rny[j] = 0.0f; rflip[j] = false;
                 rima[j] = 0.0f; rimb[j] = 0.0f; rra[j] = 0.0f; rrb[j] = 0.0f; rnm[j] = 0.0f;
+                rpoly[j] = false; rrAx[j] = 0.0f; rrAy[j] = 0.0f; rlnx[j] = 0.0f; rlny[j] = 0.0f; rlpx[j] = 0.0f; rlpy[j] = 0.0f;
                 if (rvalid[j]) {
                     const int c = rc[j];
                     const unsigned pr = lPair[c], inf = lInfo[c];
@@ -856,7 +859,26 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                         rnm[j] = k_ > 0.0f ? 1.0f / k_ : 0.0f;   // b2ContactSolver normalMass
                     }
                     // velocity-phase normal from the start-of-step positions (b2WorldManifold::Initialize)
-                    if (a >= WALL_CODE) {
+                    if (bpoly(b)) {
+                        // Box2D's A = the polygon b, B = the kilobot a: manifold, normal polygon -> kilobot, lever arm, normalMass
+                        const int m = b - N;
+                        const float *T = objTab + m * OT_WORDS;
+                        const XF xo = xf_make(pos[b].x, pos[b].y, objA[m]);
+                        const V2 bc = mk2(pos[a].x, pos[a].y);
+                        V2 ln = mk2(0.0f, 0.0f), lp = mk2(0.0f, 0.0f);
+                        collide_poly_circle(T, xo, bc, p.r_bot, ln, lp);
+                        const V2 normal = rot_mul(xo, ln);
+                        const V2 planePoint = xf_mul(xo, lp);
+                        const V2 cA = v_add(bc, v_scale(T[OT_RADIUS] - v_dot(v_sub(bc, planePoint), normal), normal));
+                        const V2 cB = v_sub(bc, v_scale(p.r_bot, normal));
+                        const V2 point = v_scale(0.5f, v_add(cA, cB));
+                        const V2 rA = v_sub(point, mk2(pos[b].x, pos[b].y));
+                        const float rnA = v_cross(rA, normal);
+                        const float kNormal = T[OT_IM] + p.im_bot + T[OT_II] * rnA * rnA;
+                        rpoly[j] = true; rnx[j] = normal.x; rny[j] = normal.y; rrAx[j] = rA.x; rrAy[j] = rA.y;
+                        rlnx[j] = ln.x; rlny[j] = ln.y; rlpx[j] = lp.x; rlpy[j] = lp.y;
+                        rnm[j] = kNormal > 0.0f ? 1.0f / kNormal : 0.0f;
+                    } else if (a >= WALL_CODE) {
                         float dist, nx, ny;
                         wall_geom(p, a - WALL_CODE, pos[b].x, pos[b].y, dist, nx, ny);
                         if (rflip[j]) { nx = -nx; ny = -ny; }
@@ -895,8 +917,15 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
             KB_REG_ROUNDS({
                 const int a = ra[j], b = rb[j];
                 const float Px = racc[j] * rnx[j], Py = racc[j] * rny[j];
-                if (a < WALL_CODE) { vel[a].x -= R_IMA(j) * Px; vel[a].y -= R_IMA(j) * Py; }
-                vel[b].x += R_IMB(j) * Px; vel[b].y += R_IMB(j) * Py;
+                if (OBJ && rpoly[j]) {   // A = polygon b, B = kilobot a
+                    const int m = b - N;
+                    objW[m] -= objTab[m * OT_WORDS + OT_II] * (rrAx[j] * Py - rrAy[j] * Px);
+                    vel[b].x -= R_IMB(j) * Px; vel[b].y -= R_IMB(j) * Py;
+                    vel[a].x += R_IMA(j) * Px; vel[a].y += R_IMA(j) * Py;
+                } else {
+                    if (a < WALL_CODE) { vel[a].x -= R_IMA(j) * Px; vel[a].y -= R_IMA(j) * Py; }
+                    vel[b].x += R_IMB(j) * Px; vel[b].y += R_IMB(j) * Py;
+                }
             })
             if (OBJ && myMc) { mc_warm_pass(myMc, lane == 0); wave_sync(); }
             // SolveVelocityConstraints: friction 0, restitution 0, one manifold point.
@@ -915,13 +944,13 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                     float vax[KREG], vay[KREG], vbx[KREG], vby[KREG];
 #pragma unroll
                     for (int j = 0; j < KREG; ++j) {
-                        const bool on = rdepth[j] == d_;
+                        const bool on = rdepth[j] == d_ && !(OBJ && rpoly[j]);
                         ia[j] = on ? iaS[j] : DUMMY; ib[j] = on ? ibS[j] : DUMMY;
                         vax[j] = vel[ia[j]].x; vay[j] = vel[ia[j]].y; vbx[j] = vel[ib[j]].x; vby[j] = vel[ib[j]].y;
                     }
 #pragma unroll
                     for (int j = 0; j < KREG; ++j) {
-                        const bool on = rdepth[j] == d_;
+                        const bool on = rdepth[j] == d_ && !(OBJ && rpoly[j]);
                         const bool wallA = ra[j] >= WALL_CODE;
                         const float nx = rnx[j], ny = rny[j];
                         const float ima = R_IMA(j), imb = R_IMB(j);
@@ -936,6 +965,25 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                         const float Px = lambda * nx, Py = lambda * ny;
                         vel[ia[j]].x = ax_ - ima * Px; vel[ia[j]].y = ay_ - ima * Py;
                         vel[ib[j]].x = vbx[j] + imb * Px; vel[ib[j]].y = vby[j] + imb * Py;
+                    }
+                    if (OBJ) {   // kilobot - polygon contacts of this depth level: one point, friction sqrt(0 * f) = 0
+#pragma unroll
+                        for (int j = 0; j < KREG; ++j) {
+                            if (!(rpoly[j] && rdepth[j] == d_)) continue;
+                            const int a = ra[j], b = rb[j], m = b - N;
+                            const float wA = objW[m];
+                            const float dvx = (vel[a].x - vel[b].x) - (-wA * rrAy[j]), dvy = (vel[a].y - vel[b].y) - (wA * rrAx[j]);
+                            const float vn = dvx * rnx[j] + dvy * rny[j];
+                            float lambda = -(rnm[j] * vn);
+                            const float accOld = racc[j];
+                            const float newimp = fmaxf(accOld + lambda, 0.0f);
+                            lambda = newimp - accOld;
+                            racc[j] = newimp;
+                            const float Px = lambda * rnx[j], Py = lambda * rny[j];
+                            vel[b].x -= rimb[j] * Px; vel[b].y -= rimb[j] * Py;
+                            objW[m] = wA - objTab[m * OT_WORDS + OT_II] * (rrAx[j] * Py - rrAy[j] * Px);
+                            vel[a].x += rima[j] * Px; vel[a].y += rima[j] * Py;
+                        }
                     }
                     wave_sync();
                 }
@@ -1007,7 +1055,27 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                 KB_REG_ROUNDS({
                     const int a = ra[j], b = rb[j];
                     const int isl = risl[j];
-                    if (act[isl]) {
+                    if (OBJ && rpoly[j]) {
+                        if (act[isl]) {   // b2PositionSolverManifold e_faceA, A = polygon b, B = kilobot a
+                            const int m = b - N;
+                            const float *T = objTab + m * OT_WORDS;
+                            const XF xo = xf_make(pos[b].x, pos[b].y, objA[m]);
+                            const V2 normal = rot_mul(xo, mk2(rlnx[j], rlny[j]));
+                            const V2 planePoint = xf_mul(xo, mk2(rlpx[j], rlpy[j]));
+                            const V2 clipPoint = mk2(pos[a].x, pos[a].y);
+                            const float sep = v_dot(v_sub(clipPoint, planePoint), normal) - T[OT_RADIUS] - p.r_bot;
+                            const V2 rA = v_sub(clipPoint, mk2(pos[b].x, pos[b].y));
+                            if (sep < -3.0f * B2_LINEAR_SLOP) { nxt[isl] = 1; viol = true; }
+                            const float C = kb_clampf(B2_BAUMGARTE * (sep + B2_LINEAR_SLOP), -B2_MAX_LINEAR_CORRECTION, 0.0f);
+                            const float rnA = v_cross(rA, normal);
+                            const float K = T[OT_IM] + p.im_bot + T[OT_II] * rnA * rnA;
+                            const float imp = K > 0.0f ? -C / K : 0.0f;
+                            const V2 P = v_scale(imp, normal);
+                            pos[b].x -= T[OT_IM] * P.x; pos[b].y -= T[OT_IM] * P.y;
+                            objA[m] -= T[OT_II] * v_cross(rA, P);
+                            pos[a].x += p.im_bot * P.x; pos[a].y += p.im_bot * P.y;
+                        }
+                    } else if (act[isl]) {
                         float nx, ny, sep;
                         const float ima = R_IMA(j), imb = R_IMB(j);
                         const float bx = pos[b].x, by = pos[b].y;
