@@ -1048,15 +1048,25 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
             }
             __syncthreads();
             KB_STAMP(5);
-            // SolvePositionConstraints; an island stops once its minSeparation >= -3 slop
+            // SolvePositionConstraints; an island stops once its minSeparation >= -3 slop.  The island flags are read
+            // once per iteration; depth levels without an active contact in this wave are skipped altogether.
             for (int it = 0; it < p.pos_iters; ++it) {
                 unsigned char *act = active + (it & 1) * NB, *nxt = active + ((it + 1) & 1) * NB;
                 bool viol = false;
-                KB_REG_ROUNDS({
-                    const int a = ra[j], b = rb[j];
-                    const int isl = risl[j];
-                    if (OBJ && rpoly[j]) {
-                        if (act[isl]) {   // b2PositionSolverManifold e_faceA, A = polygon b, B = kilobot a
+                bool ron[KREG];
+#pragma unroll
+                for (int j = 0; j < KREG; ++j) ron[j] = rvalid[j] && act[risl[j]] != 0;
+                for (int d_ = 1; d_ <= maxD; ++d_) {
+                    bool anyOn = false;
+#pragma unroll
+                    for (int j = 0; j < KREG; ++j) anyOn |= ron[j] && rdepth[j] == d_;
+                    if (!__any(anyOn)) continue;
+#pragma unroll
+                    for (int j = 0; j < KREG; ++j) {
+                        if (!(ron[j] && rdepth[j] == d_)) continue;
+                        const int a = ra[j], b = rb[j];
+                        const int isl = risl[j];
+                        if (OBJ && rpoly[j]) {   // b2PositionSolverManifold e_faceA, A = polygon b, B = kilobot a
                             const int m = b - N;
                             const float *T = objTab + m * OT_WORDS;
                             const XF xo = xf_make(pos[b].x, pos[b].y, objA[m]);
@@ -1074,8 +1084,8 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                             pos[b].x -= T[OT_IM] * P.x; pos[b].y -= T[OT_IM] * P.y;
                             objA[m] -= T[OT_II] * v_cross(rA, P);
                             pos[a].x += p.im_bot * P.x; pos[a].y += p.im_bot * P.y;
+                            continue;
                         }
-                    } else if (act[isl]) {
                         float nx, ny, sep;
                         const float ima = R_IMA(j), imb = R_IMB(j);
                         const float bx = pos[b].x, by = pos[b].y;
@@ -1102,7 +1112,8 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                         if (a < WALL_CODE) { pos[a].x = axx - ima * Px; pos[a].y = ayy - ima * Py; }
                         pos[b].x = bx + imb * Px; pos[b].y = by + imb * Py;
                     }
-                })
+                    wave_sync();
+                }
                 if (OBJ && myMc) { viol |= mc_position_pass(myMc, lane == 0, act, nxt); wave_sync(); }
 #ifdef KB_PROFILE
                 if (tid == 0) prof_acc[10] += 1;
