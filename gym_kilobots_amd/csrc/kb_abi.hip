@@ -74,7 +74,7 @@ struct kb_sim {
     kb_config cfg;
     Params p;
     bool bound;
-    bool attr_set;
+    const void *attr_fn;   // kernel whose dynamic-LDS limit has been raised
     int threads;
 };
 
@@ -128,7 +128,7 @@ int kb_create(const kb_config *cfg, kb_sim **out) {
     if (!s) return fail(KB_EINVAL, "kb_create: out of host memory");
     s->cfg = *cfg;
     s->bound = false;
-    s->attr_set = false;
+    s->attr_fn = nullptr;
     Params &p = s->p;
     memset(&p, 0, sizeof(p));
     p.N = cfg->num_bots; p.E = cfg->num_envs; p.S = cfg->ws_slots;
@@ -309,7 +309,14 @@ int kb_step(kb_sim *sim, const float *d_actions, const float *d_light_action, in
     const bool obj = p.M > 0;
     kb_step_fn fn = nullptr;
     switch (p.drive_mode) {
-    case KB_DRIVE_VELOCITY: fn = kb_pick_velocity(p.light_type, obj); break;
+    case KB_DRIVE_VELOCITY: {
+        // the flagship size has its own instantiation with a compile-time LDS layout
+        const long cap1024 = 4L * 1024 + 64;
+        const bool fixed = p.N == 1024 && !obj && p.light_type == KB_LIGHT_NONE && sim->threads == 64 * MAX_WAVES &&
+                           p.NP == 1024 && p.NB == 1024 + KB_MAX_OBJECTS + 4 && p.capL == CAP_LDS && p.cap == (int)((cap1024 + 7) & ~7L) &&
+                           BPT * 64 * MAX_WAVES == 1024;
+        fn = kb_pick_velocity(fixed ? KB_PICK_FIXED_1024 : p.light_type, obj);
+    } break;
     case KB_DRIVE_ACCEL: fn = kb_pick_accel(p.light_type, obj); break;
     case KB_DRIVE_MOTORS: fn = kb_pick_motors(p.light_type, obj); break;
     case KB_DRIVE_SIMPLE_PHOTOTAXIS: fn = kb_pick_simple_phototaxis(p.light_type, obj); break;
@@ -317,11 +324,11 @@ int kb_step(kb_sim *sim, const float *d_actions, const float *d_light_action, in
     default: break;
     }
     if (!fn) return fail(KB_EINVAL, "kb_step: no kernel for this drive mode / light type");
-    if (p.lds_total > 64 * 1024 && !sim->attr_set) {
+    if (p.lds_total > 64 * 1024 && sim->attr_fn != reinterpret_cast<const void *>(fn)) {
         hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, p.lds_total);
         if (e2 != hipSuccess) return fail(KB_EHIP, "kb_step: hipFuncSetAttribute: %s", hipGetErrorString(e2));
-        sim->attr_set = true;
+        sim->attr_fn = reinterpret_cast<const void *>(fn);
     }
     hipLaunchKernelGGL(fn, dim3((unsigned)p.E), dim3((unsigned)sim->threads), (size_t)p.lds_total,
                        (hipStream_t)stream, p);

@@ -211,8 +211,11 @@ __device__ __forceinline__ void wall_geom(const Params &p, int wl, float x, floa
 #ifdef KB_PROFILE
 // diagnostic build: thread 0 accumulates shader cycles per phase into g.status[E + 8*e + phase]
 #define KB_STAMP(ph) do { if (tid == 0) { long long t_ = clock64(); prof_acc[ph] += t_ - prof_t; prof_t = t_; } } while (0)
+// time since the last stamp without closing the interval: wave 0's own work before it waits at the barrier
+#define KB_STAMP_PRE(ph) do { if (tid == 0) { prof_acc[ph] += clock64() - prof_t; } } while (0)
 #else
 #define KB_STAMP(ph) do { } while (0)
+#define KB_STAMP_PRE(ph) do { } while (0)
 #endif
 
 // b2TimeOfImpact for a circle (radius R) whose centre moves linearly from (x0,y0) to (x1,y1) against wall wl:
@@ -385,6 +388,7 @@ __device__ __forceinline__ unsigned block_scan_u8(const unsigned char *cnt, unsi
 
 
 typedef void (*kb_step_fn)(const Params);
+constexpr int KB_PICK_FIXED_1024 = -1024;   // kb_pick_velocity: the num_bots == 1024 specialisation (no light, no objects)
 // one translation unit per drive law (kb_inst_d*.hip) instantiates its kernels and hands out the right one
 kb_step_fn kb_pick_velocity(int light_type, bool objects);
 kb_step_fn kb_pick_accel(int light_type, bool objects);

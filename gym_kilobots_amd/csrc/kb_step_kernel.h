@@ -6,18 +6,23 @@
 namespace kb {
 
 // One instantiation per (drive law, light model): keeps only that law's code (and registers) in the kernel.
-template <int DRIVE_MODE, int LIGHT_TYPE, bool OBJ>
+// FN > 0: specialisation for num_bots == FN without objects and the full workgroup (64 * KB_MAX_WAVES threads): every
+// LDS offset, array size and trip count is a compile-time constant instead of a value kept in scalar registers.
+template <int DRIVE_MODE, int LIGHT_TYPE, bool OBJ, int FN = 0>
 __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_step_kernel(const Params p) {
     extern __shared__ __align__(16) unsigned char smem[];
     int e = blockIdx.x;
-    const int tid = threadIdx.x, nt = blockDim.x;
-    const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
-    const int N = p.N, NP = p.NP, S = p.S;
+    int tid = threadIdx.x;
+    const int nt = FN ? 64 * KB_MAX_WAVES : (int)blockDim.x;
+    int lane = tid & 63, wave = tid >> 6;
+    const int nw = nt >> 6;
+    const int N = FN ? FN : p.N, NP = FN ? ((FN + 3) & ~3) : p.NP, S = p.S;
     size_t o = (size_t)e * N;
     size_t wo = (size_t)e * p.cap;       // this env's slice of the packed warm-start / scratch arrays
     const float h = p.h;
 
-    const int NB = p.NB, capL_ = p.capL;
+    const int NB = FN ? ((FN + 3) & ~3) + KB_MAX_OBJECTS + 4 : p.NB;
+    const int capL_ = FN ? (4 * FN + 64 < CAP_LDS ? 4 * FN + 64 : CAP_LDS) : p.capL;   // (FN >= 32: cap = 4 FN + 64, see kb_create)
     // LDS arrays (offsets: namespace lds in kb_common.h)
     // positions, velocities and start-of-substep positions as (x, y) pairs: one 8-byte LDS access per body
     float2 *pos = (float2 *)(smem + lds::body32(NB, 0)), *vel = (float2 *)(smem + lds::body32(NB, 2));
@@ -83,7 +88,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
     KB_ENV_ADDRESSES();
 
 #ifdef KB_PROFILE
-    long long prof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long prof_acc[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     constexpr int M_PROF_DEPTH = 12;
     long long prof_t = clock64();
 #endif
@@ -170,7 +175,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
     __syncthreads();
     // warm-start list of the previous substep: offsets, and an LDS image of the packed entries if it fits
     unsigned oldTotal = block_scan_u8(wsCnt, wsOff, NP, wsum);
-    bool oldInLds = oldTotal <= (unsigned)p.capL;
+    bool oldInLds = oldTotal <= (unsigned)capL_;
     if (oldInLds) {
         for (unsigned i = tid; i < oldTotal; i += nt) {
             const unsigned k = g.ws_key[wo + i];
@@ -183,6 +188,12 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
     KB_STAMP(13);    // kernel start: state loads, warm-start scan and list load
     for (int sub = 0; sub < p.n_substeps; ++sub) {
         KB_ENV_ADDRESSES();
+        {   // the thread index is re-read every substep: predicates derived from it are then evaluated where they are
+            // used (one compare) instead of being hoisted out of the substep loop and kept in spilled scalar registers
+            int t_ = threadIdx.x;
+            asm volatile("" : "+v"(t_));
+            tid = t_; lane = t_ & 63; wave = t_ >> 6;
+        }
         // ---- light.step: SinglePositionLight.step, light.py:59-75 (uniform per env) ----
         if (p.light_action && LGEN && drive) {
             // Light.step of every component: light.py:59-75 (positional), 300-316 (momentum), 237-253 (gradient)
@@ -309,6 +320,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
             objCnt[tid] = 0;
         }
         if (tid < M_COUNT && tid != M_STATUS) misc[tid] = 0;
+        KB_STAMP_PRE(16);
         __syncthreads();
         KB_STAMP(0);
         // object-object / object-wall manifolds (b2Contact::Update) + their velocity-constraint set-up: candidate t
@@ -401,9 +413,10 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
         };
         bool big = p.solver_mode >= 3;
         if (!big) {
-            find_pass(lPair, lInfo, p.capL);
+            find_pass(lPair, lInfo, capL_);
+            KB_STAMP_PRE(17);
             __syncthreads();
-            big = (int)misc[M_NCON] > p.capL;    // does not fit the LDS staging area: redo into the global scratch slice
+            big = (int)misc[M_NCON] > capL_;    // does not fit the LDS staging area: redo into the global scratch slice
             if (big) {
                 __syncthreads();
                 if (tid == 0) misc[M_NCON] = 0;
@@ -416,7 +429,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
             __syncthreads();
         }
         KB_STAMP(1);
-        const int stageCap = big ? p.cap : p.capL;
+        const int stageCap = big ? p.cap : capL_;
         if ((int)misc[M_NCON] > stageCap && tid == 0) atomicOr(&misc[M_STATUS], 1u);
         const int ncon = min((int)misc[M_NCON], stageCap);
 
@@ -547,6 +560,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
             }
         };
         if (big) label_pass(gPair, gInfo, gAcc); else label_pass(lPair, lInfo, lAcc);
+        KB_STAMP_PRE(18);
         __syncthreads();
         KB_STAMP(2);
 
@@ -570,7 +584,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
             active[b] = 1; active[NB + b] = 0;
         }
         const unsigned newTotal = block_scan_u8(wsCntNew, newOff, NP, wsum);   // (barriers inside)
-        const bool newInLds = newTotal <= (unsigned)p.capL;
+        const bool newInLds = newTotal <= (unsigned)capL_;
         if (OBJ && wave == 0) {   // island of every manifold constraint
             unsigned root = 0;
             const bool on = lane < NMC && mcTouch;
@@ -1420,17 +1434,17 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                 const float m1 = fminf(fminf(xb - p.xmin, p.xmax - xb), fminf(yb - p.ymin, p.ymax - yb));
                 if (m0 > total && m1 > total) continue;          // stays clear of every wall: no event possible
                 const int i = (int)atomicAdd(&misc[M_NCON], 1u);
-                if (i >= p.capL / 2) { atomicOr(&misc[M_STATUS], 8u); continue; }
+                if (i >= capL_ / 2) { atomicOr(&misc[M_STATUS], 8u); continue; }
                 cand[q] = i;
                 lPair[i] = (unsigned)b; cTh0[i] = sth0[q]; cTh[i] = th[q]; cW[i] = bw[q];
             }
             if (tid < M && objTab[tid * OT_WORDS + OT_KIND] == 0.0f) {   // circles only: no continuous step for polygons
                 const int i = (int)atomicAdd(&misc[M_NCON], 1u);
-                if (i < p.capL / 2) { candObj = i; lPair[i] = (unsigned)(N + tid); cTh0[i] = objA0[tid]; cTh[i] = objA[tid]; cW[i] = objW[tid]; }
+                if (i < capL_ / 2) { candObj = i; lPair[i] = (unsigned)(N + tid); cTh0[i] = objA0[tid]; cTh[i] = objA[tid]; cW[i] = objW[tid]; }
                 else atomicOr(&misc[M_STATUS], 8u);
             }
             __syncthreads();
-            const int ncand = min((int)misc[M_NCON], p.capL / 2);
+            const int ncand = min((int)misc[M_NCON], capL_ / 2);
             for (int i = tid; i < ncand; i += nt) {
                 const int b = (int)lPair[i];
                 const bool isObj = b >= N;
@@ -1483,9 +1497,9 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
         if (misc[M_STATUS]) atomicOr(&g.status[e], (int)misc[M_STATUS]);
 #ifdef KB_PROFILE
         prof_acc[7] += clock64() - prof_t;
-        for (int k = 0; k < 8; ++k) g.status[p.E + 16 * e + k] += (int)(prof_acc[k] >> 4);   // units of 16 cycles
-        for (int k = 8; k < 13; ++k) g.status[p.E + 16 * e + k] += (int)prof_acc[k];
-        for (int k = 13; k < 16; ++k) g.status[p.E + 16 * e + k] += (int)(prof_acc[k] >> 4);
+        for (int k = 0; k < 8; ++k) g.status[p.E + 24 * e + k] += (int)(prof_acc[k] >> 4);   // units of 16 cycles
+        for (int k = 8; k < 13; ++k) g.status[p.E + 24 * e + k] += (int)prof_acc[k];
+        for (int k = 13; k < 24; ++k) g.status[p.E + 24 * e + k] += (int)(prof_acc[k] >> 4);
 #endif
     }
 }

@@ -36,7 +36,7 @@ def main():
     if args.objects and args.boxes:
         okw = dict(obj_shape=[1] * args.objects, obj_nverts=[4] * args.objects, obj_verts=[[[0.075 * 25.0, 0.075 * 25.0]]] * args.objects)
     sim = KilobotSim(E, N, num_objects=args.objects, **okw)
-    sim.status = torch.zeros(E + 16 * E, dtype=torch.int32, device=sim.device)   # status + stamp area
+    sim.status = torch.zeros(E + 24 * E, dtype=torch.int32, device=sim.device)   # status + stamp area
     sim._bind()
     xy1, th1 = scenes.lattice_spawn(8, N, seed=1000)
     reps = (E + 7) // 8
@@ -61,7 +61,7 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / args.steps
-    raw = sim.status[E:].reshape(E, 16).double().cpu().numpy() / (args.steps * args.fused)
+    raw = sim.status[E:].reshape(E, 24).double().cpu().numpy() / (args.steps * args.fused)
     st = raw[:, :8] * 16
     mean = st.mean(0)
     print('launch %.3f ms (%d substeps per launch); cycles per env-substep (wave 0), mean over %d envs:' % (ms, args.fused, E))
@@ -71,6 +71,8 @@ def main():
     ex = raw[:, 8:13].mean(0)
     extra = raw[:, 13:16].mean(0) * 16
     print('  kernel start (per launch) %.0f, flatten+scan (part of islands+buckets) %.0f' % (extra[0], extra[1]))
+    pre = raw[:, 16:19].mean(0) * 16
+    print('  wave 0 before the barrier (own work): drive+grid %.0f, count pass %.0f, emit pass %.0f' % tuple(pre))
     print('  wave 0 per substep: keys %.1f, depth rounds/sweep %.1f (deepest wave of the env %.1f), position sweeps %.2f, reg-path fraction %.2f' % (ex[0], ex[4], ex[1], ex[2], ex[3]))
 
 
