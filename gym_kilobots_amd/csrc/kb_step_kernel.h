@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
         {   // the thread index is re-read every substep: predicates derived from it are then evaluated where they are
             // used (one compare) instead of being hoisted out of the substep loop and kept in spilled scalar registers
             int t_ = threadIdx.x;
-            asm volatile("" : "+v"(t_));
+            if (FN == 0) asm volatile("" : "+v"(t_));     // (the fixed-size instantiation has registers to spare)
             tid = t_; lane = t_ & 63; wave = t_ >> 6;
         }
         // ---- light.step: SinglePositionLight.step, light.py:59-75 (uniform per env) ----
