@@ -88,7 +88,26 @@ int kb_create(const kb_config *cfg, kb_sim **out) {
     if (cfg->num_envs < 1 || cfg->num_bots < 1 || cfg->num_bots > KB_MAX_BOTS)
         return fail(KB_EINVAL, "kb_create: num_envs >= 1 and 1 <= num_bots <= 1024 required");
     if (cfg->num_objects < 0 || cfg->num_objects > KB_MAX_OBJECTS) return fail(KB_EINVAL, "kb_create: 0 <= num_objects <= 8 required");
-    for (int m = 0; m < cfg->num_objects; ++m) {
+    const int nfix = cfg->num_fixtures > 0 ? cfg->num_fixtures : cfg->num_objects;
+    if (cfg->num_fixtures != 0 && (cfg->num_fixtures < cfg->num_objects || cfg->num_fixtures > KB_MAX_OBJECTS))
+        return fail(KB_EINVAL, "kb_create: num_fixtures must be 0 or num_objects..8");
+    {
+        int per_body[KB_MAX_OBJECTS] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int f = 0; f < nfix; ++f) {
+            const int b = cfg->num_fixtures > 0 ? cfg->obj_fixture_body[f] : f;
+            if (b < 0 || b >= cfg->num_objects) return fail(KB_EINVAL, "kb_create: obj_fixture_body out of range");
+            per_body[b]++;
+            if (cfg->obj_shape[f] == KB_SHAPE_CIRCLE && per_body[b] > 1) return fail(KB_EINVAL, "kb_create: a circle must be the only fixture of its object");
+        }
+        for (int b = 0; b < cfg->num_objects; ++b) {
+            if (per_body[b] == 0) return fail(KB_EINVAL, "kb_create: every object needs a fixture");
+            if (per_body[b] > 1)
+                for (int f = 0; f < nfix; ++f)
+                    if (cfg->obj_fixture_body[f] == b && cfg->obj_shape[f] == KB_SHAPE_CIRCLE)
+                        return fail(KB_EINVAL, "kb_create: a circle must be the only fixture of its object");
+        }
+    }
+    for (int m = 0; m < nfix; ++m) {
         const int sh = cfg->obj_shape[m];
         if (sh < KB_SHAPE_CIRCLE || sh > KB_SHAPE_POLYGON) return fail(KB_EINVAL, "kb_create: bad obj_shape");
         if (sh == KB_SHAPE_CIRCLE && !(cfg->obj_radius[m] > 0.0f)) return fail(KB_EINVAL, "kb_create: obj_radius must be positive");
@@ -180,25 +199,33 @@ int kb_create(const kb_config *cfg, kb_sim **out) {
     p.cap = (int)cap;
     // with objects the LDS staging area gives up a few entries to the manifold-constraint records, so that two envs
     // of 1024 kilobots still share a CU
-    const int capLmax = cfg->num_objects > 0 ? CAP_LDS - 8 * mc_candidates(cfg->num_objects) : CAP_LDS;
+    const int capLmax = cfg->num_objects > 0 ? CAP_LDS - 8 * mc_candidates(nfix) : CAP_LDS;
     p.capL = p.cap < capLmax ? p.cap : capLmax;
     p.NP = (p.N + 3) & ~3;
     p.NB = p.NP + KB_MAX_OBJECTS + 4;
     p.M = cfg->num_objects;
-    for (int m = 0; m < KB_MAX_OBJECTS; ++m) {
-        float *T = p.otab[m];
-        const int kind = m < cfg->num_objects ? cfg->obj_shape[m] : KB_SHAPE_CIRCLE;
+    p.F = nfix;
+    float bm[KB_MAX_OBJECTS], bi[KB_MAX_OBJECTS];
+    V2 bc[KB_MAX_OBJECTS];
+    for (int m = 0; m < KB_MAX_OBJECTS; ++m) { bm[m] = 0.0f; bi[m] = 0.0f; bc[m] = mk2(0.0f, 0.0f); }
+    for (int f = 0; f < KB_MAX_OBJECTS; ++f) {
+        float *T = p.otab[f];
+        for (int k = 0; k < OT_WORDS; ++k) T[k] = 0.0f;
+        if (f >= nfix) continue;
+        const int body = cfg->num_fixtures > 0 ? cfg->obj_fixture_body[f] : f;
+        const int kind = cfg->obj_shape[f];
         float mo, io;
-        T[OT_KIND] = (float)kind; T[OT_N] = 0.0f;
+        V2 ce = mk2(0.0f, 0.0f);
+        T[OT_KIND] = (float)kind; T[OT_N] = 0.0f; T[OT_BODY] = (float)body;
         if (kind == KB_SHAPE_CIRCLE) {
-            const float r = cfg->obj_radius[m] * WORLD_SCALE;
-            T[OT_RADIUS] = r; T[OT_BOUND] = r;
+            const float r = cfg->obj_radius[f] * WORLD_SCALE;
+            T[OT_RADIUS] = r;
             mo = cfg->obj_density * B2_PI * r * r;       // b2CircleShape::ComputeMass
             io = mo * (0.5f * r * r);                     // I = mass * (0.5 r^2 + |p|^2), p = 0
         } else {
             int n;
             if (kind == KB_SHAPE_BOX) {                   // b2PolygonShape::SetAsBox
-                const float hx = cfg->obj_verts[m][0][0], hy = cfg->obj_verts[m][0][1];
+                const float hx = cfg->obj_verts[f][0][0], hy = cfg->obj_verts[f][0][1];
                 n = 4;
                 const float vx[4] = {-hx, hx, hx, -hx}, vy[4] = {-hy, -hy, hy, hy};
                 const float nx[4] = {0.0f, 1.0f, 0.0f, -1.0f}, ny[4] = {-1.0f, 0.0f, 1.0f, 0.0f};
@@ -207,10 +234,10 @@ int kb_create(const kb_config *cfg, kb_sim **out) {
                     T[OT_NORMALS + 2 * i] = nx[i]; T[OT_NORMALS + 2 * i + 1] = ny[i];
                 }
             } else {                                      // b2PolygonShape::Set on an ordered hull
-                n = cfg->obj_nverts[m];
+                n = cfg->obj_nverts[f];
                 for (int i = 0; i < n; ++i) {
-                    T[OT_VERTS + 2 * i] = cfg->obj_verts[m][i][0];
-                    T[OT_VERTS + 2 * i + 1] = cfg->obj_verts[m][i][1];
+                    T[OT_VERTS + 2 * i] = cfg->obj_verts[f][i][0];
+                    T[OT_VERTS + 2 * i + 1] = cfg->obj_verts[f][i][1];
                 }
                 for (int i = 0; i < n; ++i) {
                     const V2 edge = v_sub(ot_v(T, i + 1 < n ? i + 1 : 0), ot_v(T, i));
@@ -220,17 +247,34 @@ int kb_create(const kb_config *cfg, kb_sim **out) {
             }
             T[OT_N] = (float)n;
             T[OT_RADIUS] = B2_POLYGON_RADIUS;
-            float far2 = 0.0f;
-            for (int i = 0; i < n; ++i) far2 = fmaxf(far2, v_dot(ot_v(T, i), ot_v(T, i)));
-            T[OT_BOUND] = sqrtf(far2) + B2_POLYGON_RADIUS;
-            polygon_mass(T, cfg->obj_density, mo, io);
+            polygon_mass(T, cfg->obj_density, mo, ce, io);
         }
-        T[OT_IM] = mo > 0.0f ? 1.0f / mo : 0.0f;
-        T[OT_II] = io > 0.0f ? 1.0f / io : 0.0f;
+        bm[body] += mo; bc[body] = v_add(bc[body], v_scale(mo, ce)); bi[body] += io;      // b2Body::ResetMassData
+    }
+    for (int m = 0; m < KB_MAX_OBJECTS; ++m) {
+        float *B = p.obody[m];
+        for (int k = 0; k < BT_WORDS; ++k) B[k] = 0.0f;
+        V2 lc = mk2(0.0f, 0.0f);
+        if (bm[m] > 0.0f) { B[BT_IM] = 1.0f / bm[m]; lc = v_scale(B[BT_IM], bc[m]); }
+        const float io = bi[m] - bm[m] * v_dot(lc, lc);     // inertia about the centre of mass
+        B[BT_II] = io > 0.0f ? 1.0f / io : 0.0f;
+        B[BT_LCX] = lc.x; B[BT_LCY] = lc.y;
+        B[BT_RADIUS] = B2_POLYGON_RADIUS;
+    }
+    for (int f = 0; f < nfix; ++f) {
+        float *T = p.otab[f];
+        const int body = ot_body(T);
+        float *B = p.obody[body];
+        T[OT_IM] = B[BT_IM]; T[OT_II] = B[BT_II];
+        B[BT_KIND] = T[OT_KIND];
+        if (ot_kind(T) == KB_SHAPE_CIRCLE) { T[OT_BOUND] = T[OT_RADIUS]; B[BT_RADIUS] = T[OT_RADIUS]; continue; }
+        float far2 = 0.0f;                                // bounding radius about the centre of mass of the body
+        for (int i = 0; i < ot_n(T); ++i) { const V2 q = v_sub(ot_v(T, i), mk2(B[BT_LCX], B[BT_LCY])); far2 = fmaxf(far2, v_dot(q, q)); }
+        T[OT_BOUND] = sqrtf(far2) + B2_POLYGON_RADIUS;
     }
     p.mu_oo = sqrtf(cfg->obj_friction * cfg->obj_friction);
     p.mu_ow = sqrtf(cfg->obj_friction * cfg->wall_friction);
-    p.nmc = mc_candidates(p.M);
+    p.nmc = mc_candidates(p.F);
     p.kl_obj = 1.0f / (1.0f + p.h * cfg->obj_linear_damping);
     p.ka_obj = 1.0f / (1.0f + p.h * cfg->obj_angular_damping);
     p.solver_mode = cfg->solver_mode;

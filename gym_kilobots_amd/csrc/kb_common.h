@@ -32,7 +32,8 @@ constexpr unsigned KEY_WALL = 0x10000u, KEY_OBJ = 0x20000u;
 constexpr int WALL_CODE = 0xFFF0;     // body id of wall w is WALL_CODE + w
 constexpr int OBJ_CODE = 0xFFE0;      // 16-bit warm-start key of object m (its body id is N + m)
 constexpr int MAXOBJ = KB_MAX_OBJECTS, OBJ_LIST = 32;
-constexpr int OT_WORDS_C = 6 + 4 * KB_MAX_POLY_VERTS;   // floats per object in the object table (kb_objects.h)
+constexpr int OT_WORDS_C = 7 + 4 * KB_MAX_POLY_VERTS;   // floats per fixture in the fixture table (kb_objects.h)
+constexpr int BT_WORDS_C = 6;                          // floats per object in the body table
 constexpr int MC_FIELDS_C = 37;                        // words per manifold-constraint record (kb_objects.h)
 constexpr unsigned EMPTY32 = 0xFFFFFFFFu;
 constexpr unsigned short EMPTY16 = 0xFFFFu;
@@ -80,7 +81,8 @@ constexpr int BKMAXRANK = BKFILL + A16(4 * MAX_BUCKETS);
 constexpr int BKLIST = BKMAXRANK + A16(4 * MAX_WAVES * NUM_CLS);
 constexpr int NLIST = BKLIST + A16(2 * MAX_BUCKETS);
 constexpr int OBJTAB = NLIST + 16;                                    // object table: mass, shape
-constexpr int OBJCNT = OBJTAB + A16(4 * OT_WORDS_C * KB_MAX_OBJECTS);
+constexpr int OBJBODY = OBJTAB + A16(4 * OT_WORDS_C * KB_MAX_OBJECTS);  // body table
+constexpr int OBJCNT = OBJBODY + A16(4 * BT_WORDS_C * KB_MAX_OBJECTS);
 constexpr int OBJLIST = OBJCNT + A16(4 * KB_MAX_OBJECTS);
 constexpr int OBJW = OBJLIST + A16(2 * KB_MAX_OBJECTS * 32);          // angular velocity, angle, angle at the start of the substep
 constexpr int OBJA = OBJW + A16(4 * KB_MAX_OBJECTS);
@@ -119,7 +121,9 @@ struct Params {
     float lradius[KB_MAX_LIGHTS], lmaxv[KB_MAX_LIGHTS];
     float llo[KB_MAX_LIGHTS][2], lhi[KB_MAX_LIGHTS][2], lalo[KB_MAX_LIGHTS][2], lahi[KB_MAX_LIGHTS][2];
     float kl_obj, ka_obj;
-    float otab[KB_MAX_OBJECTS][OT_WORDS_C];   // object table (kb_objects.h: OT_*)
+    float otab[KB_MAX_OBJECTS][OT_WORDS_C];   // fixture table (kb_objects.h: OT_*)
+    float obody[KB_MAX_OBJECTS][BT_WORDS_C];  // body table (kb_objects.h: BT_*)
+    int F;                                    // fixtures (>= M)
     float mu_oo, mu_ow;                       // b2MixFriction: object-object, object-wall
     int nmc;                                  // manifold-constraint candidates: pairs + 4 walls per object
     int lds_total;

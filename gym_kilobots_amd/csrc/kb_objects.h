@@ -50,18 +50,23 @@ __device__ __forceinline__ XF xf_make(float px, float py, float ang) {
 }
 KB_HD XF xf_identity() { XF t; t.p = mk2(0.0f, 0.0f); t.s = 0.0f; t.c = 1.0f; return t; }
 
-// ---- object table: OT_WORDS floats per object (kernel parameter -> LDS) ----
+// ---- fixture table: OT_WORDS floats per fixture (kernel parameter -> LDS).  OT_IM / OT_II are those of the body the
+//      fixture belongs to (OT_BODY); vertices and normals are in the body frame (origin, not centre of mass) ----
 enum { OT_IM = 0, OT_II = 1, OT_RADIUS = 2, OT_BOUND = 3, OT_KIND = 4, OT_N = 5, OT_VERTS = 6, OT_NORMALS = 6 + 2 * KB_MAX_POLY_VERTS,
-       OT_WORDS = 6 + 4 * KB_MAX_POLY_VERTS };
+       OT_BODY = 6 + 4 * KB_MAX_POLY_VERTS, OT_WORDS = 7 + 4 * KB_MAX_POLY_VERTS };
+// ---- body table: BT_WORDS floats per object: inverse mass / inertia, b2Sweep::localCenter, skin or circle radius, kind ----
+enum { BT_IM = 0, BT_II = 1, BT_LCX = 2, BT_LCY = 3, BT_RADIUS = 4, BT_KIND = 5, BT_WORDS = 6 };
+static_assert(BT_WORDS == BT_WORDS_C, "body table size");
 static_assert(OT_WORDS == OT_WORDS_C, "object table size");
 KB_HD int ot_kind(const float *T) { return (int)T[OT_KIND]; }
 KB_HD int ot_n(const float *T) { return (int)T[OT_N]; }
+KB_HD int ot_body(const float *T) { return (int)T[OT_BODY]; }
 KB_HD V2 ot_v(const float *T, int i) { return mk2(T[OT_VERTS + 2 * i], T[OT_VERTS + 2 * i + 1]); }
 KB_HD V2 ot_nrm(const float *T, int i) { return mk2(T[OT_NORMALS + 2 * i], T[OT_NORMALS + 2 * i + 1]); }
 
-// b2PolygonShape::ComputeMass (triangle fan about the vertex average); inertia about the centre of mass as
-// b2Body::ResetMassData leaves it.  Host side (kb_create).
-inline void polygon_mass(const float *T, float density, float &mass, float &inertia) {
+// b2PolygonShape::ComputeMass (triangle fan about the vertex average): mass, centroid, inertia about the body origin.
+// Host side (kb_create).
+inline void polygon_mass(const float *T, float density, float &mass, V2 &centroid, float &inertia) {
     const int n = ot_n(T);
     V2 center = mk2(0.0f, 0.0f), s = mk2(0.0f, 0.0f);
     float area = 0.0f, I = 0.0f;
@@ -83,8 +88,7 @@ inline void polygon_mass(const float *T, float density, float &mass, float &iner
     const V2 c = v_add(center, s);
     float Io = density * I;
     Io += m * (v_dot(c, c) - v_dot(center, center));
-    Io -= m * v_dot(c, c);
-    mass = m; inertia = Io;
+    mass = m; centroid = c; inertia = Io;
 }
 
 // ---- narrowphase ------------------------------------------------------------------------------------------------
@@ -293,7 +297,8 @@ struct BState { V2 c; float a; V2 v; float w; float m, i; };
 struct ObjCtx {
     float2 *pos, *vel;      // bodies: kilobots 0..N-1, objects N + m
     float *objW, *objA;     // angular velocity / angle of object m
-    const float *objTab;    // OT_WORDS floats per object
+    const float *objTab;    // OT_WORDS floats per fixture
+    const float *objBody;   // BT_WORDS floats per object
     float *mc;              // field-major manifold-constraint records, MCN per field
     int N, MCN;
     float mu_oo, mu_ow;     // b2MixFriction = sqrt(f1 f2): object-object, object-wall
@@ -312,7 +317,7 @@ KB_DI BState body_get(const ObjCtx &x, int id) {
     const int m = id - x.N;
     const float2 c = x.pos[id], v = x.vel[id];
     s.c = mk2(c.x, c.y); s.a = x.objA[m]; s.v = mk2(v.x, v.y); s.w = x.objW[m];
-    s.m = x.objTab[m * OT_WORDS + OT_IM]; s.i = x.objTab[m * OT_WORDS + OT_II];
+    s.m = x.objBody[m * BT_WORDS + BT_IM]; s.i = x.objBody[m * BT_WORDS + BT_II];
     return s;
 }
 KB_DI void body_put_vel(const ObjCtx &x, int id, const BState &s) {
@@ -323,15 +328,22 @@ KB_DI void body_put_pos(const ObjCtx &x, int id, const BState &s) {
     if (id >= WALL_CODE) return;
     x.pos[id].x = s.c.x; x.pos[id].y = s.c.y; x.objA[id - x.N] = s.a;
 }
+// b2Body::SynchronizeTransform: q from the angle, p = c - q * localCenter (c = centre of mass)
+KB_DI XF xf_of_body(const float *B, float cx, float cy, float a) {
+    XF t = xf_make(0.0f, 0.0f, a);
+    const float lx = B[BT_LCX], ly = B[BT_LCY];
+    t.p = mk2(cx - (t.c * lx - t.s * ly), cy - (t.s * lx + t.c * ly));
+    return t;
+}
 KB_DI XF body_xf(const ObjCtx &x, int id) {
     if (id >= WALL_CODE) return xf_identity();
-    return xf_make(x.pos[id].x, x.pos[id].y, x.objA[id - x.N]);
+    return xf_of_body(x.objBody + (id - x.N) * BT_WORDS, x.pos[id].x, x.pos[id].y, x.objA[id - x.N]);
 }
 KB_DI float body_radius(const ObjCtx &x, int id) {
-    return id >= WALL_CODE ? B2_POLYGON_RADIUS : x.objTab[(id - x.N) * OT_WORDS + OT_RADIUS];
+    return id >= WALL_CODE ? B2_POLYGON_RADIUS : x.objBody[(id - x.N) * BT_WORDS + BT_RADIUS];
 }
 
-// candidate t -> (owner object, column) of the warm-start table; pairs (m1 < m2) first, then (object, wall)
+// candidate t -> (owner fixture, column) of the warm-start table; fixture pairs (f1 < f2) first, then (fixture, wall)
 KB_DI void mc_candidate(int M, int t, int &owner, int &col) {
     const int npair = M * (M - 1) / 2;
     if (t < npair) {
@@ -354,8 +366,9 @@ __device__ __noinline__ bool mc_detect(const ObjCtx &x, const Arena &p, int M, i
     int a, b;
     const int N = x.N;
     if (col < 8) {
-        const int m1 = owner, m2 = col;
-        const float *T1 = x.objTab + m1 * OT_WORDS, *T2 = x.objTab + m2 * OT_WORDS;
+        const float *T1 = x.objTab + owner * OT_WORDS, *T2 = x.objTab + col * OT_WORDS;
+        const int m1 = ot_body(T1), m2 = ot_body(T2);
+        if (m1 == m2) return false;                        // fixtures of one body never collide
         const float dx = x.pos[N + m2].x - x.pos[N + m1].x, dy = x.pos[N + m2].y - x.pos[N + m1].y;
         const float rb = T1[OT_BOUND] + T2[OT_BOUND];
         if (dx * dx + dy * dy > rb * rb) return false;      // bounding circles (stand-in for the broadphase)
@@ -369,17 +382,16 @@ __device__ __noinline__ bool mc_detect(const ObjCtx &x, const Arena &p, int M, i
             collide_polygons(mf, T1, body_xf(x, a), T2, body_xf(x, b));
             if (mf.count == 0) return false;
         } else {                                            // the polygon is fixture A
-            const int mp = !c1 ? m1 : m2, mcirc = mp == m1 ? m2 : m1;
-            a = N + mp; b = N + mcirc;
+            const float *Tp = !c1 ? T1 : T2, *Tc = !c1 ? T2 : T1;
+            a = N + ot_body(Tp); b = N + ot_body(Tc);
             V2 ln, lp;
-            if (!collide_poly_circle(x.objTab + mp * OT_WORDS, body_xf(x, a), mk2(x.pos[b].x, x.pos[b].y),
-                                     x.objTab[mcirc * OT_WORDS + OT_RADIUS], ln, lp)) return false;
+            if (!collide_poly_circle(Tp, body_xf(x, a), mk2(x.pos[b].x, x.pos[b].y), Tc[OT_RADIUS], ln, lp)) return false;
             mf.type = 1; mf.count = 1; mf.localNormal = ln; mf.localPoint = lp;
         }
     } else {
-        const int m = owner, wl = col - 8;
-        const float *T = x.objTab + m * OT_WORDS;
-        a = WALL_CODE + wl; b = N + m;
+        const int wl = col - 8;
+        const float *T = x.objTab + owner * OT_WORDS;
+        a = WALL_CODE + wl; b = N + ot_body(T);
         if (ot_kind(T) == KB_SHAPE_CIRCLE) {                // b2CollideEdgeAndCircle, region AB
             float dist, nx, ny;
             switch (wl) {       // wall_geom
@@ -585,8 +597,8 @@ __device__ __noinline__ float mc_solve_position(const ObjCtx &x, int t) {
     float minSeparation = 0.0f;
     for (int j = 0; j < count; ++j) {
         const V2 lpj = mk2(mcf(x, j ? MC_P1X : MC_P0X, t), mcf(x, j ? MC_P1Y : MC_P0Y, t));
-        const XF xfA = a >= WALL_CODE ? xf_identity() : xf_make(A.c.x, A.c.y, A.a);
-        const XF xfB = xf_make(B.c.x, B.c.y, B.a);
+        const XF xfA = a >= WALL_CODE ? xf_identity() : xf_of_body(x.objBody + (a - x.N) * BT_WORDS, A.c.x, A.c.y, A.a);
+        const XF xfB = xf_of_body(x.objBody + (b - x.N) * BT_WORDS, B.c.x, B.c.y, B.a);
         V2 normal, point;
         float separation;
         if (type == 0) {                                    // b2PositionSolverManifold
@@ -625,8 +637,7 @@ __device__ __noinline__ float mc_solve_position(const ObjCtx &x, int t) {
 // ---- kilobot - polygon object contact (class 10; Box2D: A = the polygon, B = the kilobot, one point, friction 0) --
 struct PolyCon { V2 normal, rA; float nmass; };   // velocity phase: normal polygon -> kilobot, lever arm on the polygon
 // manifold at the poses (op, oa) / bot centre bc -> velocity constraint data.  False: not touching.
-KB_DI bool poly_contact_setup(const float *T, float opx, float opy, float oa, V2 bc, float r_bot, float im_bot, PolyCon &pc) {
-    const XF xo = xf_make(opx, opy, oa);
+KB_DI bool poly_contact_setup(const float *T, const XF &xo, float opx, float opy, V2 bc, float r_bot, float im_bot, PolyCon &pc) {
     V2 ln, lp;
     if (!collide_poly_circle(T, xo, bc, r_bot, ln, lp)) return false;
     const V2 normal = rot_mul(xo, ln);

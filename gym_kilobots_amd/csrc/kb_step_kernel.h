@@ -44,7 +44,8 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
     unsigned *bkMaxRank = (unsigned *)(smem + lds::BKMAXRANK);
     unsigned short *bkList = (unsigned short *)(smem + lds::BKLIST);
     unsigned char *nList = smem + lds::NLIST;
-    float *objTab = (float *)(smem + lds::OBJTAB);                       // object table (kb_objects.h: OT_*)
+    float *objTab = (float *)(smem + lds::OBJTAB);                       // fixture table (kb_objects.h: OT_*)
+    float *objBody = (float *)(smem + lds::OBJBODY);                     // body table (kb_objects.h: BT_*)
     unsigned *objCnt = (unsigned *)(smem + lds::OBJCNT);                 // kilobots touching object m
     unsigned short *objList = (unsigned short *)(smem + lds::OBJLIST);   // ... and who they are
     float *objW = (float *)(smem + lds::OBJW), *objA = (float *)(smem + lds::OBJA), *objA0 = (float *)(smem + lds::OBJA0);
@@ -52,20 +53,21 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
     const int M = OBJ ? p.M : 0;   // OBJ = false: every object loop below folds away
     // inverse mass / radius of a body id: kilobot < N, object N + m, wall >= WALL_CODE (static, edge skin radius)
     auto bim = [&](int id) __attribute__((always_inline)) -> float {
-        return id >= WALL_CODE ? 0.0f : ((!OBJ || id < N) ? p.im_bot : objTab[(id - N) * OT_WORDS + OT_IM]);
+        return id >= WALL_CODE ? 0.0f : ((!OBJ || id < N) ? p.im_bot : objBody[(id - N) * BT_WORDS + BT_IM]);
     };
     auto brad = [&](int id) __attribute__((always_inline)) -> float {
-        return id >= WALL_CODE ? B2_POLYGON_RADIUS : ((!OBJ || id < N) ? p.r_bot : objTab[(id - N) * OT_WORDS + OT_RADIUS]);
+        return id >= WALL_CODE ? B2_POLYGON_RADIUS : ((!OBJ || id < N) ? p.r_bot : objBody[(id - N) * BT_WORDS + BT_RADIUS]);
     };
     // is body id a polygon object (kilobot - polygon contacts carry a lever arm on the object)
     auto bpoly = [&](int id) __attribute__((always_inline)) -> bool {
-        return OBJ && id >= N && id < WALL_CODE && objTab[(id - N) * OT_WORDS + OT_KIND] != 0.0f;
+        return OBJ && id >= N && id < WALL_CODE && objBody[(id - N) * BT_WORDS + BT_KIND] != 0.0f;
     };
     ObjCtx ox;
-    ox.pos = pos; ox.vel = vel; ox.objW = objW; ox.objA = objA; ox.objTab = objTab;
+    ox.pos = pos; ox.vel = vel; ox.objW = objW; ox.objA = objA; ox.objTab = objTab; ox.objBody = objBody;
     ox.mc = (float *)(smem + lds::mcarea(NB, capL_, NP, p.ncell));
     ox.N = N; ox.MCN = p.nmc; ox.mu_oo = p.mu_oo; ox.mu_ow = p.mu_ow;
-    const int NMC = OBJ ? p.nmc : 0;      // manifold-constraint candidates (object pairs, object-wall)
+    const int NMC = OBJ ? p.nmc : 0;      // manifold-constraint candidates (fixture pairs, fixture-wall)
+    const int F = OBJ ? p.F : 0;          // fixtures of the objects (>= M)
 
     const kb_buffers &g = p.buf;
     // contact staging in global scratch, used when an env has more contacts than fit the LDS staging area
@@ -128,8 +130,15 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
         const size_t oi = (size_t)e * M + tid;
         pos[N + tid].x = g.ox[oi]; pos[N + tid].y = g.oy[oi]; vel[N + tid].x = g.ovx[oi]; vel[N + tid].y = g.ovy[oi];
         objA[tid] = g.otheta[oi]; objW[tid] = g.ow[oi];
+        const float lx = p.obody[tid][BT_LCX], ly = p.obody[tid][BT_LCY];
+        if (lx != 0.0f || ly != 0.0f) {    // the state holds the body origin, the solver works on the centre of mass
+            const XF t = xf_make(g.ox[oi], g.oy[oi], g.otheta[oi]);
+            const V2 cm = xf_mul(t, mk2(lx, ly));
+            pos[N + tid].x = cm.x; pos[N + tid].y = cm.y;
+        }
     }
-    for (int k = tid; k < M * OT_WORDS; k += nt) objTab[k] = p.otab[k / OT_WORDS][k % OT_WORDS];
+    for (int k = tid; k < F * OT_WORDS; k += nt) objTab[k] = p.otab[k / OT_WORDS][k % OT_WORDS];
+    for (int k = tid; k < M * BT_WORDS; k += nt) objBody[k] = p.obody[k / BT_WORDS][k % BT_WORDS];
     // manifold-constraint candidate t (object pair / object-wall) is looked after by lane t of wave 0
     bool mcTouch = false;
     float *owsMine = nullptr;
@@ -319,6 +328,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
             parent[N + tid] = N + tid;
             objCnt[tid] = 0;
         }
+        if (OBJ && tid >= M && tid < F) objCnt[tid] = 0;
         if (tid < M_COUNT && tid != M_STATUS) misc[tid] = 0;
         KB_STAMP_PRE(16);
         __syncthreads();
@@ -331,7 +341,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                 owsMine = g.ows_acc + (size_t)e * (MAXOBJ * KB_OWS_COLS * KB_OWS_WORDS);
                 Arena ar;
                 ar.xmin = p.xmin; ar.ymin = p.ymin; ar.xmax = p.xmax; ar.ymax = p.ymax;
-                mcTouch = mc_detect(ox, ar, M, lane, owsMine);
+                mcTouch = mc_detect(ox, ar, F, lane, owsMine);
             }
         }
 
@@ -389,21 +399,22 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                 // pushable objects: b2CollideCircles / b2CollidePolygonAndCircle kilobot - object m
                 // (info 9 + m; bits 8..: how many lower objects this kilobot touches)
                 unsigned nobj = 0;
-                for (int m = 0; m < M; ++m) {
-                    const float *T = objTab + m * OT_WORDS;
+                for (int f = 0; f < F; ++f) {
+                    const float *T = objTab + f * OT_WORDS;
+                    const int m = ot_body(T);
                     const float dx = pos[N + m].x - ax, dy = pos[N + m].y - ay;
                     const float ro = p.r_bot + T[OT_BOUND];       // circle: contact radius; polygon: bounding radius
                     if (dx * dx + dy * dy > ro * ro) continue;
                     if (T[OT_KIND] != 0.0f) {
                         V2 ln, lp;
-                        if (!collide_poly_circle(T, xf_make(pos[N + m].x, pos[N + m].y, objA[m]), mk2(ax, ay), p.r_bot, ln, lp)) continue;
+                        if (!collide_poly_circle(T, body_xf(ox, N + m), mk2(ax, ay), p.r_bot, ln, lp)) continue;
                     }
                     mine++;
-                    const unsigned pos = atomicAdd(&objCnt[m], 1u);
-                    if (pos < (unsigned)OBJ_LIST) objList[m * OBJ_LIST + pos] = (unsigned short)a;
+                    const unsigned pos = atomicAdd(&objCnt[f], 1u);
+                    if (pos < (unsigned)OBJ_LIST) objList[f * OBJ_LIST + pos] = (unsigned short)a;
                     else atomicOr(&misc[M_STATUS], 4u);
                     const unsigned c = atomicAdd(&misc[M_NCON], 1u);
-                    if (c < (unsigned)stageCap_) { sPair[c] = (unsigned)a | ((unsigned)(N + m) << 16); sInfo[c] = (unsigned)(9 + m) | (nobj << 8); }
+                    if (c < (unsigned)stageCap_) { sPair[c] = (unsigned)a | ((unsigned)(N + m) << 16); sInfo[c] = (unsigned)(9 + f) | (nobj << 8); }
                     nobj++;
                 }
                 dirCnt[a] = cnt;
@@ -420,7 +431,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
             if (big) {
                 __syncthreads();
                 if (tid == 0) misc[M_NCON] = 0;
-                if (tid < M) objCnt[tid] = 0;
+                if (tid < F) objCnt[tid] = 0;
                 __syncthreads();
             }
         }
@@ -462,6 +473,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                 const unsigned pr = sPair[c], inf0 = sInfo[c];
                 const int k = inf0 & 31;
                 int cls, r, slot;
+                unsigned fixbits = 0;
                 float acc;
                 if (k >= 9) {    // kilobot - object m, owned by the kilobot; all of them strictly sequential
                     const int a = pr & 0xFFFF, m = k - 9;
@@ -483,7 +495,8 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                     slot += (int)((inf0 >> 8) & 15u);      // lower objects this kilobot touches (counted by the find pass)
                     cls = CLS_BOT_OBJ;
                     acc = ws_find(a, (unsigned)(OBJ_CODE + m));
-                    unsigned ra = a, rb = N + m;
+                    fixbits = (unsigned)m << 24;      // the fixture travels with the contact (bits 24..27)
+                    unsigned ra = a, rb = pr >> 16;        // the object the fixture belongs to
                     for (;;) {
                         while (true) { unsigned t = ((volatile unsigned *)parent)[ra]; if (t == ra) break; ra = t; }
                         while (true) { unsigned t = ((volatile unsigned *)parent)[rb]; if (t == rb) break; rb = t; }
@@ -555,7 +568,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                 if (acc < 0.0f) acc = 0.0f;
                 if (slot >= S) slot = 255;
                 if (r > 255) { r = 255; atomicOr(&misc[M_STATUS], 4u); }
-                sInfo[c] = (unsigned)cls | ((unsigned)r << 8) | ((unsigned)slot << 16);
+                sInfo[c] = (unsigned)cls | ((unsigned)r << 8) | ((unsigned)slot << 16) | fixbits;
                 sAcc[c] = acc;
             }
         };
@@ -693,7 +706,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
         auto mc_store = [&]() __attribute__((always_inline)) {
             if (OBJ && wave == 0 && lane < NMC) {
                 int owner, col;
-                mc_candidate(M, lane, owner, col);
+                mc_candidate(F, lane, owner, col);
                 float *dst = owsMine + (owner * KB_OWS_COLS + col) * KB_OWS_WORDS;
                 float o[KB_OWS_WORDS] = {-1.0f, -1.0f, -1.0f, -1.0f, -1.0f, -1.0f};
                 if (mcTouch) {
@@ -875,9 +888,8 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                     // velocity-phase normal from the start-of-step positions (b2WorldManifold::Initialize)
                     if (bpoly(b)) {
                         // Box2D's A = the polygon b, B = the kilobot a: manifold, normal polygon -> kilobot, lever arm, normalMass
-                        const int m = b - N;
-                        const float *T = objTab + m * OT_WORDS;
-                        const XF xo = xf_make(pos[b].x, pos[b].y, objA[m]);
+                        const float *T = objTab + ((inf >> 24) & 15u) * OT_WORDS;     // the fixture that is touched
+                        const XF xo = body_xf(ox, b);
                         const V2 bc = mk2(pos[a].x, pos[a].y);
                         V2 ln = mk2(0.0f, 0.0f), lp = mk2(0.0f, 0.0f);
                         collide_poly_circle(T, xo, bc, p.r_bot, ln, lp);
@@ -924,8 +936,9 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
             unsigned long long myMc = 0ull;
             if (OBJ) {
                 const unsigned long long mm = mcMask[wave];
-                myMc = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(mm >> 32)) << 32) |
-                       (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)mm);
+                // (readfirstlane returns int: go through unsigned, or bit 31 smears into the upper half)
+                myMc = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(mm >> 32)) << 32) |
+                       (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)mm);
             }
             // b2ContactSolver::WarmStart
             KB_REG_ROUNDS({
@@ -933,7 +946,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                 const float Px = racc[j] * rnx[j], Py = racc[j] * rny[j];
                 if (OBJ && rpoly[j]) {   // A = polygon b, B = kilobot a
                     const int m = b - N;
-                    objW[m] -= objTab[m * OT_WORDS + OT_II] * (rrAx[j] * Py - rrAy[j] * Px);
+                    objW[m] -= objBody[m * BT_WORDS + BT_II] * (rrAx[j] * Py - rrAy[j] * Px);
                     vel[b].x -= R_IMB(j) * Px; vel[b].y -= R_IMB(j) * Py;
                     vel[a].x += R_IMA(j) * Px; vel[a].y += R_IMA(j) * Py;
                 } else {
@@ -995,7 +1008,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                             racc[j] = newimp;
                             const float Px = lambda * rnx[j], Py = lambda * rny[j];
                             vel[b].x -= rimb[j] * Px; vel[b].y -= rimb[j] * Py;
-                            objW[m] = wA - objTab[m * OT_WORDS + OT_II] * (rrAx[j] * Py - rrAy[j] * Px);
+                            objW[m] = wA - objBody[m * BT_WORDS + BT_II] * (rrAx[j] * Py - rrAy[j] * Px);
                             vel[a].x += rima[j] * Px; vel[a].y += rima[j] * Py;
                         }
                     }
@@ -1016,7 +1029,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                 if (!rvalid[j] || rslot[j] == 255) continue;
                 const int a = ra[j], b = rb[j];
                 const int owner = a < WALL_CODE ? a : b;
-                const unsigned key16 = a >= WALL_CODE ? (unsigned)a : (b >= N ? (unsigned)(OBJ_CODE + (b - N)) : (unsigned)b);
+                const unsigned key16 = a >= WALL_CODE ? (unsigned)a : (b >= N ? (unsigned)OBJ_CODE + ((lInfo[rc[j]] >> 24) & 15u) : (unsigned)b);
                 const unsigned pos = (unsigned)newOff[owner] + (unsigned)rslot[j];
                 if (pos >= (unsigned)p.cap) continue;
                 if (newInLds) { oldKey[pos] = (unsigned short)key16; oldAcc[pos] = racc[j]; }
@@ -1082,21 +1095,21 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                         const int isl = risl[j];
                         if (OBJ && rpoly[j]) {   // b2PositionSolverManifold e_faceA, A = polygon b, B = kilobot a
                             const int m = b - N;
-                            const float *T = objTab + m * OT_WORDS;
-                            const XF xo = xf_make(pos[b].x, pos[b].y, objA[m]);
+                            const float *T = objBody + m * BT_WORDS;
+                            const XF xo = body_xf(ox, b);
                             const V2 normal = rot_mul(xo, mk2(rlnx[j], rlny[j]));
                             const V2 planePoint = xf_mul(xo, mk2(rlpx[j], rlpy[j]));
                             const V2 clipPoint = mk2(pos[a].x, pos[a].y);
-                            const float sep = v_dot(v_sub(clipPoint, planePoint), normal) - T[OT_RADIUS] - p.r_bot;
+                            const float sep = v_dot(v_sub(clipPoint, planePoint), normal) - T[BT_RADIUS] - p.r_bot;
                             const V2 rA = v_sub(clipPoint, mk2(pos[b].x, pos[b].y));
                             if (sep < -3.0f * B2_LINEAR_SLOP) { nxt[isl] = 1; viol = true; }
                             const float C = kb_clampf(B2_BAUMGARTE * (sep + B2_LINEAR_SLOP), -B2_MAX_LINEAR_CORRECTION, 0.0f);
                             const float rnA = v_cross(rA, normal);
-                            const float K = T[OT_IM] + p.im_bot + T[OT_II] * rnA * rnA;
+                            const float K = T[BT_IM] + p.im_bot + T[BT_II] * rnA * rnA;
                             const float imp = K > 0.0f ? -C / K : 0.0f;
                             const V2 P = v_scale(imp, normal);
-                            pos[b].x -= T[OT_IM] * P.x; pos[b].y -= T[OT_IM] * P.y;
-                            objA[m] -= T[OT_II] * v_cross(rA, P);
+                            pos[b].x -= T[BT_IM] * P.x; pos[b].y -= T[BT_IM] * P.y;
+                            objA[m] -= T[BT_II] * v_cross(rA, P);
                             pos[a].x += p.im_bot * P.x; pos[a].y += p.im_bot * P.y;
                             continue;
                         }
@@ -1160,8 +1173,8 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                 unsigned long long myMc = 0ull;
                 if (OBJ) {
                     const unsigned long long mm = mcMask[coop ? nw : wave];
-                    myMc = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(mm >> 32)) << 32) |
-                           (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)mm);
+                    myMc = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(mm >> 32)) << 32) |
+                           (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)mm);
                 }
                 const bool leader = lid == 0;
 #define KB_ROUND_SYNC() do { if (coop) __syncthreads(); else wave_sync(); } while (0)
@@ -1206,9 +1219,9 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                     const bool flip = (sInfo[c] & 0x80) != 0;
                     if (bpoly(b)) {   // kilobot a - polygon b: Box2D's A = the polygon, B = the kilobot
                         const int m = b - N;
-                        const float *T = objTab + m * OT_WORDS;
+                        const float *T = objTab + ((sInfo[c] >> 24) & 15u) * OT_WORDS;      // the fixture that is touched
                         PolyCon pc;
-                        poly_contact_setup(T, pos[b].x, pos[b].y, objA[m], mk2(pos[a].x, pos[a].y), p.r_bot, p.im_bot, pc);
+                        poly_contact_setup(T, body_xf(ox, b), pos[b].x, pos[b].y, mk2(pos[a].x, pos[a].y), p.r_bot, p.im_bot, pc);
                         const float acc = sAcc[c];
                         const float Px = acc * pc.normal.x, Py = acc * pc.normal.y;
                         objW[m] -= T[OT_II] * (pc.rA.x * Py - pc.rA.y * Px);
@@ -1232,9 +1245,9 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                         const bool flip = (sInfo[c] & 0x80) != 0;
                         if (bpoly(b)) {   // kilobot a - polygon b: one point, friction sqrt(0 * f) = 0
                             const int m = b - N;
-                            const float *T = objTab + m * OT_WORDS;
+                            const float *T = objTab + ((sInfo[c] >> 24) & 15u) * OT_WORDS;
                             PolyCon pc;
-                            poly_contact_setup(T, pos[b].x, pos[b].y, objA[m], mk2(pos[a].x, pos[a].y), p.r_bot, p.im_bot, pc);
+                            poly_contact_setup(T, body_xf(ox, b), pos[b].x, pos[b].y, mk2(pos[a].x, pos[a].y), p.r_bot, p.im_bot, pc);
                             const float wA = objW[m];
                             const float dvx = (vel[a].x - vel[b].x) - (-wA * pc.rA.y), dvy = (vel[a].y - vel[b].y) - (wA * pc.rA.x);
                             const float vn = dvx * pc.normal.x + dvy * pc.normal.y;
@@ -1282,7 +1295,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                     const int a = pr & 0xFFFF, b = pr >> 16;
                     const int owner = a < WALL_CODE ? a : b;
                     const float acc = sAcc[c];
-                    const unsigned key16 = a >= WALL_CODE ? (unsigned)a : (b >= N ? (unsigned)(OBJ_CODE + (b - N)) : (unsigned)b);
+                    const unsigned key16 = a >= WALL_CODE ? (unsigned)a : (b >= N ? (unsigned)OBJ_CODE + ((inf >> 24) & 15u) : (unsigned)b);
                     const unsigned pos = (unsigned)newOff[owner] + (unsigned)sl;
                     if (pos >= (unsigned)p.cap) continue;
                     if (newInLds) { oldKey[pos] = (unsigned short)key16; oldAcc[pos] = acc; }
@@ -1340,10 +1353,10 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                             // b2PositionSolverManifold e_faceA, A = polygon b, B = kilobot a; the manifold is the one of
                             // the start-of-substep poses
                             const int m = b - N;
-                            const float *T = objTab + m * OT_WORDS;
+                            const float *T = objTab + ((sInfo[c] >> 24) & 15u) * OT_WORDS;
                             V2 ln, lp;
-                            collide_poly_circle(T, xf_make(start[b].x, start[b].y, objA0[m]), mk2(start[a].x, start[a].y), p.r_bot, ln, lp);
-                            const XF xo = xf_make(pos[b].x, pos[b].y, objA[m]);
+                            collide_poly_circle(T, xf_of_body(objBody + m * BT_WORDS, start[b].x, start[b].y, objA0[m]), mk2(start[a].x, start[a].y), p.r_bot, ln, lp);
+                            const XF xo = body_xf(ox, b);
                             const V2 normal = rot_mul(xo, ln);
                             const V2 planePoint = xf_mul(xo, lp);
                             const V2 clipPoint = mk2(pos[a].x, pos[a].y);
@@ -1438,7 +1451,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                 cand[q] = i;
                 lPair[i] = (unsigned)b; cTh0[i] = sth0[q]; cTh[i] = th[q]; cW[i] = bw[q];
             }
-            if (tid < M && objTab[tid * OT_WORDS + OT_KIND] == 0.0f) {   // circles only: no continuous step for polygons
+            if (tid < M && objBody[tid * BT_WORDS + BT_KIND] == 0.0f) {   // circles only: no continuous step for polygons
                 const int i = (int)atomicAdd(&misc[M_NCON], 1u);
                 if (i < capL_ / 2) { candObj = i; lPair[i] = (unsigned)(N + tid); cTh0[i] = objA0[tid]; cTh[i] = objA[tid]; cW[i] = objW[tid]; }
                 else atomicOr(&misc[M_STATUS], 8u);
@@ -1448,7 +1461,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
             for (int i = tid; i < ncand; i += nt) {
                 const int b = (int)lPair[i];
                 const bool isObj = b >= N;
-                const float R = isObj ? objTab[(b - N) * OT_WORDS + OT_RADIUS] : p.r_bot, im = isObj ? objTab[(b - N) * OT_WORDS + OT_IM] : p.im_bot;
+                const float R = isObj ? objBody[(b - N) * BT_WORDS + BT_RADIUS] : p.r_bot, im = isObj ? objBody[(b - N) * BT_WORDS + BT_IM] : p.im_bot;
                 float x_ = pos[b].x, y_ = pos[b].y, a_ = cTh[i], vx_ = vel[b].x, vy_ = vel[b].y, w_ = cW[i];
                 kb_toi_walls_body(p, R, im, start[b].x, start[b].y, cTh0[i], x_, y_, a_, vx_, vy_, w_);
                 pos[b].x = x_; pos[b].y = y_; vel[b].x = vx_; vel[b].y = vy_; cTh[i] = a_; cW[i] = w_;
@@ -1481,6 +1494,10 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
     if (tid < M && p.n_substeps > 0) {
         const size_t oi = (size_t)e * M + tid;
         g.ox[oi] = pos[N + tid].x; g.oy[oi] = pos[N + tid].y; g.otheta[oi] = objA[tid];
+        if (objBody[tid * BT_WORDS + BT_LCX] != 0.0f || objBody[tid * BT_WORDS + BT_LCY] != 0.0f) {   // b2Body::SynchronizeTransform
+            const XF t = body_xf(ox, N + tid);
+            g.ox[oi] = t.p.x; g.oy[oi] = t.p.y;
+        }
         g.ovx[oi] = vel[N + tid].x; g.ovy[oi] = vel[N + tid].y; g.ow[oi] = objW[tid];
     }
     if (tid == 0) {

@@ -200,16 +200,18 @@ class KilobotsEnv(object):
         kbs = self._kilobots
         if len(kbs) == 0:
             raise ValueError('the configured scene has no kilobots')
-        specs = []
-        for ob in self._objects:
+        specs, fixture_body = [], []
+        for i, ob in enumerate(self._objects):
             if isinstance(ob, Kilobot) or not hasattr(ob, '_shape_spec'):
-                raise UnknownObjectException('pushable objects must be lib.Circle, lib.Quad / CornerQuad or a single-fixture lib.Polygon')
+                raise UnknownObjectException('pushable objects must be lib.Circle, lib.Quad / CornerQuad or a lib.Polygon')
             try:
-                specs.append(ob._shape_spec())
+                fixtures = ob._shape_spec()
             except NotImplementedError as err:
                 raise UnknownObjectException(str(err))
-        if len(self._objects) > nat.MAX_OBJECTS:
-            raise UnknownObjectException('at most %d objects per env' % nat.MAX_OBJECTS)
+            specs.extend(fixtures)
+            fixture_body.extend([i] * len(fixtures))
+        if len(specs) > nat.MAX_OBJECTS:
+            raise UnknownObjectException('at most %d fixtures (convex parts of all objects) per env' % nat.MAX_OBJECTS)
         kinds = {type(k).drive_mode for k in kbs}
         if len(kinds) != 1:
             raise ValueError('all kilobots of an env must share one drive law (got %s)' % sorted(kinds))
@@ -225,10 +227,11 @@ class KilobotsEnv(object):
                          bot_angular_damping=float(type(kbs[0])._angular_damping))
         if self._objects:
             ob0 = type(self._objects[0])
-            pad = nat.MAX_OBJECTS - len(self._objects)
+            pad = nat.MAX_OBJECTS - len(specs)
             radii = [sp[1] for sp in specs] + [0.075] * pad
             verts = [[list(v) for v in sp[2]] + [[0.0, 0.0]] * (nat.MAX_POLY_VERTS - len(sp[2])) for sp in specs]
             overrides.update(num_objects=len(self._objects), obj_radius=radii,
+                             num_fixtures=len(specs), obj_fixture_body=fixture_body + [0] * pad,
                              obj_shape=[sp[0] for sp in specs] + [0] * pad,
                              obj_nverts=[len(sp[2]) for sp in specs] + [0] * pad,
                              obj_verts=verts + [[[0.0, 0.0]] * nat.MAX_POLY_VERTS] * pad,

@@ -3,8 +3,9 @@
 Drop-in for the reference's `YamlKilobotsEnv` / `EnvConfiguration`
 (gym_kilobots/envs/yaml_kilobots_env.py): the same YAML tags (`!EvalEnv`, `!ObjectConf`, `!LightConf`,
 `!KilobotsConf`), the same constructor (`YamlKilobotsEnv(configuration=conf)`), the same spaces and
-random-initialisation rules.  What runs on the GPU: every light model, kilobots of any drive law, circular, box and
-triangular objects.  The multi-fixture shapes (`l_shape`, `t_shape`, `c_shape`) raise `UnknownObjectException` at reset().
+random-initialisation rules.  What runs on the GPU: every light model, kilobots of any drive law, every object shape
+(circle, square / rect, corner_quad, triangle, l_shape, t_shape, c_shape) as long as one env holds at most 8 convex
+fixtures in total (`UnknownObjectException` at reset() beyond that).
 """
 import random
 

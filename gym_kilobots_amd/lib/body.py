@@ -177,8 +177,8 @@ class Circle(Body):
         return ('ox', 'oy', 'otheta')
 
     def _shape_spec(self):
-        """(kb_shape, radius [m], vertices [world units]) as the device configuration takes it."""
-        return 0, float(self._radius), []
+        """Fixtures as the device configuration takes them: a list of (kb_shape, radius [m], vertices [world units])."""
+        return [(0, float(self._radius), [])]
 
     @property
     def width(self):
@@ -208,7 +208,7 @@ class Quad(Body):
         return ('ox', 'oy', 'otheta')
 
     def _shape_spec(self):
-        return 1, 0.0, [[self._width / 2 * _world_scale, self._height / 2 * _world_scale]]      # body.py:137
+        return [(1, 0.0, [[self._width / 2 * _world_scale, self._height / 2 * _world_scale]])]      # body.py:137
 
     @property
     def width(self):
@@ -270,8 +270,8 @@ def _hull_order(points):
 
 class Polygon(Body):
     """Polygon bodies of the reference (body.py:217-262): `_shape_vertices()` lists convex sub-polygons that are
-    scaled to width x height and recentred on the area-weighted mean of their vertex means.  Bodies made of ONE
-    convex polygon with at most 4 vertices run on the device; multi-fixture shapes do not yet."""
+    scaled to width x height and recentred on the area-weighted mean of their vertex means; every sub-polygon becomes
+    one fixture of the body (at most 8 fixtures per env in total on the device)."""
 
     def __init__(self, width, height, **kwargs):
         super().__init__(**kwargs)
@@ -295,10 +295,10 @@ class Polygon(Body):
         return ('ox', 'oy', 'otheta')
 
     def _shape_spec(self):
-        if len(self._local_vertices) != 1 or not 3 <= len(self._local_vertices[0]) <= 4:
-            raise NotImplementedError('%s: bodies with several fixtures do not run on the device yet'
-                                      % type(self).__name__)
-        return 2, 0.0, [[float(x), float(y)] for x, y in _hull_order([tuple(v) for v in self._local_vertices[0] * _world_scale])]
+        if not all(3 <= len(vs) <= 4 for vs in self._local_vertices):
+            raise NotImplementedError('%s: convex fixtures of 3 or 4 vertices run on the device' % type(self).__name__)
+        return [(2, 0.0, [[float(x), float(y)] for x, y in _hull_order([tuple(v) for v in vs * _world_scale])])
+                for vs in self._local_vertices]                                         # body.py:243-251
 
     @property
     def width(self):

@@ -110,6 +110,13 @@ typedef struct kb_config {
                                                    POLYGON: counter-clockwise hull in b2PolygonShape::Set order, centred on
                                                    its centroid (body.py:226-241) */
     float wall_friction;                        /* [0.2] b2FixtureDef default of the arena chain, kilobots_env.py:46-51 */
+    /* bodies with several convex fixtures (LForm, TForm, CForm: body.py:277-334).  With num_fixtures > 0 the arrays
+     * obj_shape / obj_nverts / obj_verts / obj_radius are indexed by FIXTURE and fixture f belongs to object
+     * obj_fixture_body[f] (fixtures of one object need not be adjacent); num_fixtures == 0 means one fixture per
+     * object.  Mass, centre of mass and inertia follow b2Body::ResetMassData; ox / oy hold the body ORIGIN like
+     * Body.get_pose (body.py:63-65), ovx / ovy the velocity of the centre of mass like b2Body::GetLinearVelocity. */
+    int32_t num_fixtures;                       /* 0, or num_objects..KB_MAX_OBJECTS (at most 8 fixtures per env in total) */
+    int32_t obj_fixture_body[KB_MAX_OBJECTS];
 } kb_config;
 
 /* Device buffers of one handle.  NULL is allowed for buffers the configuration never touches

@@ -29,9 +29,8 @@
  *   - pushable objects are circles, boxes or single convex polygons (body.py:129-192, 217-262) with Box2D's
  *     full contact model among themselves and against the walls (manifolds with feature ids, Coulomb friction
  *     sqrt(f1 f2), two-point block solver, rotation); kilobot contacts are frictionless in the reference
- *     (kilobot.py:26) and central on the kilobot side.  A polygon's centre of mass is taken as its body origin
- *     (exact for boxes, ~1e-8 for the reference's Triangle); no continuous step for polygons; multi-fixture
- *     bodies (LForm, TForm, CForm) are not restated.
+ *     (kilobot.py:26) and central on the kilobot side.  Bodies may carry several convex fixtures (LForm, TForm, CForm,
+ *     body.py:277-334) with b2Body::ResetMassData's centre of mass; no continuous step for polygons.
  */
 #include "kb_oracle.h"
 
@@ -151,15 +150,17 @@ typedef struct {
     float r_bot, im_bot;            /* world radius, inverse mass */
     float kl_bot, ka_bot;           /* Pade damping factors 1/(1+h c), b2Island.cpp */
     float h;
-    float r_obj[KBO_MAX_OBJECTS], im_obj[KBO_MAX_OBJECTS], ii_obj[KBO_MAX_OBJECTS];
+    float r_obj[KBO_MAX_OBJECTS];   /* per fixture: contact radius (circle) / bounding radius about the body's centre of mass */
+    float im_obj[KBO_MAX_OBJECTS], ii_obj[KBO_MAX_OBJECTS];   /* per object: inverse mass, inverse inertia about the centre of mass */
+    v2 lc_obj[KBO_MAX_OBJECTS];     /* per object: b2Sweep::localCenter (centre of mass in the body frame) */
     float kl_obj, ka_obj;
-    shape_t shape[KBO_MAX_OBJECTS];
+    int nfix, fix_body[KBO_MAX_OBJECTS];
+    shape_t shape[KBO_MAX_OBJECTS]; /* per fixture, body frame */
     float mu_oo, mu_ow;             /* b2MixFriction: sqrt(f1 * f2) */
 } derived_t;
 
-/* b2PolygonShape::ComputeMass (triangle fan about the vertex average); inertia about the centre of mass as
- * b2Body::ResetMassData leaves it */
-static void polygon_mass(const shape_t *sh, float density, float *mass, float *inertia) {
+/* b2PolygonShape::ComputeMass (triangle fan about the vertex average): mass, centroid, inertia about the body origin */
+static void polygon_mass(const shape_t *sh, float density, float *mass, v2 *centroid, float *inertia) {
     v2 center = V2(0.0f, 0.0f), s = V2(0.0f, 0.0f);
     float area = 0.0f, I = 0.0f;
     for (int i = 0; i < sh->n; ++i) s = v_add(s, sh->v[i]);
@@ -180,8 +181,7 @@ static void polygon_mass(const shape_t *sh, float density, float *mass, float *i
     v2 c = v_add(center, s);
     float Io = density * I;
     Io += m * (v_dot(c, c) - v_dot(center, center));
-    Io -= m * v_dot(c, c);                     /* b2Body::ResetMassData: about the centre of mass */
-    *mass = m; *inertia = Io;
+    *mass = m; *centroid = c; *inertia = Io;
 }
 
 static void derive(const kbo_config *c, derived_t *d) {
@@ -205,16 +205,23 @@ static void derive(const kbo_config *c, derived_t *d) {
     d->im_bot = m > 0.0f ? 1.0f / m : 0.0f;
     d->kl_bot = 1.0f / (1.0f + d->h * c->bot_linear_damping);
     d->ka_bot = 1.0f / (1.0f + d->h * c->bot_angular_damping);
+    d->nfix = c->num_fixtures > 0 ? c->num_fixtures : c->num_objects;
+    float bm[KBO_MAX_OBJECTS], bi[KBO_MAX_OBJECTS];
+    v2 bc[KBO_MAX_OBJECTS];
+    for (int m = 0; m < KBO_MAX_OBJECTS; ++m) { bm[m] = 0.0f; bi[m] = 0.0f; bc[m] = V2(0.0f, 0.0f); d->fix_body[m] = m; }
     for (int k = 0; k < KBO_MAX_OBJECTS; ++k) {
         shape_t *sh = &d->shape[k];
         memset(sh, 0, sizeof(*sh));
+        if (k >= d->nfix) { d->r_obj[k] = 0.0f; continue; }
+        if (c->num_fixtures > 0) d->fix_body[k] = c->obj_fixture_body[k];
         sh->kind = c->obj_shape[k];
         float mo, io;
+        v2 ce = V2(0.0f, 0.0f);
         if (sh->kind == KBO_SHAPE_CIRCLE) {
-            d->r_obj[k] = c->obj_radius[k] * WORLD_SCALE;
-            sh->radius = d->r_obj[k]; sh->bound = d->r_obj[k];
-            mo = c->obj_density * B2_PI * d->r_obj[k] * d->r_obj[k];     /* b2CircleShape::ComputeMass */
-            io = mo * (0.5f * d->r_obj[k] * d->r_obj[k]);                /* I = mass * (0.5 r^2 + |p|^2), p = 0 */
+            float r = c->obj_radius[k] * WORLD_SCALE;
+            sh->radius = r;
+            mo = c->obj_density * B2_PI * r * r;                           /* b2CircleShape::ComputeMass */
+            io = mo * (0.5f * r * r);                                      /* I = mass * (0.5 r^2 + |p|^2), p = 0 */
         } else {
             if (sh->kind == KBO_SHAPE_BOX) {                               /* b2PolygonShape::SetAsBox */
                 float hx = c->obj_verts[k][0][0], hy = c->obj_verts[k][0][1];
@@ -230,14 +237,28 @@ static void derive(const kbo_config *c, derived_t *d) {
                 }
             }
             sh->radius = B2_POLYGON_RADIUS;
-            float far2 = 0.0f;
-            for (int i = 0; i < sh->n; ++i) far2 = fmaxf(far2, v_dot(sh->v[i], sh->v[i]));
-            sh->bound = sqrtf(far2) + B2_POLYGON_RADIUS;
-            d->r_obj[k] = sh->bound;
-            polygon_mass(sh, c->obj_density, &mo, &io);
+            polygon_mass(sh, c->obj_density, &mo, &ce, &io);
         }
-        d->im_obj[k] = mo > 0.0f ? 1.0f / mo : 0.0f;
-        d->ii_obj[k] = io > 0.0f ? 1.0f / io : 0.0f;
+        /* b2Body::ResetMassData: accumulate over the fixtures of the body */
+        const int m = d->fix_body[k];
+        bm[m] += mo; bc[m] = v_add(bc[m], v_scale(mo, ce)); bi[m] += io;
+    }
+    for (int m = 0; m < KBO_MAX_OBJECTS; ++m) {
+        d->lc_obj[m] = V2(0.0f, 0.0f);
+        if (bm[m] > 0.0f) {
+            d->im_obj[m] = 1.0f / bm[m];
+            d->lc_obj[m] = v_scale(d->im_obj[m], bc[m]);
+        } else d->im_obj[m] = 0.0f;
+        float io = bi[m] - bm[m] * v_dot(d->lc_obj[m], d->lc_obj[m]);     /* inertia about the centre of mass */
+        d->ii_obj[m] = io > 0.0f ? 1.0f / io : 0.0f;
+    }
+    for (int k = 0; k < d->nfix; ++k) {           /* bounding radius about the centre of mass of the body */
+        shape_t *sh = &d->shape[k];
+        if (sh->kind == KBO_SHAPE_CIRCLE) { sh->bound = sh->radius; d->r_obj[k] = sh->radius; continue; }
+        float far2 = 0.0f;
+        for (int i = 0; i < sh->n; ++i) { v2 q = v_sub(sh->v[i], d->lc_obj[d->fix_body[k]]); far2 = fmaxf(far2, v_dot(q, q)); }
+        sh->bound = sqrtf(far2) + B2_POLYGON_RADIUS;
+        d->r_obj[k] = sh->bound;
     }
     d->mu_oo = sqrtf(c->obj_friction * c->obj_friction);
     d->mu_ow = sqrtf(c->obj_friction * c->wall_friction);
@@ -377,7 +398,7 @@ typedef struct {
     float ra, rb;
     int owner, slot;    /* warm-start slot (owner bot, slot index) or -1 */
     /* kilobot - polygon object (b2CollidePolygonAndCircle; Box2D's A = the polygon = body b, B = the kilobot = body a) */
-    int poly;
+    int poly, fix;      /* fix: the fixture of the object that is touched */
     v2 ln, lp;          /* manifold: localNormal, localPoint in the polygon's frame */
     v2 rA;              /* velocity phase: contact point relative to the polygon's centre */
     float nmass;        /* velocity phase: normalMass */
@@ -391,7 +412,7 @@ typedef struct {
 } manifold_t;
 typedef struct {
     int a, b;                   /* bodies; a = -1 - wall for a wall */
-    int owner, col;             /* warm-start table entry ows[owner object][col] */
+    int owner, col;             /* warm-start table entry ows[owner fixture][col]: col = partner fixture or 8 + wall */
     manifold_t m;
     float friction, radA, radB;
     float nimp[2], timp[2];
@@ -418,6 +439,7 @@ typedef struct {
     int *cell_start, *cell_items;
     contact_t *con; int ncon, cap;
     mc_t mc[MAX_MC]; int nmc;
+    const derived_t *d;
     float *ang;            /* working copy of the object angles (index N + m) */
     int *parent; unsigned char *active, *next_active;
     int *woff, *wnoff;     /* packed warm-start offsets: previous / next substep */
@@ -449,7 +471,7 @@ static void add_contact(work_t *w, int a, int b, int cls, int group, float ima, 
     contact_t *c = &w->con[w->ncon++];
     c->a = a; c->b = b; c->cls = cls; c->group = group; c->ima = ima; c->imb = imb;
     c->ra = ra; c->rb = rb; c->acc = acc; c->owner = owner; c->slot = slot; c->nx = 0; c->ny = 0;
-    c->poly = 0; c->ln = V2(0.0f, 0.0f); c->lp = V2(0.0f, 0.0f); c->rA = V2(0.0f, 0.0f); c->nmass = 0.0f;
+    c->poly = 0; c->fix = 0; c->ln = V2(0.0f, 0.0f); c->lp = V2(0.0f, 0.0f); c->rA = V2(0.0f, 0.0f); c->nmass = 0.0f;
 }
 
 static inline float wall_dist(const derived_t *d, int wl, float x, float y, float *nx, float *ny);
@@ -628,9 +650,16 @@ static void collide_wall_poly(manifold_t *m, const derived_t *d, int wl, const s
     m->count = pc;
 }
 
+/* b2Body::SynchronizeTransform: q from the angle, p = c - q * localCenter (c = centre of mass) */
+static inline xf_t xf_of_body(const derived_t *d, int m, v2 c, float a) {
+    xf_t t = xf_make(0.0f, 0.0f, a);
+    const v2 lc = d->lc_obj[m];
+    t.p = V2(c.x - (t.c * lc.x - t.s * lc.y), c.y - (t.s * lc.x + t.c * lc.y));
+    return t;
+}
 static inline xf_t body_xf(const work_t *w, int b) {
     if (b < 0) { xf_t t; t.p = V2(0.0f, 0.0f); t.s = 0.0f; t.c = 1.0f; return t; }     /* static arena body */
-    return xf_make(w->px[b], w->py[b], w->ang[b]);
+    return xf_of_body(w->d, b - w->N, V2(w->px[b], w->py[b]), w->ang[b]);
 }
 
 /* previous manifold of the same pair -> impulses of the points whose feature id is unchanged (b2Contact::Update) */
@@ -643,48 +672,54 @@ static void mc_warm(const kbo_state *st, int e, mc_t *c) {
     }
 }
 
-/* all object-object and object-wall manifolds of one env, in canonical order */
+/* all object-object and object-wall manifolds of one env, in canonical order: fixture pairs (f1 < f2, different
+ * bodies) lexicographically, then (fixture, wall) */
 static void detect_mc(const derived_t *d, const kbo_state *st, int e, work_t *w) {
-    const int N = w->N, M = w->M;
+    const int N = w->N, F = d->nfix;
     w->nmc = 0;
-    for (int m1 = 0; m1 < M; ++m1)
-        for (int m2 = m1 + 1; m2 < M; ++m2) {
-            const shape_t *s1 = &d->shape[m1], *s2 = &d->shape[m2];
-            {   /* bounding circles (stand-in for the broadphase; never rejects a touching pair) */
+    for (int f1 = 0; f1 < F; ++f1)
+        for (int f2 = f1 + 1; f2 < F; ++f2) {
+            const int m1 = d->fix_body[f1], m2 = d->fix_body[f2];
+            if (m1 == m2) continue;                         /* fixtures of one body never collide */
+            const shape_t *s1 = &d->shape[f1], *s2 = &d->shape[f2];
+            {   /* bounding circles about the centres of mass (stand-in for the broadphase; never rejects a touching pair) */
                 float dx = w->px[N + m2] - w->px[N + m1], dy = w->py[N + m2] - w->py[N + m1];
                 float rb = s1->bound + s2->bound;
                 if (dx * dx + dy * dy > rb * rb) continue;
             }
             mc_t c; memset(&c, 0, sizeof(c));
-            c.owner = m1; c.col = m2; c.friction = d->mu_oo;
+            c.owner = f1; c.col = f2; c.friction = d->mu_oo;
             if (s1->kind == KBO_SHAPE_CIRCLE && s2->kind == KBO_SHAPE_CIRCLE) {      /* b2CollideCircles */
                 float dx = w->px[N + m2] - w->px[N + m1], dy = w->py[N + m2] - w->py[N + m1];
                 float rr = s1->radius + s2->radius;
                 if (dx * dx + dy * dy > rr * rr) continue;
                 c.a = N + m1; c.b = N + m2; c.m.type = 0; c.m.count = 1; c.m.id[0] = 0;
                 c.m.localPoint = V2(0.0f, 0.0f); c.m.lp[0] = V2(0.0f, 0.0f);
+                c.radA = s1->radius; c.radB = s2->radius;
             } else if (s1->kind != KBO_SHAPE_CIRCLE && s2->kind != KBO_SHAPE_CIRCLE) {
                 c.a = N + m1; c.b = N + m2;
                 xf_t xa = body_xf(w, c.a), xb = body_xf(w, c.b);
                 collide_polygons(&c.m, s1, &xa, s2, &xb);
                 if (c.m.count == 0) continue;
+                c.radA = s1->radius; c.radB = s2->radius;
             } else {                                                                   /* polygon is fixture A */
-                const int mp = s1->kind != KBO_SHAPE_CIRCLE ? m1 : m2, mcirc = mp == m1 ? m2 : m1;
-                c.a = N + mp; c.b = N + mcirc;
+                const int fp = s1->kind != KBO_SHAPE_CIRCLE ? f1 : f2, fc = fp == f1 ? f2 : f1;
+                c.a = N + d->fix_body[fp]; c.b = N + d->fix_body[fc];
                 xf_t xa = body_xf(w, c.a);
                 v2 ln, lp;
-                if (!collide_poly_circle(&d->shape[mp], &xa, V2(w->px[c.b], w->py[c.b]), d->shape[mcirc].radius, &ln, &lp)) continue;
+                if (!collide_poly_circle(&d->shape[fp], &xa, V2(w->px[c.b], w->py[c.b]), d->shape[fc].radius, &ln, &lp)) continue;
                 c.m.type = 1; c.m.count = 1; c.m.localNormal = ln; c.m.localPoint = lp; c.m.lp[0] = V2(0.0f, 0.0f); c.m.id[0] = 0;
+                c.radA = d->shape[fp].radius; c.radB = d->shape[fc].radius;
             }
-            c.radA = d->shape[c.a - N].radius; c.radB = d->shape[c.b - N].radius;
             mc_warm(st, e, &c);
             w->mc[w->nmc++] = c;
         }
-    for (int m = 0; m < M; ++m)
+    for (int f = 0; f < F; ++f)
         for (int wl = 0; wl < 4; ++wl) {
-            const shape_t *sh = &d->shape[m];
+            const shape_t *sh = &d->shape[f];
+            const int m = d->fix_body[f];
             mc_t c; memset(&c, 0, sizeof(c));
-            c.a = -1 - wl; c.b = N + m; c.owner = m; c.col = 8 + wl; c.friction = d->mu_ow;
+            c.a = -1 - wl; c.b = N + m; c.owner = f; c.col = 8 + wl; c.friction = d->mu_ow;
             c.radA = B2_POLYGON_RADIUS; c.radB = sh->radius;
             if (sh->kind == KBO_SHAPE_CIRCLE) {                                        /* b2CollideEdgeAndCircle, region AB */
                 float nx, ny; float dist = wall_dist(d, wl, w->px[N + m], w->py[N + m], &nx, &ny);
@@ -770,26 +805,29 @@ static void detect_env(const kbo_config *cfg, const derived_t *d, const kbo_stat
             nslot++;
             add_contact(w, -1 - wl, a, CLS_WALL, a, 0.0f, d->im_bot, B2_POLYGON_RADIUS, d->r_bot, acc, a, slot);
         }
-        /* pushable objects: b2CollideCircles / b2CollidePolygonAndCircle kilobot - object */
-        for (int m = 0; m < w->M; ++m) {
-            const shape_t *sh = &d->shape[m];
+        /* pushable objects: b2CollideCircles / b2CollidePolygonAndCircle kilobot - fixture f of object m */
+        for (int f = 0; f < d->nfix; ++f) {
+            const shape_t *sh = &d->shape[f];
+            const int m = d->fix_body[f];
             float dx = w->px[N + m] - w->px[a], dy = w->py[N + m] - w->py[a];
-            float ro = d->r_bot + d->r_obj[m];                  /* circle: contact radius; polygon: bounding radius */
+            float ro = d->r_bot + d->r_obj[f];                  /* circle: contact radius; polygon: bounding radius */
             if (dx * dx + dy * dy > ro * ro) continue;
             v2 ln = V2(0.0f, 0.0f), lp = V2(0.0f, 0.0f);
             if (sh->kind != KBO_SHAPE_CIRCLE) {
                 xf_t xo = body_xf(w, N + m);
                 if (!collide_poly_circle(sh, &xo, V2(w->px[a], w->py[a]), d->r_bot, &ln, &lp)) continue;
             }
-            float acc = ws_lookup(st, w, e, a, KEY_OBJ + (unsigned)m);
+            float acc = ws_lookup(st, w, e, a, KEY_OBJ + (unsigned)f);
             if (acc < 0.0f) acc = 0.0f;
             int slot = nslot < S ? nslot : -1;
             if (slot < 0) w->status |= 2;
             nslot++;
-            add_contact(w, a, N + m, CLS_BOT_OBJ, m, d->im_bot, d->im_obj[m], d->r_bot, sh->radius, acc, a, slot);
-            if (sh->kind != KBO_SHAPE_CIRCLE && w->ncon > 0 && w->con[w->ncon - 1].a == a && w->con[w->ncon - 1].b == N + m) {
+            const int before = w->ncon;
+            add_contact(w, a, N + m, CLS_BOT_OBJ, f, d->im_bot, d->im_obj[m], d->r_bot, sh->radius, acc, a, slot);
+            if (w->ncon > before) {
                 contact_t *c = &w->con[w->ncon - 1];
-                c->poly = 1; c->ln = ln; c->lp = lp;
+                c->fix = f;
+                if (sh->kind != KBO_SHAPE_CIRCLE) { c->poly = 1; c->ln = ln; c->lp = lp; }
             }
         }
     }
@@ -1082,8 +1120,8 @@ static float mc_solve_position(const derived_t *d, work_t *w, mc_t *c) {
     float minSeparation = 0.0f;
     for (int j = 0; j < c->m.count; ++j) {
         xf_t xfA, xfB;
-        if (c->a < 0) { xfA.p = V2(0.0f, 0.0f); xfA.s = 0.0f; xfA.c = 1.0f; } else xfA = xf_make(A.c.x, A.c.y, A.a);
-        xfB = xf_make(B.c.x, B.c.y, B.a);
+        if (c->a < 0) { xfA.p = V2(0.0f, 0.0f); xfA.s = 0.0f; xfA.c = 1.0f; } else xfA = xf_of_body(d, c->a - w->N, A.c, A.a);
+        xfB = xf_of_body(d, c->b - w->N, B.c, B.a);
         v2 normal, point; float separation;
         if (c->m.type == 0) {                               /* b2PositionSolverManifold */
             v2 pointA = xf_mul(&xfA, c->m.localPoint), pointB = xf_mul(&xfB, c->m.lp[0]);
@@ -1212,7 +1250,7 @@ static void world_step_env(const kbo_config *cfg, const derived_t *d, kbo_state 
     }
     /* StoreImpulses -> warm-start cache of the next substep */
     memset(st->ws_cnt + (size_t)e * N, 0, (size_t)N);
-    for (int m = 0; m < w->M; ++m)
+    for (int m = 0; m < d->nfix; ++m)
         for (int k = 0; k < OWS * OWW; ++k) st->ows_acc[((size_t)e * KBO_MAX_OBJECTS + m) * OWS * OWW + k] = -1.0f;
     for (int i = 0; i < w->nmc; ++i) {
         const mc_t *c = &w->mc[i];
@@ -1235,7 +1273,7 @@ static void world_step_env(const kbo_config *cfg, const derived_t *d, kbo_state 
         int pos = w->wnoff[c->owner] + c->slot;
         if (pos >= w->cap) continue;
         size_t idx = (size_t)e * w->cap + (size_t)pos;
-        unsigned key = c->a < 0 ? KEY_WALL + (unsigned)(-1 - c->a) : (c->b >= N ? KEY_OBJ + (unsigned)(c->b - N) : (unsigned)c->b);
+        unsigned key = c->a < 0 ? KEY_WALL + (unsigned)(-1 - c->a) : (c->b >= N ? KEY_OBJ + (unsigned)c->fix : (unsigned)c->b);
         st->ws_key[idx] = key; st->ws_acc[idx] = c->acc;
     }
     /* integrate positions */
@@ -1341,9 +1379,10 @@ static void world_step_env(const kbo_config *cfg, const derived_t *d, kbo_state 
         for (int b = 0; b < N; ++b)
             toi_walls_body(cfg, d, d->r_bot, d->im_bot, w->x0[b], w->y0[b], w->a0[b], &w->px[b], &w->py[b],
                            &st->theta[(size_t)e * N + b], &w->vx[b], &w->vy[b], &w->bw[b]);
-        for (int m = 0; m < w->M; ++m) {
-            if (d->shape[m].kind != KBO_SHAPE_CIRCLE) continue;       /* polygons: no continuous step (see header) */
-            toi_walls_body(cfg, d, d->r_obj[m], d->im_obj[m], w->x0[N + m], w->y0[N + m], w->a0[N + m], &w->px[N + m],
+        for (int f = 0; f < d->nfix; ++f) {
+            if (d->shape[f].kind != KBO_SHAPE_CIRCLE) continue;       /* polygons: no continuous step (see header) */
+            const int m = d->fix_body[f];
+            toi_walls_body(cfg, d, d->r_obj[f], d->im_obj[m], w->x0[N + m], w->y0[N + m], w->a0[N + m], &w->px[N + m],
                            &w->py[N + m], &w->ang[N + m], &w->vx[N + m], &w->vy[N + m], &w->bw[N + m]);
         }
     }
@@ -1425,6 +1464,11 @@ static void substep_env(const kbo_config *cfg, const derived_t *d, kbo_state *st
         w->px[N + m] = st->ox[oi]; w->py[N + m] = st->oy[oi];
         w->vx[N + m] = st->ovx[oi]; w->vy[N + m] = st->ovy[oi]; w->bw[N + m] = st->ow[oi];
         w->ang[N + m] = st->otheta[oi];
+        if (d->lc_obj[m].x != 0.0f || d->lc_obj[m].y != 0.0f) {    /* state holds the body origin, the solver the centre of mass */
+            xf_t t = xf_make(st->ox[oi], st->oy[oi], st->otheta[oi]);
+            v2 cm = xf_mul(&t, d->lc_obj[m]);
+            w->px[N + m] = cm.x; w->py[N + m] = cm.y;
+        }
     }
     world_step_env(cfg, d, st, e, w);
     for (int b = 0; b < N; ++b) { st->x[o + b] = w->px[b]; st->y[o + b] = w->py[b]; }
@@ -1433,6 +1477,10 @@ static void substep_env(const kbo_config *cfg, const derived_t *d, kbo_state *st
         st->ox[oi] = w->px[N + m]; st->oy[oi] = w->py[N + m];
         st->ovx[oi] = w->vx[N + m]; st->ovy[oi] = w->vy[N + m]; st->ow[oi] = w->bw[N + m];
         st->otheta[oi] = w->ang[N + m];
+        if (d->lc_obj[m].x != 0.0f || d->lc_obj[m].y != 0.0f) {    /* b2Body::SynchronizeTransform */
+            xf_t t = xf_of_body(d, m, V2(w->px[N + m], w->py[N + m]), w->ang[N + m]);
+            st->ox[oi] = t.p.x; st->oy[oi] = t.p.y;
+        }
     }
     if (st->status) st->status[e] |= w->status;
 }
@@ -1451,7 +1499,7 @@ int kbo_contact_capacity(const kbo_config *cfg) {
 static int work_alloc(work_t *w, const kbo_config *cfg, const derived_t *d) {
     memset(w, 0, sizeof(*w));
     int N = cfg->num_bots, M = cfg->num_objects, T = N + M;
-    w->N = N; w->M = M; w->S = cfg->ws_slots;
+    w->N = N; w->M = M; w->S = cfg->ws_slots; w->d = d;
     w->px = (float *)malloc(sizeof(float) * T * 9);
     w->py = w->px + T; w->vx = w->py + T; w->vy = w->vx + T; w->bw = w->vy + T;
     w->x0 = w->bw + T; w->y0 = w->x0 + T; w->a0 = w->y0 + T; w->ang = w->a0 + T;
@@ -1531,6 +1579,11 @@ int kbo_count_contacts(const kbo_config *cfg, const kbo_state *st, int env, int 
         w.px[cfg->num_bots + m] = st->ox[(size_t)env * cfg->num_objects + m];
         w.py[cfg->num_bots + m] = st->oy[(size_t)env * cfg->num_objects + m];
         w.ang[cfg->num_bots + m] = st->otheta[(size_t)env * cfg->num_objects + m];
+        if (d.lc_obj[m].x != 0.0f || d.lc_obj[m].y != 0.0f) {
+            xf_t t = xf_make(w.px[cfg->num_bots + m], w.py[cfg->num_bots + m], w.ang[cfg->num_bots + m]);
+            v2 cm = xf_mul(&t, d.lc_obj[m]);
+            w.px[cfg->num_bots + m] = cm.x; w.py[cfg->num_bots + m] = cm.y;
+        }
     }
     detect_env(cfg, &d, st, env, &w);
     int nb = 0, nw = 0;

@@ -48,6 +48,7 @@ class Config(C.Structure):
         ('obj_shape', C.c_int32 * MAX_OBJECTS), ('obj_nverts', C.c_int32 * MAX_OBJECTS),
         ('obj_verts', ((C.c_float * 2) * MAX_POLY_VERTS) * MAX_OBJECTS),
         ('wall_friction', C.c_float),
+        ('num_fixtures', C.c_int32), ('obj_fixture_body', C.c_int32 * MAX_OBJECTS),
     ]
 
 

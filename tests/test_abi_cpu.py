@@ -30,7 +30,7 @@ def test_exports_every_declared_symbol(lib):
 def test_struct_sizes_match_header():
     # 3 ints, 2+1 floats, 2 ints, 2 ints, 4+1 floats, 8 floats, 1 float, 1 int, 8 floats, 4 floats, 1 int
     # ... + solver_mode, light_count, light_kind[4], 2 x [4], 4 x [4][2]
-    assert C.sizeof(nat.KbConfig) == 4 * (3 + 3 + 2 + 2 + 5 + 8 + 1 + 1 + 8 + 4 + 1 + 1 + 1 + 4 + 8 + 32 + 8 + 8 + 64 + 1)
+    assert C.sizeof(nat.KbConfig) == 4 * (3 + 3 + 2 + 2 + 5 + 8 + 1 + 1 + 8 + 4 + 1 + 1 + 1 + 4 + 8 + 32 + 8 + 8 + 64 + 1 + 1 + 8)
     assert C.sizeof(nat.KbBuffers) == 8 * len(nat.BUFFER_FIELDS)
 
 

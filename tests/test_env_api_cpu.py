@@ -172,7 +172,7 @@ def test_env_with_a_pushable_box_and_triangle():
     np.testing.assert_allclose(box.vertices[0][2], np.array([.1, .02]) + .075, atol=1e-6)      # SetAsBox order
     # Polygon bodies are recentred on their centroid (body.py:226-241): vertex mean of a triangle is the origin
     np.testing.assert_allclose(tri.local_vertices[0].mean(0), 0.0, atol=1e-12)
-    spec = tri._shape_spec()
+    (spec,) = tri._shape_spec()                       # one fixture
     assert spec[0] == 2 and len(spec[2]) == 3
     hull = np.array(spec[2])
     assert np.allclose(hull[0], hull[hull[:, 0].argmax()])                  # starts at the right-most (lowest) vertex
@@ -186,13 +186,41 @@ def test_env_with_a_pushable_box_and_triangle():
     assert abs(obs['objects'][0, 2]) > 1e-4                                 # ... and turned (off-centre crowd)
     np.testing.assert_allclose(box.get_pose(), obs['objects'][0], atol=1e-6)
 
-    class LEnv(BoxEnv):
+    # multi-fixture bodies (the reference's TriangleTestEnv objects, kilobots_test_envs.py:98-103): 1 + 2 + 2 + 3 fixtures
+    from gym_kilobots_amd.lib import TForm, CForm
+
+    class ShapesEnv(BoxEnv):
         def _configure_environment(self):
-            self._add_object(LForm(world=self.world, width=.15, height=.15, position=(.3, .0)))
-            self._add_kilobot(SimpleVelocityControlKilobot(self.world, position=(0, 0), velocity=[0.0, 0.0]))
+            self._add_object(Triangle(world=self.world, width=.15, height=.15, position=(.0, .0)))
+            self._add_object(LForm(world=self.world, width=.15, height=.15, position=(.0, .3)))
+            self._add_object(TForm(world=self.world, width=.15, height=.15, position=(.0, -.3)))
+            self._add_object(CForm(world=self.world, width=.15, height=.15, position=(.3, .0)))
+            for i in range(6):
+                self._add_kilobot(SimpleVelocityControlKilobot(self.world, position=(0.2, 0.035 * (i - 2.5)), velocity=[0.0, 0.0]))
+
+        def get_reward(self, state, action, new_state):
+            return float(new_state['objects'][3, 0] - state['objects'][3, 0])
+
+    env = ShapesEnv(sim_factory=OracleBackend)
+    obs = env.reset()
+    assert obs['objects'].shape == (4, 3) and env.sim.cfg.num_fixtures == 8
+    assert list(env.sim.cfg.obj_fixture_body) == [0, 1, 1, 2, 2, 3, 3, 3]
+    np.testing.assert_allclose(obs['objects'][1], (.0, .3, .0), atol=1e-6)        # the state is the body origin
+    total = 0.0
+    for _ in range(30):
+        obs, r, done, info = env.step(np.tile([0.01, 0.0], (6, 1)))
+        total += r
+    assert total > 0.005 and int(env.sim.status.max()) == 0                          # the C was pushed along +x
+    assert env.objects[3].vertices.shape == (3, 4, 2)
+
+    class TooManyEnv(BoxEnv):
+        def _configure_environment(self):
+            for i in range(3):
+                self._add_object(CForm(world=self.world, width=.15, height=.15, position=(.3 * i - .3, .0)))
+            self._add_kilobot(SimpleVelocityControlKilobot(self.world, position=(0, 0.4), velocity=[0.0, 0.0]))
 
     with pytest.raises(UnknownObjectException):
-        LEnv(sim_factory=OracleBackend).reset()
+        TooManyEnv(sim_factory=OracleBackend).reset()
 
 
 def test_unsupported_scenes_fail_loudly():
@@ -342,6 +370,10 @@ def test_yaml_env_f3():
     assert o3['objects'].shape == (2, 3) and env2.objects[0].vertices.shape == (1, 4, 2)
     env2.step(np.array([0.0, 0.0, 0.0, 0.0]))
     conf.objects[0].shape = 'l_shape'
+    env3 = YamlKilobotsEnv(configuration=conf, sim_factory=OracleBackend)
+    env3.reset()
+    assert type(env3.objects[0]).__name__ == 'LForm' and env3.sim.cfg.num_fixtures == 3
+    conf.objects[0].shape = 'pentagon'
     with pytest.raises(UnknownObjectException):
         YamlKilobotsEnv(configuration=conf, sim_factory=OracleBackend).reset()
 

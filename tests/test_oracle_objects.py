@@ -228,3 +228,79 @@ def test_threads_do_not_change_results():
         return sim.poses_m(), sim.objects_m()
     a, b = run(1), run(4)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def _lform_fixtures(width=0.15, height=0.15):
+    """The reference's LForm (body.py:277-287) as lib.body.Polygon scales and recentres it: two boxes."""
+    raw = np.array([[(-0.05, 0.0), (0.1, 0.0), (0.1, 0.3), (-0.05, 0.3)],
+                    [(0.1, 0.0), (0.1, -0.15), (-0.2, -0.15), (-0.2, 0.0)]])
+    size = raw.max((0, 1)) - raw.min((0, 1))
+    v = raw / size * np.array((width, height))
+    cen, area = np.zeros(2), 0.0
+    for vs in v:
+        a = 0.5 * abs(np.dot(vs[:, 0], np.roll(vs[:, 1], 1)) - np.dot(vs[:, 1], np.roll(vs[:, 0], 1)))
+        area += a
+        cen += vs.mean(0) * a
+    return v - cen / area
+
+
+def _ccw_from_lowest_right(vs):
+    """b2PolygonShape::Set order for a convex quad given in any rotation direction."""
+    vs = np.asarray(vs)
+    x, y = vs[:, 0], vs[:, 1]
+    if np.dot(x, np.roll(y, -1)) - np.dot(y, np.roll(x, -1)) < 0:
+        vs = vs[::-1]
+    i0 = max(range(len(vs)), key=lambda i: (vs[i, 0], -vs[i, 1]))
+    return np.roll(vs, -i0, axis=0)
+
+
+def test_two_fixture_body_mass_centre_and_push():
+    fx = [_ccw_from_lowest_right(f) for f in _lform_fixtures()]
+    cfg = O.default_config(1, 1, O.DRIVE_VELOCITY, num_objects=1, num_fixtures=2, obj_fixture_body=[0, 0],
+                           obj_shape=[O.SHAPE_POLYGON, O.SHAPE_POLYGON], obj_nverts=[4, 4],
+                           obj_verts=[[(x * W, y * W) for x, y in f] for f in fx], obj_radius=[0.0, 0.0])
+    sim = O.OracleSim(cfg)
+    sim.set_poses_m([[[0.9, 0.6]]], [[0.0]])
+    sim.set_actions(None)
+    sim.set_objects_m([[[0.0, 0.0]]], [[0.4]])
+    sim.ovx[...] = 1.0
+    sim.ow[...] = 0.0
+    sim.step(1)
+    # free flight: the body ORIGIN is what the state holds (Body.get_pose); without spin it moves with the centre of mass
+    assert np.isclose(sim.ovx[0, 0], KL, rtol=1e-6) and np.isclose(sim.ox[0, 0], 0.1 * KL, rtol=1e-5, atol=1e-7)
+    assert np.isclose(sim.otheta[0, 0], 0.4, rtol=1e-6)
+    # pure spin about the centre of mass: the origin (which the reference recentres on the area-weighted vertex mean,
+    # equal to the centre of mass for two rectangles) stays put up to rounding
+    sim.set_objects_m([[[0.0, 0.0]]], [[0.0]])
+    sim.ovx[...] = 0.0
+    sim.ow[...] = 1.0
+    sim.step(5)
+    assert abs(sim.ox[0, 0]) < 1e-4 and abs(sim.oy[0, 0]) < 1e-4 and sim.otheta[0, 0] > 0.3
+    # a kilobot pushes the long arm: the L turns and moves, both fixtures can be touched
+    sim2 = O.OracleSim(cfg)
+    sim2.set_poses_m([[[-0.2, 0.06]]], [[0.0]])
+    sim2.set_objects_m([[[0.0, 0.0]]], [[0.0]])
+    sim2.set_actions(np.array([[[0.01, 0.0]]], np.float32))
+    sim2.step(250)
+    assert sim2.status[0] == 0 and sim2.ox[0, 0] > 0.01 and abs(sim2.otheta[0, 0]) > 1e-3
+
+
+def test_two_fixture_body_against_wall_and_box():
+    fx = [_ccw_from_lowest_right(f) for f in _lform_fixtures()]
+    cfg = O.default_config(1, 1, O.DRIVE_VELOCITY, num_objects=2, num_fixtures=3, obj_fixture_body=[0, 0, 1],
+                           obj_shape=[O.SHAPE_POLYGON, O.SHAPE_POLYGON, O.SHAPE_BOX], obj_nverts=[4, 4, 4],
+                           obj_verts=[[(x * W, y * W) for x, y in f] for f in fx] + [[(0.05 * W, 0.05 * W)]],
+                           obj_radius=[0.0, 0.0, 0.0])
+    sim = O.OracleSim(cfg)
+    sim.set_poses_m([[[-0.9, 0.6]]], [[0.0]])
+    sim.set_actions(None)
+    sim.set_objects_m([[[0.55, 0.0], [0.8, 0.02]]], [[0.3, 0.1]])
+    sim.ovx[0] = [10.0, 0.0]
+    m = None
+    for k in range(120):
+        sim.step(1)
+    assert sim.status[0] == 0
+    # the L shoved the box to the right wall; nothing ended up outside the arena
+    assert sim.ox[0, 1] / W > 0.85 and sim.ox[0, 1] / W < 1.0 - 0.05 + 0.002
+    assert (sim.ows_acc[0, :3, :, 0] >= 0).any()          # manifolds between fixtures / walls were active
+    del m

@@ -490,6 +490,115 @@ def test_box_wall_box_box_and_disc_manifolds():
     assert_same(osim, gsim, 'manifolds fused', OBJ_FIELDS)
 
 
+def _reference_polygon_fixtures(raw, width=0.15, height=0.15):
+    """Sub-polygons of a lib.body.Polygon subclass -> hull-ordered fixtures in world units (what the env uploads)."""
+    from gym_kilobots_amd.lib.body import _hull_order
+    v = np.array(raw, dtype=np.float64)
+    v = v / (v.max((0, 1)) - v.min((0, 1))) * np.array((width, height))
+    cen, area = np.zeros(2), 0.0
+    for vs in v:
+        a = 0.5 * abs(np.dot(vs[:, 0], np.roll(vs[:, 1], 1)) - np.dot(vs[:, 1], np.roll(vs[:, 0], 1)))
+        area += a
+        cen += vs.mean(0) * a
+    v = v - cen / area
+    return [[list(q) for q in _hull_order([tuple(x) for x in vs * 25.0])] for vs in v]
+
+
+LFORM = [[(-0.05, 0.0), (0.1, 0.0), (0.1, 0.3), (-0.05, 0.3)], [(0.1, 0.0), (0.1, -0.15), (-0.2, -0.15), (-0.2, 0.0)]]
+CFORM = [[(0.09, 0.15), (0.09, -0.15), (-0.01, -0.15), (-0.01, 0.15)], [(-0.01, -0.15), (-0.11, -0.15), (-0.11, -0.08), (-0.01, -0.05)],
+         [(-0.01, 0.15), (-0.11, 0.15), (-0.11, 0.08), (-0.01, 0.05)]]
+
+
+def _compound_kw():
+    """Objects: 0 = LForm (2 fixtures), 1 = disc, 2 = CForm (3 fixtures), 3 = box: 7 fixtures, not adjacent per body."""
+    lf, cf = _reference_polygon_fixtures(LFORM), _reference_polygon_fixtures(CFORM)
+    fixtures = [(2, lf[0], 0), (0, None, 1), (2, cf[0], 2), (2, lf[1], 0), (2, cf[1], 2), (1, [[0.05 * 25.0, 0.1 * 25.0]], 3), (2, cf[2], 2)]
+    kw = dict(num_objects=4, num_fixtures=len(fixtures), obj_fixture_body=[f[2] for f in fixtures] + [0],
+              obj_shape=[f[0] for f in fixtures], obj_nverts=[0 if f[1] is None else len(f[1]) for f in fixtures],
+              obj_radius=[0.05 if f[0] == 0 else 0.0 for f in fixtures],
+              obj_verts=[[[0.0, 0.0]] if f[1] is None else f[1] for f in fixtures])
+    return kw
+
+
+@pytest.mark.parametrize('mode', [0, 1, 2, 3])
+def test_multi_fixture_bodies_in_a_crowd(mode):
+    """LForm / CForm bodies (several convex fixtures, centre of mass off the body origin) among 256 kilobots."""
+    E, N = 3, 256
+    xy, th = scenes.gaussian_spawn(E, N, sigma=0.3, seed=63)
+    th = scenes.toward_objects_theta(xy)
+    objs = np.tile(scenes.CFG4_OBJECTS[None], (E, 1, 1))
+    oth = np.tile(np.array([0.4, 0.0, -1.2, 0.8])[None], (E, 1))
+    osim, gsim = make_pair(E, N, xy=xy, th=th, solver_mode=mode, **_compound_kw())
+    osim.set_objects_m(objs, oth)
+    gsim.set_objects_m(objs, oth)
+    a = np.zeros((E, N, 2), np.float32)
+    a[..., 0] = 0.01
+    for k in range(6):
+        osim.set_actions(a)
+        osim.step(10)
+        gsim.step(10, actions=dev(a))
+        assert_same(osim, gsim, 'compound mode %d step %d' % (mode, k), OBJ_FIELDS)
+        assert_ws_same(osim, gsim, 'compound mode %d step %d' % (mode, k))
+    assert osim.count_contacts(0, True)[2] > 3
+    assert int(cpu(gsim.status).max()) == 0
+    assert np.abs(osim.objects_m()[..., 2] - oth).max() > 1e-4
+
+
+def test_multi_fixture_bodies_collide_with_walls_and_each_other():
+    E, N = 4, 2
+    xy = np.tile(np.array([[-0.9, 0.7], [-0.85, 0.7]])[None], (E, 1, 1))
+    osim, gsim = make_pair(E, N, xy=xy, th=np.zeros((E, N)), **_compound_kw())
+    rng = np.random.default_rng(19)
+    objs = np.tile(np.array([[0.55, 0.0], [0.3, 0.05], [0.8, -0.1], [0.75, 0.35]])[None], (E, 1, 1)) + rng.uniform(-0.01, 0.01, (E, 4, 2))
+    oth = rng.uniform(-1.5, 1.5, (E, 4))
+    osim.set_objects_m(objs, oth)
+    gsim.set_objects_m(objs, oth)
+    v0 = np.tile(np.array([7.0, 12.0, 3.0, 2.0], np.float32)[None], (E, 1))
+    vy0 = np.tile(np.array([0.5, -0.5, 1.0, -4.0], np.float32)[None], (E, 1))
+    w0 = np.tile(np.array([0.5, 0.0, -0.3, 0.2], np.float32)[None], (E, 1))
+    osim.ovx[...] = v0; osim.ovy[...] = vy0; osim.ow[...] = w0
+    gsim.ovx.copy_(dev(v0)); gsim.ovy.copy_(dev(vy0)); gsim.ow.copy_(dev(w0))
+    touched = False
+    for k in range(70):
+        osim.step(1)
+        gsim.step(1)
+        assert_same(osim, gsim, 'compound manifolds substep %d' % k, OBJ_FIELDS)
+        touched |= bool((osim.ows_acc[..., 0] >= 0).any())
+    assert touched and int(cpu(gsim.status).max()) == 0
+    osim.step(30)
+    gsim.step(30)
+    assert_same(osim, gsim, 'compound manifolds fused', OBJ_FIELDS)
+
+
+def test_eight_objects_every_candidate_index():
+    """8 objects = 60 manifold candidates (28 pairs + 32 object-wall): the objects fly apart into all four walls and
+    into each other, so candidates with high indices (mask bits >= 31) are active."""
+    E, N = 2, 2
+    xy = np.tile(np.array([[0.0, 0.0], [0.04, 0.0]])[None], (E, 1, 1))
+    shapes = [('box', 0.1, 0.1), ('circle', 0.04), ('box', 0.12, 0.06), ('circle', 0.05),
+              ('poly', TRIANGLE), ('box', 0.08, 0.08), ('circle', 0.03), ('box', 0.1, 0.05)]
+    osim, gsim = make_pair(E, N, xy=xy, th=np.zeros((E, N)), num_objects=8, **_shape_kw(shapes))
+    ang = np.linspace(0, 2 * np.pi, 8, endpoint=False) + 0.2
+    objs = np.tile(np.stack([0.45 * np.cos(ang), 0.4 * np.sin(ang)], -1)[None], (E, 1, 1))
+    objs[1] *= 0.97
+    oth = np.tile(np.linspace(-1, 1, 8)[None], (E, 1))
+    osim.set_objects_m(objs, oth)
+    gsim.set_objects_m(objs, oth)
+    v = (14.0 * np.stack([np.cos(ang), np.sin(ang)], -1)).astype(np.float32)
+    osim.ovx[...] = v[:, 0]; osim.ovy[...] = v[:, 1]
+    gsim.ovx.copy_(dev(np.tile(v[None, :, 0], (E, 1)))); gsim.ovy.copy_(dev(np.tile(v[None, :, 1], (E, 1))))
+    seen = set()
+    for k in range(80):
+        osim.step(1)
+        gsim.step(1)
+        assert_same(osim, gsim, 'eight objects substep %d' % k, OBJ_FIELDS)
+        seen |= {(int(o), int(c)) for _, o, c in np.argwhere(osim.ows_acc[..., 0] >= 0)}
+    walls = {c for _, c in seen if c >= 8}
+    assert len(walls) == 4, 'all four walls should have been hit: %s' % sorted(seen)
+    assert any(o >= 6 and c >= 8 for o, c in seen), 'no high candidate index was active: %s' % sorted(seen)
+    assert int(cpu(gsim.status).max()) == 0
+
+
 def test_1024_bots_with_boxes():
     E, N = 2, 1024
     xy, th = scenes.lattice_spawn(E, N, seed=72)
