@@ -131,19 +131,33 @@ class Body:
         return np.array([c * point[0] - s * point[1] + x, s * point[0] + c * point[1] + y])
 
     def collides_with(self, other):
-        """True if a touching contact with `other` exists (reference body.py:87-90 walks Box2D's
-        contact list; here: the manifold test b2CollideCircles applies, distance <= rA + rB)."""
-        ra, rb = getattr(self, '_radius', None), getattr(other, '_radius', None)
-        if ra is None or rb is None:
-            raise NotImplementedError('collides_with is implemented for circular bodies')
-        (xa, ya, _), (xb, yb, _) = self.get_pose(), other.get_pose()
-        # compare in fp32 world units like the kernel does
-        dx = np.float32(xb * _world_scale) - np.float32(xa * _world_scale)
-        dy = np.float32(yb * _world_scale) - np.float32(ya * _world_scale)
-        rr = np.float32(ra * _world_scale) + np.float32(rb * _world_scale)
-        if np.float32(dx * dx) + np.float32(dy * dy) <= np.float32(rr * rr):
-            return True
+        """True if a touching contact with `other` exists (reference body.py:87-90 walks Box2D's contact list).  Here the
+        narrowphase predicates are evaluated on the current poses in fp32 world units: b2CollideCircles,
+        b2CollidePolygonAndCircle, and for two polygons the separating-axis stage of b2CollidePolygons (skin radii
+        included).  Returns True or None like the reference."""
+        mine, theirs = self._world_fixtures(), other._world_fixtures()
+        for fa in mine:
+            for fb in theirs:
+                if _fixtures_touch(fa, fb):
+                    return True
         return None
+
+    def _world_fixtures(self):
+        """[(kind, centre or vertices [world units], radius)] of this body at its current pose."""
+        x, y, th = self.get_pose()
+        c, s = np.cos(th), np.sin(th)
+        out = []
+        for kind, radius, verts in self._shape_spec():
+            if kind == 0:
+                out.append(('circle', np.array([x, y]) * _world_scale, radius * _world_scale))
+                continue
+            if kind == 1:
+                hx, hy = verts[0]
+                verts = [(-hx, -hy), (hx, -hy), (hx, hy), (-hx, hy)]
+            v = np.array(verts, dtype=np.float64)
+            w = np.stack([c * v[:, 0] - s * v[:, 1], s * v[:, 0] + c * v[:, 1]], -1) + np.array([x, y]) * _world_scale
+            out.append(('poly', w, 0.01))
+        return out
 
     @property
     def color(self):
@@ -166,6 +180,43 @@ class Body:
 
     def plot(self, axes, **kwargs):
         raise NotImplementedError('plotting is outside the accelerated hot path (SURVEY.md 2, component 9)')
+
+
+def _poly_normals(v):
+    e = np.roll(v, -1, axis=0) - v
+    n = np.stack([e[:, 1], -e[:, 0]], -1)
+    return n / np.linalg.norm(n, axis=1, keepdims=True)
+
+
+def _fixtures_touch(fa, fb):
+    (ka, pa, ra), (kb, pb, rb) = fa, fb
+    if ka == 'circle' and kb == 'circle':
+        d = np.float32(pb) - np.float32(pa)
+        rr = np.float32(ra) + np.float32(rb)
+        return bool(np.float32(d[0] * d[0]) + np.float32(d[1] * d[1]) <= np.float32(rr * rr))
+    if ka == 'circle':
+        return _fixtures_touch(fb, fa)
+    na = _poly_normals(pa)
+    if kb == 'circle':                                   # b2CollidePolygonAndCircle
+        radius = ra + rb
+        sep = ((pb - pa) * na).sum(1)
+        i = int(sep.argmax())
+        if sep[i] > radius:
+            return False
+        if sep[i] < 1.19209290e-07:
+            return True
+        v1, v2 = pa[i], pa[(i + 1) % len(pa)]
+        u1, u2 = np.dot(pb - v1, v2 - v1), np.dot(pb - v2, v1 - v2)
+        if u1 <= 0:
+            return bool(np.dot(pb - v1, pb - v1) <= radius * radius)
+        if u2 <= 0:
+            return bool(np.dot(pb - v2, pb - v2) <= radius * radius)
+        return True
+    nb = _poly_normals(pb)                               # b2FindMaxSeparation both ways
+    total = ra + rb
+    sep_a = max(min(np.dot(n, q - v) for q in pb) for n, v in zip(na, pa))
+    sep_b = max(min(np.dot(n, q - v) for q in pa) for n, v in zip(nb, pb))
+    return bool(sep_a <= total and sep_b <= total)
 
 
 class Circle(Body):

@@ -185,6 +185,11 @@ def test_env_with_a_pushable_box_and_triangle():
     assert total > 0.01 and obs['objects'][0, 0] > 0.11                     # pushed along +x ...
     assert abs(obs['objects'][0, 2]) > 1e-4                                 # ... and turned (off-centre crowd)
     np.testing.assert_allclose(box.get_pose(), obs['objects'][0], atol=1e-6)
+    # Body.collides_with (body.py:87-90) for every shape: the pushing kilobots touch the box, nothing touches the triangle
+    assert any(kb.collides_with(box) for kb in env.kilobots) and any(box.collides_with(kb) for kb in env.kilobots)
+    assert all(kb.collides_with(tri) is None for kb in env.kilobots) and box.collides_with(tri) is None
+    tri.set_pose((obs['objects'][0][0] + 0.12, obs['objects'][0][1], 0.0))
+    assert box.collides_with(tri) is True and tri.collides_with(box) is True
 
     # multi-fixture bodies (the reference's TriangleTestEnv objects, kilobots_test_envs.py:98-103): 1 + 2 + 2 + 3 fixtures
     from gym_kilobots_amd.lib import TForm, CForm
