@@ -866,6 +866,39 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
             for (int j = 0; j < KREG; ++j) maxD = max(maxD, rdepth[j]);
             for (int dd = 32; dd >= 1; dd >>= 1) maxD = max(maxD, __shfl_xor(maxD, dd));
             maxD = __builtin_amdgcn_readfirstlane(maxD);
+            // ---- deal the contacts to (lane, slot) in order of depth: the 64 shallowest go to slot 0, the rest to
+            // slot 1, ...  A depth level then lives in one slot (two at a boundary), and a sweep round only pays for
+            // the slots that hold contacts of its level. ----
+            if (KREG > 1 && mycnt > 64u) {
+                unsigned base_ = 0;
+                for (int d_ = 1; d_ <= maxD; ++d_) {
+#pragma unroll
+                    for (int j = 0; j < KREG; ++j) {
+                        const bool is = rvalid[j] && rdepth[j] == d_;
+                        const unsigned long long m_ = __ballot(is);
+                        if (is) {
+                            const unsigned at = mybase + base_ + (unsigned)__popcll(m_ & ((1ull << lane) - 1ull));
+                            lOrder[at] = (unsigned short)rc[j];
+                            lCbk[at] = (unsigned short)d_;
+                        }
+                        base_ += (unsigned)__popcll(m_);
+                    }
+                }
+                wave_sync();
+#pragma unroll
+                for (int j = 0; j < KREG; ++j)
+                    if (rvalid[j]) { rc[j] = lOrder[mybase + lane + 64u * j]; rdepth[j] = lCbk[mybase + lane + 64u * j]; }
+            }
+            // depth levels present in every slot (bit min(depth, 63)), wave-uniform
+            unsigned long long slotLevels[KREG];
+#pragma unroll
+            for (int j = 0; j < KREG; ++j) {
+                const unsigned long long mine = rvalid[j] ? 1ull << min(rdepth[j], 63) : 0ull;
+                unsigned lo = (unsigned)mine, hi = (unsigned)(mine >> 32);
+                for (int dd = 32; dd >= 1; dd >>= 1) { lo |= __shfl_xor(lo, dd); hi |= __shfl_xor(hi, dd); }
+                slotLevels[j] = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(hi) << 32) |
+                                (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(lo);
+            }
             // ---- full load of the contacts ----
 #pragma unroll
             for (int j = 0; j < KREG; ++j) {
@@ -965,34 +998,42 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                 iaS[j] = (rvalid[j] && ra[j] < WALL_CODE) ? ra[j] : DUMMY;
                 ibS[j] = rvalid[j] ? rb[j] : DUMMY;
             }
+#define KB_VEL_ROUND(J0, J1)                                                                        \
+                    {                                                                               \
+                        int ia[KREG], ib[KREG];                                                     \
+                        float vax[KREG], vay[KREG], vbx[KREG], vby[KREG];                           \
+                        _Pragma("unroll") for (int j = J0; j < J1; ++j) {                           \
+                            const bool on = rdepth[j] == d_ && !(OBJ && rpoly[j]);                  \
+                            ia[j] = on ? iaS[j] : DUMMY; ib[j] = on ? ibS[j] : DUMMY;               \
+                            vax[j] = vel[ia[j]].x; vay[j] = vel[ia[j]].y; vbx[j] = vel[ib[j]].x; vby[j] = vel[ib[j]].y; \
+                        }                                                                           \
+                        _Pragma("unroll") for (int j = J0; j < J1; ++j) {                           \
+                            const bool on = rdepth[j] == d_ && !(OBJ && rpoly[j]);                  \
+                            const bool wallA = ra[j] >= WALL_CODE;                                  \
+                            const float nx = rnx[j], ny = rny[j];                                   \
+                            const float ima = R_IMA(j), imb = R_IMB(j);                             \
+                            const float ax_ = wallA ? 0.0f : vax[j], ay_ = wallA ? 0.0f : vay[j];   \
+                            const float dvx = vbx[j] - ax_, dvy = vby[j] - ay_;                     \
+                            const float vn = dvx * nx + dvy * ny;                                   \
+                            float lambda = -(R_NM(j) * vn);                                         \
+                            const float accOld = racc[j];                                           \
+                            const float newimp = fmaxf(accOld + lambda, 0.0f);                      \
+                            lambda = newimp - accOld;                                               \
+                            racc[j] = on ? newimp : accOld;                                         \
+                            const float Px = lambda * nx, Py = lambda * ny;                         \
+                            vel[ia[j]].x = ax_ - ima * Px; vel[ia[j]].y = ay_ - ima * Py;           \
+                            vel[ib[j]].x = vbx[j] + imb * Px; vel[ib[j]].y = vby[j] + imb * Py;     \
+                        }                                                                           \
+                    }
             for (int it = 0; it < p.vel_iters; ++it) {
                 for (int d_ = 1; d_ <= maxD; ++d_) {
-                    int ia[KREG], ib[KREG];
-                    float vax[KREG], vay[KREG], vbx[KREG], vby[KREG];
-#pragma unroll
-                    for (int j = 0; j < KREG; ++j) {
-                        const bool on = rdepth[j] == d_ && !(OBJ && rpoly[j]);
-                        ia[j] = on ? iaS[j] : DUMMY; ib[j] = on ? ibS[j] : DUMMY;
-                        vax[j] = vel[ia[j]].x; vay[j] = vel[ia[j]].y; vbx[j] = vel[ib[j]].x; vby[j] = vel[ib[j]].y;
-                    }
-#pragma unroll
-                    for (int j = 0; j < KREG; ++j) {
-                        const bool on = rdepth[j] == d_ && !(OBJ && rpoly[j]);
-                        const bool wallA = ra[j] >= WALL_CODE;
-                        const float nx = rnx[j], ny = rny[j];
-                        const float ima = R_IMA(j), imb = R_IMB(j);
-                        const float ax_ = wallA ? 0.0f : vax[j], ay_ = wallA ? 0.0f : vay[j];
-                        const float dvx = vbx[j] - ax_, dvy = vby[j] - ay_;
-                        const float vn = dvx * nx + dvy * ny;
-                        float lambda = -(R_NM(j) * vn);
-                        const float accOld = racc[j];
-                        const float newimp = fmaxf(accOld + lambda, 0.0f);
-                        lambda = newimp - accOld;
-                        racc[j] = on ? newimp : accOld;
-                        const float Px = lambda * nx, Py = lambda * ny;
-                        vel[ia[j]].x = ax_ - ima * Px; vel[ia[j]].y = ay_ - ima * Py;
-                        vel[ib[j]].x = vbx[j] + imb * Px; vel[ib[j]].y = vby[j] + imb * Py;
-                    }
+                    // which slots hold contacts of this level (branch-free inside a slot set: its LDS reads go out together)
+                    const int lv = min(d_, 63);
+                    const bool s0 = (slotLevels[0] >> lv) & 1ull, s1 = KREG > 1 && ((slotLevels[KREG > 1 ? 1 : 0] >> lv) & 1ull);
+                    if (KREG != 2) KB_VEL_ROUND(0, KREG)
+                    else if (s0 && s1) KB_VEL_ROUND(0, 2)
+                    else if (s1) KB_VEL_ROUND(1, 2)
+                    else KB_VEL_ROUND(0, 1)
                     if (OBJ) {   // kilobot - polygon contacts of this depth level: one point, friction sqrt(0 * f) = 0
 #pragma unroll
                         for (int j = 0; j < KREG; ++j) {
@@ -1152,6 +1193,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                 if (OBJ && myMc) mc_clear_flags(myMc, lane == 0, act);
                 wave_sync();
             }
+#undef KB_VEL_ROUND
 #undef KB_REG_ROUNDS
 #undef KB_REG_KEY_ROUNDS
 #undef R_IMA
