@@ -31,7 +31,7 @@ constexpr int MAX_CELLS = 8192;
 constexpr unsigned KEY_WALL = 0x10000u, KEY_OBJ = 0x20000u;
 constexpr int WALL_CODE = 0xFFF0;     // body id of wall w is WALL_CODE + w
 constexpr int OBJ_CODE = 0xFFE0;      // 16-bit warm-start key of object m (its body id is N + m)
-constexpr int MAXOBJ = KB_MAX_OBJECTS, OBJ_LIST = 32;
+constexpr int MAXOBJ = KB_MAX_OBJECTS, OBJ_LIST = 64;   // OBJ_LIST: kilobots that may touch one fixture at a time
 constexpr int OT_WORDS_C = 7 + 4 * KB_MAX_POLY_VERTS;   // floats per fixture in the fixture table (kb_objects.h)
 constexpr int BT_WORDS_C = 6;                          // floats per object in the body table
 constexpr int MC_FIELDS_C = 37;                        // words per manifold-constraint record (kb_objects.h)
@@ -84,7 +84,7 @@ constexpr int OBJTAB = NLIST + 16;                                    // object 
 constexpr int OBJBODY = OBJTAB + A16(4 * OT_WORDS_C * KB_MAX_OBJECTS);  // body table
 constexpr int OBJCNT = OBJBODY + A16(4 * BT_WORDS_C * KB_MAX_OBJECTS);
 constexpr int OBJLIST = OBJCNT + A16(4 * KB_MAX_OBJECTS);
-constexpr int OBJW = OBJLIST + A16(2 * KB_MAX_OBJECTS * 32);          // angular velocity, angle, angle at the start of the substep
+constexpr int OBJW = OBJLIST + A16(2 * KB_MAX_OBJECTS * OBJ_LIST);          // angular velocity, angle, angle at the start of the substep
 constexpr int OBJA = OBJW + A16(4 * KB_MAX_OBJECTS);
 constexpr int OBJA0 = OBJA + A16(4 * KB_MAX_OBJECTS);
 constexpr int MCMASK = OBJA0 + A16(4 * KB_MAX_OBJECTS);                // per wave: which manifold constraints it owns (u64)

@@ -1514,6 +1514,16 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                 if (cand[q] >= 0) { th[q] = cTh[cand[q]]; bw[q] = cW[cand[q]]; }
             if (candObj >= 0) { objA[tid] = cTh[candObj]; objW[tid] = cW[candObj]; }
         }
+        // The state of an object between substeps is its body origin (what one-substep launches store and load, and
+        // what the specification's substep does): bodies whose centre of mass is off the origin go through the same
+        // origin -> centre of mass conversion inside a fused launch, so that fusing never changes a bit.
+        if (OBJ && tid < M && sub + 1 < p.n_substeps &&
+            (objBody[tid * BT_WORDS + BT_LCX] != 0.0f || objBody[tid * BT_WORDS + BT_LCY] != 0.0f)) {
+            const XF t0 = body_xf(ox, N + tid);                                   // b2Body::SynchronizeTransform
+            const XF t1 = xf_make(t0.p.x, t0.p.y, objA[tid]);
+            const V2 cm = xf_mul(t1, mk2(objBody[tid * BT_WORDS + BT_LCX], objBody[tid * BT_WORDS + BT_LCY]));
+            pos[N + tid].x = cm.x; pos[N + tid].y = cm.y;
+        }
         // the new warm-start list becomes the old one
         for (int b = tid; b < NP; b += nt) { wsCnt[b] = wsCntNew[b]; wsOff[b] = newOff[b]; }
         oldInLds = newInLds;

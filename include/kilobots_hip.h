@@ -142,7 +142,8 @@ typedef struct kb_buffers {
     float *light_value, *light_gx, *light_gy; /* optional outputs: last sensed light (kilobots_env.py:176-180) */
     float *cmd_vx, *cmd_vy, *cmd_w;     /* optional outputs: body velocity written by the drive law */
     int32_t *status;                    /* required: [num_envs]; bit0 contact capacity overflow,
-                                           bit1 warm-start slot overflow, bit2 rank/cell overflow,
+                                           bit1 warm-start slot overflow, bit2 a device staging limit was hit (more than 64 kilobots
+                                           on one fixture, 255 kilobot-object contacts in one env, or 63 partners in one cell pair),
                                            bit3 more than 512 bodies near the walls in one substep (TOI skipped for the rest) */
     void *scratch;                      /* required: kb_scratch_bytes() bytes; contact staging of envs whose
                                            contacts do not fit the LDS staging area (contents are transient) */

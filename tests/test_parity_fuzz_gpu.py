@@ -1,0 +1,100 @@
+"""Randomised parity sweep: many small random scenes (bot counts, drive laws, light models, object shapes with random
+fixture-to-body maps, spawn densities, solver paths), each compared bit for bit with the oracle substep by substep."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from tests import scenes
+from tests.test_parity_gpu import make_pair, assert_same, assert_ws_same, cpu, dev, OBJ_FIELDS, TRIANGLE
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_objects(rng):
+    """Random bodies: circles, boxes, triangles and two-/three-part compounds; fixtures shuffled across bodies."""
+    from gym_kilobots_amd.lib.body import _hull_order
+    nobj = int(rng.integers(1, 5))
+    fixtures = []                      # (shape, verts or None, radius, body)
+    for b in range(nobj):
+        kind = rng.choice(['circle', 'box', 'tri', 'two', 'three']) if len(fixtures) <= 5 else rng.choice(['circle', 'box'])
+        if kind == 'circle':
+            fixtures.append((O.SHAPE_CIRCLE, None, float(rng.uniform(0.03, 0.07)), b))
+        elif kind == 'box':
+            fixtures.append((O.SHAPE_BOX, [[float(rng.uniform(0.03, 0.09)) * 25.0, float(rng.uniform(0.03, 0.09)) * 25.0]], 0.0, b))
+        elif kind == 'tri':
+            fixtures.append((O.SHAPE_POLYGON, [[x * 25.0, y * 25.0] for x, y in TRIANGLE], 0.0, b))
+        else:
+            parts = 2 if kind == 'two' else 3
+            w, h = float(rng.uniform(0.04, 0.07)), float(rng.uniform(0.02, 0.04))
+            for k in range(parts):     # a row of boxes glued together (as explicit quads)
+                cx = (k - (parts - 1) / 2) * 2 * w
+                quad = [(cx - w, -h), (cx + w, -h), (cx + w, h * (1 + 0.5 * k)), (cx - w, h)]
+                fixtures.append((O.SHAPE_POLYGON, [list(q) for q in _hull_order([(x * 25.0, y * 25.0) for x, y in quad])], 0.0, b))
+    fixtures = fixtures[:8]
+    nobj = len({f[3] for f in fixtures})
+    remap = {b: i for i, b in enumerate(sorted({f[3] for f in fixtures}))}
+    order = rng.permutation(len(fixtures))
+    fixtures = [fixtures[i] for i in order]
+    # a circle must be alone on its body: guaranteed by construction
+    pad = 8 - len(fixtures)
+    kw = dict(num_objects=nobj, num_fixtures=len(fixtures), obj_fixture_body=[remap[f[3]] for f in fixtures] + [0] * pad,
+              obj_shape=[f[0] for f in fixtures], obj_nverts=[0 if f[1] is None else len(f[1]) for f in fixtures],
+              obj_radius=[f[2] for f in fixtures], obj_verts=[[[0.0, 0.0]] if f[1] is None else f[1] for f in fixtures])
+    return nobj, kw
+
+
+@pytest.mark.parametrize('seed', list(range(40)))
+def test_random_scene(seed):
+    rng = np.random.default_rng(1000 + seed)
+    N = int(rng.choice([1, 2, 7, 16, 33, 64, 100, 128, 200, 256, 300]))
+    E = int(rng.integers(1, 5))
+    mode = int(rng.choice([O.DRIVE_VELOCITY, O.DRIVE_VELOCITY, O.DRIVE_ACCEL, O.DRIVE_MOTORS, O.DRIVE_SIMPLE_PHOTOTAXIS, O.DRIVE_PHOTOTAXIS]))
+    light = O.LIGHT_NONE
+    if mode in (O.DRIVE_SIMPLE_PHOTOTAXIS, O.DRIVE_PHOTOTAXIS) or rng.random() < 0.3:
+        light = int(rng.choice([O.LIGHT_CIRCULAR, O.LIGHT_GRADIENT, O.LIGHT_MOMENTUM]))
+    kw = dict(solver_mode=int(rng.choice([0, 0, 0, 1, 2, 3, 4])), toi_walls=int(rng.random() < 0.8))
+    with_objects = rng.random() < 0.6
+    nobj = 0
+    if with_objects:
+        nobj, okw = _random_objects(rng)
+        kw.update(okw)
+    sigma = float(rng.choice([0.03, 0.08, 0.2, 0.5]))
+    xy = np.clip(rng.normal(scale=sigma, size=(E, N, 2)) + rng.uniform(-0.5, 0.5, (E, 1, 2)), [-0.97, -0.72], [0.97, 0.72])
+    th = rng.uniform(-np.pi, np.pi, (E, N))
+    osim, gsim = make_pair(E, N, mode, light, xy=xy, th=th, **kw)
+    if nobj:
+        objs = rng.uniform([-0.8, -0.55], [0.8, 0.55], (E, nobj, 2))
+        oth = rng.uniform(-np.pi, np.pi, (E, nobj))
+        osim.set_objects_m(objs, oth)
+        gsim.set_objects_m(objs, oth)
+        v0 = rng.uniform(-6, 6, (E, nobj)).astype(np.float32)
+        osim.ovx[...] = v0
+        gsim.ovx.copy_(dev(v0))
+    if light != O.LIGHT_NONE:
+        lx = rng.uniform(-0.5, 0.5, osim.light_x.shape).astype(np.float32)
+        osim.light_x[...] = lx
+        gsim.light_x.copy_(dev(lx))
+    fields = ('x', 'y', 'theta') + (OBJ_FIELDS[3:] if nobj else ())
+    la_dim = {O.LIGHT_NONE: 0, O.LIGHT_GRADIENT: 1}.get(light, 2)
+    for k in range(12):
+        la = None if la_dim == 0 or k % 3 == 2 else rng.uniform(-0.02, 0.02, (E, la_dim)).astype(np.float32)
+        n_sub = int(rng.choice([1, 1, 3, 10]))
+        if mode in (O.DRIVE_VELOCITY, O.DRIVE_ACCEL):
+            a = scenes.random_actions(E, N, seed=5000 + 31 * seed + k)
+            osim.set_actions(a)
+            osim.step(n_sub, light_action=la)
+            gsim.step(n_sub, actions=dev(a), light_action=None if la is None else dev(la))
+        else:
+            osim.step(n_sub, light_action=la)
+            gsim.step(n_sub, light_action=None if la is None else dev(la))
+        torch.cuda.synchronize()
+        so, sg = osim.status, cpu(gsim.status)
+        if ((so | sg) & 1).any() or (sg & 4).any():
+            # contact capacity exceeded (absurdly dense spawn) or more kilobots on one fixture / in one rank group than
+            # the device stages: which contacts are dropped is unspecified, only the flag is
+            assert ((so & 1) == (sg & 1)).all(), 'capacity flag differs: %s vs %s' % (so, sg)
+            return
+        assert_same(osim, gsim, 'seed %d (N=%d E=%d mode=%d light=%d objects=%d %s) step %d' % (seed, N, E, mode, light, nobj, kw.get('solver_mode'), k), fields)
+        assert_ws_same(osim, gsim, 'seed %d step %d' % (seed, k))
+    assert np.array_equal(osim.status & 3, cpu(gsim.status) & 3)     # (bits 2, 3 are limits of the device staging only)
