@@ -1,5 +1,7 @@
 """Randomised parity sweep: many small random scenes (bot counts, drive laws, light models, object shapes with random
 fixture-to-body maps, spawn densities, solver paths), each compared bit for bit with the oracle substep by substep."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -44,10 +46,12 @@ def _random_objects(rng):
     return nobj, kw
 
 
-@pytest.mark.parametrize('seed', list(range(40)))
+@pytest.mark.parametrize('seed', list(range(int(os.environ.get('KB_FUZZ_SEEDS', '40')))))
 def test_random_scene(seed):
     rng = np.random.default_rng(1000 + seed)
     N = int(rng.choice([1, 2, 7, 16, 33, 64, 100, 128, 200, 256, 300]))
+    if os.environ.get('KB_FUZZ_BIG'):
+        N = int(rng.choice([512, 700, 1000, 1024, 1024]))
     E = int(rng.integers(1, 5))
     mode = int(rng.choice([O.DRIVE_VELOCITY, O.DRIVE_VELOCITY, O.DRIVE_ACCEL, O.DRIVE_MOTORS, O.DRIVE_SIMPLE_PHOTOTAXIS, O.DRIVE_PHOTOTAXIS]))
     light = O.LIGHT_NONE
@@ -60,6 +64,8 @@ def test_random_scene(seed):
         nobj, okw = _random_objects(rng)
         kw.update(okw)
     sigma = float(rng.choice([0.03, 0.08, 0.2, 0.5]))
+    if os.environ.get('KB_FUZZ_BIG'):
+        sigma = float(rng.choice([0.12, 0.2, 0.3, 0.5]))
     xy = np.clip(rng.normal(scale=sigma, size=(E, N, 2)) + rng.uniform(-0.5, 0.5, (E, 1, 2)), [-0.97, -0.72], [0.97, 0.72])
     th = rng.uniform(-np.pi, np.pi, (E, N))
     osim, gsim = make_pair(E, N, mode, light, xy=xy, th=th, **kw)
