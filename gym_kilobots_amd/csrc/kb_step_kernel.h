@@ -587,6 +587,8 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
             head[cellOf[b]] = EMPTY16;
             active[b] = 1; active[NB + b] = 0;
         }
+        if (tid < 64) bkStart[tid] = 0;     // size-class counters of the island placement
+        if (tid < 32) bkFill[tid] = 0;
         if (tid < M) {
             const int b = N + tid;
             unsigned r = b;
@@ -622,6 +624,41 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
         //   reg : every wave can hold its contacts in registers (<= KREG per lane) -> no contact arrays in the sweeps
         //   list: per-wave sweeps over the staged contact arrays
         const bool coop = misc[M_MAXISL] > (unsigned)GIANT_ISLAND || nw == 1 || p.solver_mode == 2 || p.solver_mode == 4;
+        if (!coop && !big && p.solver_mode == 0) {
+            // Placement of the islands on the waves in order of size: the largest (= deepest) islands share the first
+            // waves, the many tiny ones fill the rest.  A wave sweeps as many rounds as its deepest island has levels
+            // and the LDS pipeline is shared, so what counts is the SUM of those depths over the waves -- about a third
+            // less than with a hash placement.  Counting sort over 32 size classes; results never depend on it.
+            unsigned *szSum = bkStart, *szPre = bkStart + 32, *szFill = bkFill;     // (zeroed in the flatten phase)
+            for (int b = tid; b < N + M; b += nt) {
+                if (parent[b] != (unsigned)b) continue;
+                const unsigned cnt_ = islCnt[b];
+                if (cnt_ != 0) atomicAdd(&szSum[32u - min(cnt_, 32u)], cnt_);
+            }
+            __syncthreads();
+            if (wave == 0) {
+                const unsigned v_ = lane < 32 ? szSum[lane] : 0u;
+                unsigned incl = v_;
+                for (int d = 1; d < 32; d <<= 1) { const unsigned t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+                if (lane < 32) szPre[lane] = incl - v_;
+                if (lane < nw) misc[M_WCNT + lane] = 0;
+            }
+            __syncthreads();
+            const unsigned chunk = ((unsigned)ncon + (unsigned)nw - 1u) / (unsigned)nw;
+            for (int b = tid; b < N + M; b += nt) {
+                if (parent[b] != (unsigned)b) continue;
+                const unsigned cnt_ = islCnt[b];
+                if (cnt_ == 0) continue;
+                const unsigned q_ = 32u - min(cnt_, 32u);
+                const unsigned at = szPre[q_] + atomicAdd(&szFill[q_], cnt_);
+                const unsigned w_ = min(at / max(chunk, 1u), (unsigned)nw - 1u);
+                islWave[b] = (unsigned char)w_;
+                atomicAdd(&misc[M_WCNT + w_], cnt_);
+            }
+            __syncthreads();
+            maxw = 0;
+            for (int w = 0; w < nw; ++w) maxw = max(maxw, misc[M_WCNT + w]);
+        }
         bool reg = !coop && !big && maxw <= 64u * KREG && p.solver_mode == 0;
         if (!coop && !big && maxw > 64u * KREG && p.solver_mode == 0) {
             // The default placement (root id mod #waves) overloads a wave.  Place the islands of BIG_ISLAND contacts or
