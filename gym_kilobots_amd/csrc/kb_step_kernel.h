@@ -185,21 +185,12 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
     // warm-start list of the previous substep: offsets, and an LDS image of the packed entries if it fits
     unsigned oldTotal = block_scan_u8(wsCnt, wsOff, NP, wsum);
     bool oldInLds = oldTotal <= (unsigned)capL_;
-    // The list is first needed by the label pass: the first two entries per thread are only requested here and are
-    // put into LDS after the first substep's drive and find phases, which hide this second trip to memory.
-    auto key16 = [](unsigned k) __attribute__((always_inline)) -> unsigned short {
-        return (unsigned short)(k >= KEY_OBJ ? OBJ_CODE + (k - KEY_OBJ) : (k >= KEY_WALL ? WALL_CODE + (k - KEY_WALL) : k));
-    };
-    unsigned preKey[2] = {0u, 0u};
-    float preAcc[2] = {0.0f, 0.0f};
-    const unsigned preTotal = oldInLds ? oldTotal : 0u;
     if (oldInLds) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const unsigned i = (unsigned)tid + (unsigned)(q * nt);
-            if (i < oldTotal) { preKey[q] = g.ws_key[wo + i]; preAcc[q] = g.ws_acc[wo + i]; }
+        for (unsigned i = tid; i < oldTotal; i += nt) {
+            const unsigned k = g.ws_key[wo + i];
+            oldKey[i] = (unsigned short)(k >= KEY_OBJ ? OBJ_CODE + (k - KEY_OBJ) : (k >= KEY_WALL ? WALL_CODE + (k - KEY_WALL) : k));
+            oldAcc[i] = g.ws_acc[wo + i];
         }
-        for (unsigned i = tid + 2 * nt; i < oldTotal; i += nt) { oldKey[i] = key16(g.ws_key[wo + i]); oldAcc[i] = g.ws_acc[wo + i]; }
     }
     __syncthreads();
 
@@ -431,13 +422,6 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                 wsCntNew[a] = (unsigned char)mine;
             }
         };
-        if (sub == 0) {   // the head of the warm-start list requested at kernel start has arrived by now
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const unsigned i = (unsigned)tid + (unsigned)(q * nt);
-                if (i < preTotal) { oldKey[i] = key16(preKey[q]); oldAcc[i] = preAcc[q]; }
-            }
-        }
         bool big = p.solver_mode >= 3;
         if (!big) {
             find_pass(lPair, lInfo, capL_);
