@@ -106,7 +106,8 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
         if (b < N) {
             pos[b].x = g.x[o + b]; pos[b].y = g.y[o + b]; th[q] = g.theta[o + b];
             wsCnt[b] = g.ws_cnt[o + b];
-            if (velmode) { cv[q] = g.v[o + b]; cw[q] = g.w[o + b]; }
+            // (a velocity action replaces the stored command: nothing to load then)
+            if (velmode && !(DRIVE_MODE == KB_DRIVE_VELOCITY && p.actions)) { cv[q] = g.v[o + b]; cw[q] = g.w[o + b]; }
             if (DRIVE_MODE == KB_DRIVE_ACCEL) { av[q] = g.acc_v[o + b]; aw[q] = g.acc_w[o + b]; }
             if (p.actions) {
                 const float2 a = reinterpret_cast<const float2 *>(p.actions)[o + b];
