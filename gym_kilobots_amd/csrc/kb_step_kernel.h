@@ -645,7 +645,10 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                 if (lane < nw) misc[M_WCNT + lane] = 0;
             }
             __syncthreads();
-            const unsigned chunk = ((unsigned)ncon + (unsigned)nw - 1u) / (unsigned)nw;
+            // the first nw - 1 waves get about 60 contacts each (one register slot: no dealing, one-slot rounds), the
+            // last one the remaining small islands (two slots, but only one or two depth levels)
+            unsigned chunk = 60u;
+            if ((unsigned)ncon > 60u * (unsigned)(nw - 1) + 124u) chunk = ((unsigned)ncon - 124u + (unsigned)nw - 2u) / (unsigned)(nw - 1);
             for (int b = tid; b < N + M; b += nt) {
                 if (parent[b] != (unsigned)b) continue;
                 const unsigned cnt_ = islCnt[b];
@@ -885,25 +888,53 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                 }                                                                                   \
             }
 
+            KB_STAMP_PRE(19);    // (profile build) wave 0: contacts grouped + light load
             // ---- dependency depth of every contact: 1 + the depth of the latest earlier contact (canonical key
             // order) on either of its bodies.  Contacts of equal depth never share a body, and sweeping by
             // increasing depth keeps the relative order of any two contacts that do -- so depth rounds give exactly
             // the result of the key-by-key sweep, in (typically) a third of the rounds. ----
             unsigned *bodyDepth = islCnt;   // zeroed before the wave sort
-            KB_REG_KEY_ROUNDS({
-                const int a = ra[j], b = rb[j];
-                unsigned d = bodyDepth[b];
-                if (a < WALL_CODE) d = max(d, bodyDepth[a]);
-                d += 1u;
-                bodyDepth[b] = d;
-                if (a < WALL_CODE) bodyDepth[a] = d;
-                rdepth[j] = (int)d;
-            })
+            {
+                // one round per key (contacts of equal key share no body): the reads of all slots go out together,
+                // slots that are not part of the round work on the scratch body
+                const int DUMMYD = NB - 1;
+                auto depth_round = [&](int key_, int r_) __attribute__((always_inline)) {
+                    int ia[KREG], ib[KREG];
+                    unsigned da[KREG], db[KREG];
+                    bool on[KREG];
+#pragma unroll
+                    for (int j = 0; j < KREG; ++j) {
+                        on[j] = rvalid[j] && rkey[j] == key_ && (r_ < 0 || rrank[j] == r_);
+                        ia[j] = (on[j] && ra[j] < WALL_CODE) ? ra[j] : DUMMYD;
+                        ib[j] = on[j] ? rb[j] : DUMMYD;
+                        da[j] = bodyDepth[ia[j]]; db[j] = bodyDepth[ib[j]];
+                    }
+#pragma unroll
+                    for (int j = 0; j < KREG; ++j) {
+                        const unsigned d = max((on[j] && ra[j] < WALL_CODE) ? da[j] : 0u, db[j]) + 1u;
+                        if (on[j]) {
+                            rdepth[j] = (int)d;
+                            bodyDepth[ib[j]] = d;
+                            if (ra[j] < WALL_CODE) bodyDepth[ia[j]] = d;
+                        }
+                    }
+                    wave_sync();
+                };
+                for (unsigned long long m_ = keymask; m_; m_ &= m_ - 1) {
+                    const int key_ = __builtin_ctzll(m_);
+                    if ((key_ % RK) < RK - 1) depth_round(key_, -1);
+                    else {
+                        const int maxr_ = (int)bkMaxRank[wave * NUM_CLS + key_ / RK];
+                        for (int r_ = RK - 1; r_ <= maxr_; ++r_) depth_round(key_, r_);
+                    }
+                }
+            }
             int maxD = 0;
 #pragma unroll
             for (int j = 0; j < KREG; ++j) maxD = max(maxD, rdepth[j]);
             for (int dd = 32; dd >= 1; dd >>= 1) maxD = max(maxD, __shfl_xor(maxD, dd));
             maxD = __builtin_amdgcn_readfirstlane(maxD);
+            KB_STAMP_PRE(20);    // ... + depth pass
             // ---- deal the contacts to (lane, slot) in order of depth: the 64 shallowest go to slot 0, the rest to
             // slot 1, ...  A depth level then lives in one slot (two at a boundary), and a sweep round only pays for
             // the slots that hold contacts of its level. ----
@@ -927,6 +958,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                 for (int j = 0; j < KREG; ++j)
                     if (rvalid[j]) { rc[j] = lOrder[mybase + lane + 64u * j]; rdepth[j] = lCbk[mybase + lane + 64u * j]; }
             }
+            KB_STAMP_PRE(21);    // ... + dealing
             // depth levels present in every slot (bit min(depth, 63)), wave-uniform
             unsigned long long slotLevels[KREG];
 #pragma unroll

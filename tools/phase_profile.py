@@ -73,6 +73,8 @@ def main():
     print('  kernel start (per launch) %.0f, flatten+scan (part of islands+buckets) %.0f' % (extra[0], extra[1]))
     pre = raw[:, 16:19].mean(0) * 16
     print('  wave 0 before the barrier (own work): drive+grid %.0f, count pass %.0f, emit pass %.0f' % tuple(pre))
+    sub_ = raw[:, 19:22].mean(0) * 16
+    print('  wave 0 inside the register set-up, cumulative since the sort barrier: light load %.0f, + depth pass %.0f, + dealing %.0f' % tuple(sub_))
     print('  wave 0 per substep: keys %.1f, depth rounds/sweep %.1f (deepest wave of the env %.1f), position sweeps %.2f, reg-path fraction %.2f' % (ex[0], ex[4], ex[1], ex[2], ex[3]))
 
 
