@@ -1,28 +1,28 @@
-// kb_abi.hip -- batched Kilobot world step for MI355X (gfx950 / CDNA4) + its C ABI.
+// kb_abi.hip -- the C ABI of libkilobots_hip.so (include/kilobots_hip.h) and two small elementwise kernels.
 //
-// One workgroup owns one env for the whole launch: positions are loaded once from HBM into LDS,
-// `n_substeps` iterations of the reference substep loop
-// (gym_kilobots/envs/kilobots_env.py:168-190) run out of LDS / registers, poses are written back once.
-// Per substep:
-//   drive law (kilobot.py:86-127,191-203,253-258,294-300,318-333) + light (light.py:59-75,176-189)
+// The hot kernel is kb_step_kernel (kb_step_kernel.h, instantiated per drive law in kb_inst_d*.hip):
+// one workgroup owns one env for the whole launch: poses are loaded once from HBM into LDS, `n_substeps` iterations
+// of the reference substep loop (gym_kilobots/envs/kilobots_env.py:168-190) run out of LDS / registers, poses are
+// written back once.  Per substep:
+//   drive law (kilobot.py:86-127,191-203,253-258,294-300,318-333) + light (light.py:59-75,99-148,176-189,218-319)
 //   -> broadphase: uniform grid of per-cell linked lists in LDS (one atomic exchange per bot)
-//   -> narrowphase: circle-circle / circle-wall (Box2D b2CollideCircles, b2CollideEdgeAndCircle),
-//      5-cell half stencil, warm-start impulses matched from the previous substep
-//   -> islands: lock-free union-find in LDS
-//   -> solver (b2ContactSolver semantics): warm start + 10 sequential-impulse velocity sweeps,
-//      symplectic Euler, <= 10 position sweeps with Box2D's per-island early out.
-// Gauss-Seidel order.  Every contact gets a key (class, rank): class from the relative grid position
-// of the two bodies and the parity of the base cell, rank from its position inside its cell-pair
-// group.  Two contacts with the same key never share a body, so all contacts of one key can be
-// solved concurrently and the result equals the sequential sweep in (class, group, A, B) order that
-// DESIGN.md specifies.  Islands are independent, so each island is bound to ONE wavefront
-// (root id mod #waves): a wave walks its own contacts key by key with no workgroup barrier at all
-// (LDS operations of one wave execute in order).  Only when one island is very large does the whole
+//   -> narrowphase: circle-circle / circle-wall / circle-polygon (Box2D b2CollideCircles, b2CollideEdgeAndCircle,
+//      b2CollidePolygonAndCircle), 5-cell half stencil, warm-start impulses matched from the previous substep;
+//      manifolds of the object-object and object-wall contacts (kb_objects.h)
+//   -> islands: lock-free union-find in LDS; islands placed on wavefronts in order of size
+//   -> solver (b2ContactSolver semantics): warm start + 10 sequential-impulse velocity sweeps, symplectic Euler,
+//      <= 10 position sweeps with Box2D's per-island early out, continuous step against the walls.
+// Gauss-Seidel order.  Every contact gets a key (class, rank): class from the relative grid position of the two
+// bodies and the parity of the base cell, rank from its position inside its cell-pair group.  Two contacts with the
+// same key never share a body, so all contacts of one key can be solved concurrently and the result equals the
+// sequential sweep in (class, group, A, B) order that DESIGN.md specifies.  Islands are independent, so each island
+// is bound to ONE wavefront, which sweeps its contacts level by level of their dependency depth with no workgroup
+// barrier at all (LDS operations of one wave execute in order).  Only when one island is very large does the whole
 // workgroup cooperate on the sweep with s_barrier between keys.
-// No MFMA anywhere: this is LDS/latency- and HBM-bound integer/float work.
+// No MFMA anywhere: this is LDS-, issue- and HBM-bound integer/float work.
 //
-// Arithmetic: fp32, compiled with -ffp-contract=off; every expression is written in the operation
-// order of the specification so results do not depend on launch fusion, workgroup size or sharding.
+// Arithmetic: fp32, compiled with -ffp-contract=off; every expression is written in the operation order of the
+// specification so results do not depend on launch fusion, workgroup size or sharding.
 #include <new>
 
 #include "kb_common.h"

@@ -35,7 +35,6 @@ constexpr int MAXOBJ = KB_MAX_OBJECTS, OBJ_LIST = 64;   // OBJ_LIST: kilobots th
 constexpr int OT_WORDS_C = 7 + 4 * KB_MAX_POLY_VERTS;   // floats per fixture in the fixture table (kb_objects.h)
 constexpr int BT_WORDS_C = 6;                          // floats per object in the body table
 constexpr int MC_FIELDS_C = 37;                        // words per manifold-constraint record (kb_objects.h)
-constexpr unsigned EMPTY32 = 0xFFFFFFFFu;
 constexpr unsigned short EMPTY16 = 0xFFFFu;
 
 // contact classes in canonical order; +1 on E/N/NE/NW for odd base-cell parity
@@ -387,8 +386,6 @@ __device__ __forceinline__ unsigned block_scan_u8(const unsigned char *cnt, unsi
     return total;
 }
 
-#define KB_NEXT(b) (nextb[b] == EMPTY16 ? EMPTY32 : (unsigned)nextb[b])
-#define KB_HEAD(c) (head[c] == EMPTY16 ? EMPTY32 : (unsigned)head[c])
 
 
 typedef void (*kb_step_fn)(const Params);
