@@ -72,3 +72,56 @@ def test_sim_fails_loudly_without_gpu():
     from gym_kilobots_amd.sim import KilobotSim
     with pytest.raises(nat.KilobotsHipError):
         KilobotSim(1, 16)
+
+
+def test_object_configuration_is_validated(lib):
+    h = C.c_void_p()
+    W = 25.0
+
+    def create(**kw):
+        cfg = nat.default_config(2, 16, **kw)
+        rc = lib.kb_create(C.byref(cfg), C.byref(h))
+        if rc == 0:
+            lib.kb_destroy(h)
+        return rc
+
+    box = [[0.075 * W, 0.075 * W]]
+    tri = [[1.25, -1.25], [1.25, 2.5], [-2.5, -1.25]]
+    assert create(num_objects=1, obj_shape=[nat.SHAPE_BOX], obj_verts=[box]) == 0
+    assert create(num_objects=1, obj_shape=[nat.SHAPE_POLYGON], obj_nverts=[3], obj_verts=[tri]) == 0
+    # two fixtures on one body + a disc on another
+    assert create(num_objects=2, num_fixtures=3, obj_fixture_body=[0, 1, 0], obj_shape=[nat.SHAPE_BOX, nat.SHAPE_CIRCLE, nat.SHAPE_POLYGON],
+                  obj_nverts=[4, 0, 3], obj_radius=[0.0, 0.05, 0.0], obj_verts=[box, [[0, 0]], tri]) == 0
+    bad = [
+        dict(num_objects=1, obj_shape=[7]),                                                     # unknown shape
+        dict(num_objects=1, obj_shape=[nat.SHAPE_BOX], obj_verts=[[[0.0, 1.0]]]),                # empty box
+        dict(num_objects=1, obj_shape=[nat.SHAPE_POLYGON], obj_nverts=[2], obj_verts=[tri]),     # too few vertices
+        dict(num_objects=1, obj_shape=[nat.SHAPE_POLYGON], obj_nverts=[3], obj_verts=[tri[::-1]]),   # clockwise
+        dict(num_objects=1, obj_shape=[nat.SHAPE_CIRCLE], obj_radius=[0.0]),                     # no radius
+        dict(num_objects=2, num_fixtures=1),                                                    # fewer fixtures than objects
+        dict(num_objects=1, num_fixtures=2, obj_fixture_body=[0, 3], obj_shape=[nat.SHAPE_BOX] * 2, obj_verts=[box, box]),   # body out of range
+        dict(num_objects=1, num_fixtures=2, obj_fixture_body=[0, 0], obj_shape=[nat.SHAPE_CIRCLE, nat.SHAPE_BOX],
+             obj_radius=[0.05, 0.0], obj_verts=[[[0, 0]], box]),                                  # a circle shares its body
+        dict(num_objects=2, num_fixtures=2, obj_fixture_body=[0, 0], obj_shape=[nat.SHAPE_BOX] * 2, obj_verts=[box, box]),   # object 1 has no fixture
+        dict(num_objects=1, obj_shape=[nat.SHAPE_BOX], obj_verts=[box], obj_friction=-1.0),
+    ]
+    for kw in bad:
+        assert create(**kw) == nat.KB_EINVAL, kw
+        assert lib.kb_last_error()
+
+
+def test_contact_capacity_matches_the_oracle(lib):
+    from oracle import oracle as O
+    h = C.c_void_p()
+    for n in (1, 2, 7, 16, 33, 64, 100, 300, 512, 1000, 1024):
+        for m in (0, 1, 4, 8):
+            cfg = nat.default_config(3, n, num_objects=m)
+            assert lib.kb_create(C.byref(cfg), C.byref(h)) == 0
+            cap = lib.kb_contact_capacity(h)
+            lds = lib.kb_lds_bytes(h)
+            lib.kb_destroy(h)
+            ocfg = O.default_config(3, n, num_objects=m)
+            assert cap == O.lib().kbo_contact_capacity(C.byref(ocfg)), (n, m)
+            assert lds <= 160 * 1024
+            if n == 1024:
+                assert lds <= 80 * 1024, 'two envs of 1024 kilobots must share a CU (LDS %d B with %d objects)' % (lds, m)
