@@ -624,7 +624,9 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
         //   coop: one island is so large that a single wave would serialise the env
         //   reg : every wave can hold its contacts in registers (<= KREG per lane) -> no contact arrays in the sweeps
         //   list: per-wave sweeps over the staged contact arrays
-        const bool coop = misc[M_MAXISL] > (unsigned)GIANT_ISLAND || nw == 1 || p.solver_mode == 2 || p.solver_mode == 4;
+        // (a one-wave workgroup is its own cooperative group; it may still take the register path)
+        const bool coopForced = misc[M_MAXISL] > (unsigned)GIANT_ISLAND || p.solver_mode == 2 || p.solver_mode == 4;
+        const bool coop = coopForced || nw == 1;
         if (!coop && !big && p.solver_mode == 0) {
             // Placement of the islands on the waves in order of size: the largest (= deepest) islands share the first
             // waves, the many tiny ones fill the rest.  A wave sweeps as many rounds as its deepest island has levels
@@ -663,7 +665,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
             maxw = 0;
             for (int w = 0; w < nw; ++w) maxw = max(maxw, misc[M_WCNT + w]);
         }
-        bool reg = !coop && !big && maxw <= 64u * KREG && p.solver_mode == 0;
+        bool reg = !coopForced && !big && maxw <= 64u * KREG && p.solver_mode == 0;
         if (!coop && !big && maxw > 64u * KREG && p.solver_mode == 0) {
             // The default placement (root id mod #waves) overloads a wave.  Place the islands of BIG_ISLAND contacts or
             // more one by one, largest first, each on the wave with the least load (ties: lowest root / lowest wave);

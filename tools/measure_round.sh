@@ -22,6 +22,7 @@ python3 bench.py > $OUT/bench_line.json 2> $OUT/bench.err
 echo bench done
 python3 bench.py --steps 40 --no-cpu-baseline --objects 4 > $OUT/bench_cfg4_line.json 2>> $OUT/bench.err
 python3 bench.py --steps 40 --no-cpu-baseline --objects 4 --boxes > $OUT/bench_cfg4_boxes_line.json 2>> $OUT/bench.err
+python3 bench.py --envs 256 --bots 64 --steps 400 --warmup 100 --no-cpu-baseline > $OUT/bench_cfg2_line.json 2>> $OUT/bench.err
 KB_HIP_LIB=$ROOT/gym_kilobots_amd/libkilobots_hip_prof.so python3 tools/phase_profile.py > $OUT/phase_cycles.txt 2>> $OUT/bench.err
 KB_HIP_LIB=$ROOT/gym_kilobots_amd/libkilobots_hip_prof.so python3 tools/phase_profile.py --objects 4 > $OUT/phase_cycles_cfg4.txt 2>> $OUT/bench.err
 # keep the merge small: the raw traces stay on the box except the per-kernel csv files
