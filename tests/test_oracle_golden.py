@@ -215,3 +215,19 @@ def test_f2_composite_light(golden):
     sim.step(1, light_action=np.array([[0.01, 0.0, 0.0, -0.02]]))
     np.testing.assert_allclose(sim.light_x[0], [g['lights'][0]['position'][0] + 0.001, g['lights'][1]['position'][0]], atol=1e-7)
     np.testing.assert_allclose(sim.light_y[0], [g['lights'][0]['position'][1], g['lights'][1]['position'][1] - 0.001], atol=1e-7)
+
+
+def test_oracle_semantics_regression():
+    """The oracle's own end states for three small scenes (tests/golden/oracle_regression.npz, written by
+    tools/gen_oracle_regression.py).  Not reference data: it makes a change of the specification a deliberate act."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('gen_oracle_regression', os.path.join(root, 'tools', 'gen_oracle_regression.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    want = np.load(os.path.join(root, 'tests', 'golden', 'oracle_regression.npz'))
+    got = mod.compute()
+    assert sorted(want.files) == sorted(got)
+    for k in want.files:
+        assert np.array_equal(want[k], got[k]), k
