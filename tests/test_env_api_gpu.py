@@ -110,3 +110,50 @@ def test_yaml_scene_with_boxes_on_gpu_equals_oracle_env():
     assert int(g.sim.status.max().item()) == int(o.sim.status.max().item())     # (dense spawn: warm-start slots may overflow)
     assert np.abs(og['objects'] - start).max() > 1e-3          # the swarm moved something
     g.close()
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2, 3, 4, 5])
+def test_random_yaml_scenes_on_gpu_equal_oracle_env(seed):
+    """Random YAML documents (every shape string, every light type, random inits): env on the HIP path == oracle-backed env."""
+    import yaml
+    from gym_kilobots_amd.envs import YamlKilobotsEnv
+    rng = np.random.RandomState(100 + seed)
+    shapes = ['square', 'rect', 'corner_quad', 'triangle', 'circle', 'l_shape', 't_shape', 'c_shape']
+    fixtures = {'square': 1, 'rect': 1, 'corner_quad': 1, 'triangle': 1, 'circle': 1, 'l_shape': 2, 't_shape': 2, 'c_shape': 3}
+    objs, budget = [], 8
+    for i in range(rng.randint(1, 5)):
+        sh = shapes[rng.randint(len(shapes))]
+        if fixtures[sh] > budget:
+            continue
+        budget -= fixtures[sh]
+        w = float(rng.uniform(0.04, 0.07) if sh == 'circle' else rng.uniform(0.1, 0.2))
+        init = 'random' if rng.rand() < 0.3 else [float(rng.uniform(-0.3, 0.3)), float(rng.uniform(-0.25, 0.25)), float(rng.uniform(-3, 3))]
+        objs.append('    - !ObjectConf {idx: %d, shape: %s, width: %.3f, height: %.3f, init: %s, color: ~, symmetry: 1}'
+                    % (i, sh, w, float(rng.uniform(0.1, 0.2)), init))
+    kind = ['circular', 'momentum', 'linear', 'composite'][rng.randint(4)]
+    if kind == 'linear':
+        light = 'light: !LightConf {type: linear, init: %.3f}' % rng.uniform(-3, 3)
+    elif kind == 'composite':
+        light = ('light: !LightConf\n  type: composite\n  init: fixed\n  components:\n'
+                 '    - !LightConf {type: circular, init: [-0.2, 0.0], radius: 0.3}\n'
+                 '    - !LightConf {type: momentum, init: [0.2, 0.1], radius: 0.25}')
+    else:
+        light = 'light: !LightConf {type: %s, init: %s, radius: %.2f}' % (kind, 'random' if rng.rand() < 0.5 else '[0.1, -0.1]', rng.uniform(0.2, 0.5))
+    doc = ('!EvalEnv\nwidth: 1.2\nheight: 0.9\nresolution: 500\nobjects:\n%s\n%s\n'
+           'kilobots: !KilobotsConf {num: %d, mean: %s, std: %.3f}\n'
+           % ('\n'.join(objs), light, rng.randint(5, 60), 'random' if rng.rand() < 0.3 else '[0.0, 0.0]', rng.uniform(0.05, 0.2)))
+    conf = yaml.load(doc, Loader=yaml.Loader)
+    g = YamlKilobotsEnv(configuration=conf)
+    o = YamlKilobotsEnv(configuration=conf, sim_factory=OracleBackend)
+    np.random.seed(7 + seed)
+    og = g.reset()
+    np.random.seed(7 + seed)
+    oo = o.reset()
+    adim = g.action_space.shape[0]
+    for k in range(15):
+        a = rng.uniform(-0.02, 0.02, adim) if kind != 'linear' else rng.uniform(-3, 3, adim)
+        og, *_ = g.step(a)
+        oo, *_ = o.step(a)
+        for key in ('kilobots', 'objects', 'light'):
+            assert np.array_equal(og[key], oo[key]), (seed, k, key, doc)
+    g.close()
