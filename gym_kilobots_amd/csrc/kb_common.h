@@ -202,7 +202,8 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ void wall_geom(const Params &p, int wl, float x, float y, float &dist, float &nx, float &ny) {
+template <class AR>
+__device__ __forceinline__ void wall_geom(const AR &p, int wl, float x, float y, float &dist, float &nx, float &ny) {
     switch (wl) {
     case 0: nx = 1.0f; ny = 0.0f; dist = x - p.xmin; break;
     case 1: nx = 0.0f; ny = 1.0f; dist = y - p.ymin; break;
@@ -224,7 +225,8 @@ __device__ __forceinline__ void wall_geom(const Params &p, int wl, float x, floa
 // b2TimeOfImpact for a circle (radius R) whose centre moves linearly from (x0,y0) to (x1,y1) against wall wl:
 // Box2D's control flow (conservative advancement + bisection / secant root finder) on the closed-form distance of
 // the centre to an axis-aligned wall.  True and t in [0,1] when the state is e_touching.
-__device__ __forceinline__ bool kb_toi_wall(const Params &p, int wl, float R, float x0, float y0, float x1, float y1, float &tout) {
+template <class AR>
+__device__ __forceinline__ bool kb_toi_wall(const AR &p, int wl, float R, float x0, float y0, float x1, float y1, float &tout) {
     const float total = R + B2_POLYGON_RADIUS;
     const float target = fmaxf(B2_LINEAR_SLOP, total - 3.0f * B2_LINEAR_SLOP);
     const float tol = 0.25f * B2_LINEAR_SLOP;

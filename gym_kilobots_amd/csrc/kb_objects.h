@@ -355,9 +355,9 @@ KB_DI void mc_candidate(int M, int t, int &owner, int &col) {
     }
 }
 
-// Manifold of candidate t at the current poses + impulses of the same features in the previous substep
-// (b2Contact::Update) + b2ContactSolver::InitializeVelocityConstraints; writes record t.  False: not touching.
-__device__ __noinline__ bool mc_detect(const ObjCtx &x, const Arena &p, int M, int t, const float *owsOld) {
+// Manifold of candidate t at the current poses + impulses of the same features in the stored manifold
+// (b2Contact::Update); writes the manifold part of record t.  False: not touching.
+__device__ __noinline__ bool mc_manifold(const ObjCtx &x, const Arena &p, int M, int t, const float *owsOld) {
     int owner, col;
     mc_candidate(M, t, owner, col);
     Manifold mf;
@@ -420,7 +420,26 @@ __device__ __noinline__ bool mc_detect(const ObjCtx &x, const Arena &p, int M, i
             for (int k = 0; k < 2; ++k)
                 if (o[3 * k] >= 0.0f && (int)o[3 * k] == mf.id[j]) { nimp[j] = o[3 * k + 1]; timp[j] = o[3 * k + 2]; break; }
     }
-    // b2ContactSolver::InitializeVelocityConstraints (b2WorldManifold::Initialize inside)
+    mci_set(x, MC_A, t, a); mci_set(x, MC_B, t, b);
+    mci_set(x, MC_TYPE, t, mf.type | (mf.count << 2));
+    mci_set(x, MC_ID, t, mf.id[0] | (mf.id[1] << 8));
+    mcf(x, MC_LNX, t) = mf.localNormal.x; mcf(x, MC_LNY, t) = mf.localNormal.y;
+    mcf(x, MC_LPX, t) = mf.localPoint.x; mcf(x, MC_LPY, t) = mf.localPoint.y;
+    mcf(x, MC_P0X, t) = mf.lp[0].x; mcf(x, MC_P0Y, t) = mf.lp[0].y; mcf(x, MC_P1X, t) = mf.lp[1].x; mcf(x, MC_P1Y, t) = mf.lp[1].y;
+    mcf(x, MC_NI0, t) = nimp[0]; mcf(x, MC_NI1, t) = nimp[1]; mcf(x, MC_TI0, t) = timp[0]; mcf(x, MC_TI1, t) = timp[1];
+    return true;
+}
+
+// b2ContactSolver::InitializeVelocityConstraints (b2WorldManifold::Initialize inside) of record t at the current poses
+__device__ __noinline__ void mc_init_velocity(const ObjCtx &x, int t) {
+    const int a = mci(x, MC_A, t), b = mci(x, MC_B, t);
+    Manifold mf;
+    {
+        const int tc = mci(x, MC_TYPE, t);
+        mf.type = tc & 3; mf.count = (tc >> 2) & 3;
+    }
+    mf.localNormal = mk2(mcf(x, MC_LNX, t), mcf(x, MC_LNY, t)); mf.localPoint = mk2(mcf(x, MC_LPX, t), mcf(x, MC_LPY, t));
+    mf.lp[0] = mk2(mcf(x, MC_P0X, t), mcf(x, MC_P0Y, t)); mf.lp[1] = mk2(mcf(x, MC_P1X, t), mcf(x, MC_P1Y, t));
     const BState A = body_get(x, a), B = body_get(x, b);
     const XF xfA = body_xf(x, a), xfB = body_xf(x, b);
     const float radA = body_radius(x, a), radB = body_radius(x, b);
@@ -484,19 +503,19 @@ __device__ __noinline__ bool mc_detect(const ObjCtx &x, const Arena &p, int M, i
             vcount = 1;                                     // the constraints are redundant: use one
         }
     }
-    mci_set(x, MC_A, t, a); mci_set(x, MC_B, t, b);
     mci_set(x, MC_TYPE, t, mf.type | (mf.count << 2) | (vcount << 4));
-    mci_set(x, MC_ID, t, mf.id[0] | (mf.id[1] << 8));
-    mcf(x, MC_LNX, t) = mf.localNormal.x; mcf(x, MC_LNY, t) = mf.localNormal.y;
-    mcf(x, MC_LPX, t) = mf.localPoint.x; mcf(x, MC_LPY, t) = mf.localPoint.y;
-    mcf(x, MC_P0X, t) = mf.lp[0].x; mcf(x, MC_P0Y, t) = mf.lp[0].y; mcf(x, MC_P1X, t) = mf.lp[1].x; mcf(x, MC_P1Y, t) = mf.lp[1].y;
-    mcf(x, MC_NI0, t) = nimp[0]; mcf(x, MC_NI1, t) = nimp[1]; mcf(x, MC_TI0, t) = timp[0]; mcf(x, MC_TI1, t) = timp[1];
     mcf(x, MC_NX, t) = normal.x; mcf(x, MC_NY, t) = normal.y;
     mcf(x, MC_RA0X, t) = rA[0].x; mcf(x, MC_RA0Y, t) = rA[0].y; mcf(x, MC_RB0X, t) = rB[0].x; mcf(x, MC_RB0Y, t) = rB[0].y;
     mcf(x, MC_RA1X, t) = rA[1].x; mcf(x, MC_RA1Y, t) = rA[1].y; mcf(x, MC_RB1X, t) = rB[1].x; mcf(x, MC_RB1Y, t) = rB[1].y;
     mcf(x, MC_NM0, t) = nmass[0]; mcf(x, MC_NM1, t) = nmass[1]; mcf(x, MC_TM0, t) = tmass[0]; mcf(x, MC_TM1, t) = tmass[1];
     mcf(x, MC_K11, t) = k11; mcf(x, MC_K12, t) = k12; mcf(x, MC_K22, t) = k22;
     mcf(x, MC_N11, t) = n11; mcf(x, MC_N12, t) = n12; mcf(x, MC_N22, t) = n22;
+}
+
+// b2Contact::Update + InitializeVelocityConstraints of candidate t (the start of a substep).  False: not touching.
+KB_DI bool mc_detect(const ObjCtx &x, const Arena &p, int M, int t, const float *owsOld) {
+    if (!mc_manifold(x, p, M, t, owsOld)) return false;
+    mc_init_velocity(x, t);
     return true;
 }
 
@@ -588,7 +607,7 @@ __device__ __noinline__ void mc_solve_velocity(const ObjCtx &x, int t) {
 }
 
 // b2ContactSolver::SolvePositionConstraints of record t; returns its minimum separation
-__device__ __noinline__ float mc_solve_position(const ObjCtx &x, int t) {
+__device__ __noinline__ float mc_solve_position(const ObjCtx &x, int t, float baumgarte) {
     const int a = mci(x, MC_A, t), b = mci(x, MC_B, t);
     const int tc = mci(x, MC_TYPE, t), type = tc & 3, count = (tc >> 2) & 3;
     BState A = body_get(x, a), B = body_get(x, b);
@@ -622,7 +641,7 @@ __device__ __noinline__ float mc_solve_position(const ObjCtx &x, int t) {
         }
         const V2 rA = v_sub(point, A.c), rB = v_sub(point, B.c);
         minSeparation = fminf(minSeparation, separation);
-        const float C = kb_clampf(B2_BAUMGARTE * (separation + B2_LINEAR_SLOP), -B2_MAX_LINEAR_CORRECTION, 0.0f);
+        const float C = kb_clampf(baumgarte * (separation + B2_LINEAR_SLOP), -B2_MAX_LINEAR_CORRECTION, 0.0f);
         const float rnA = v_cross(rA, normal), rnB = v_cross(rB, normal);
         const float K = A.m + B.m + A.i * rnA * rnA + B.i * rnB * rnB;
         const float impulse = K > 0.0f ? -C / K : 0.0f;
@@ -632,6 +651,148 @@ __device__ __noinline__ float mc_solve_position(const ObjCtx &x, int t) {
     }
     body_put_pos(x, a, A); body_put_pos(x, b, B);
     return minSeparation;
+}
+
+// ---- continuous step of the objects against the walls (b2World::SolveTOI) ------------------------------------------
+KB_DI float wall_sdist(const Arena &p, int wl, V2 v) {
+    switch (wl) {
+    case 0: return v.x - p.xmin;
+    case 1: return v.y - p.ymin;
+    case 2: return p.xmax - v.x;
+    default: return p.ymax - v.y;
+    }
+}
+
+// b2TimeOfImpact of polygon fixture T (body table B) sweeping from (c0, a0) to (c1, a1) against wall wl.  The wall
+// is proxy A, so the separation function is e_faceA on the wall: the signed distance from the wall line of the
+// polygon's support vertex along -normal.  Box2D's control flow (conservative advancement, push-back over the
+// vertices, bisection / secant root finder).  True and t when the state is e_touching.
+__device__ __noinline__ bool toi_wall_poly(const Arena &p, int wl, const float *T, const float *B, V2 c0, float a0, V2 c1, float a1, float &tout) {
+    const float total = B2_POLYGON_RADIUS + B2_POLYGON_RADIUS;
+    const float target = fmaxf(B2_LINEAR_SLOP, total - 3.0f * B2_LINEAR_SLOP);
+    const float tol = 0.25f * B2_LINEAR_SLOP;
+    const int n = ot_n(T);
+    {                                                                 // b2Sweep::Normalize
+        const float twoPi = 2.0f * B2_PI;
+        const float dd = twoPi * floorf(a0 / twoPi);
+        a0 -= dd; a1 -= dd;
+    }
+    const V2 axis = v_neg(wall_normal(wl));
+    auto xf_at = [&](float t) __attribute__((always_inline)) -> XF {
+        return xf_of_body(B, (1.0f - t) * c0.x + t * c1.x, (1.0f - t) * c0.y + t * c1.y, (1.0f - t) * a0 + t * a1);
+    };
+    float t1 = 0.0f;
+    for (int iter = 0; iter < 20; ++iter) {
+        const XF x1 = xf_at(t1);
+        float dist = 3.402823466e+38f;
+        for (int i = 0; i < n; ++i) dist = fminf(dist, wall_sdist(p, wl, xf_mul(x1, ot_v(T, i))));
+        if (dist <= 0.0f) return false;                               // overlapped
+        if (dist < target + tol) { tout = t1; return true; }          // touching
+        float t2 = 1.0f;
+        for (int push = 0; push < 8; ++push) {
+            const XF x2 = xf_at(t2);
+            const V2 axisB = rot_mulT(x2, axis);                      // FindMinSeparation
+            int idx = 0;
+            float best = v_dot(ot_v(T, 0), axisB);
+            for (int i = 1; i < n; ++i) { const float val = v_dot(ot_v(T, i), axisB); if (val > best) { best = val; idx = i; } }
+            float s2 = wall_sdist(p, wl, xf_mul(x2, ot_v(T, idx)));
+            if (s2 > target + tol) return false;                      // separated at the end of the step
+            if (s2 > target - tol) { t1 = t2; break; }
+            float s1 = wall_sdist(p, wl, xf_mul(x1, ot_v(T, idx)));
+            if (s1 < target - tol) return false;                      // failed
+            if (s1 <= target + tol) { tout = t1; return true; }
+            float r1 = t1, r2 = t2;
+            for (int root = 0; root < 50; ++root) {
+                const float t = (root & 1) ? r1 + (target - s1) * (r2 - r1) / (s2 - s1) : 0.5f * (r1 + r2);
+                const XF xt = xf_at(t);
+                const float sv = wall_sdist(p, wl, xf_mul(xt, ot_v(T, idx)));
+                if (fabsf(sv - target) < tol) { t2 = t; break; }
+                if (sv > target) { r1 = t; s1 = sv; } else { r2 = t; s2 = sv; }
+            }
+        }
+    }
+    return false;                                                     // failed (iteration cap)
+}
+
+// b2World::SolveTOI + b2Island::SolveTOI for object m against the arena walls with the manifold constraints' contact
+// model (friction, block solver, rotation), zero initial impulses.  The body's state is the one in LDS (pose after
+// b2Island::Solve); (c0, a0) = its pose at the start of the substep.  The wall records of the body's fixtures are
+// reused; `ows` = this env's warm-start table (b2Contact::Update at the TOI pose re-matches the stored impulses).
+__device__ __noinline__ void toi_walls_object(const ObjCtx &x, const Arena &p, int F, int m, float c0x, float c0y, float a0,
+                                              float h, int vel_iters, float *ows) {
+    const int N = x.N, b = N + m;
+    const float *B = x.objBody + m * BT_WORDS;
+    const int npair = F * (F - 1) / 2;
+    V2 c0 = mk2(c0x, c0y);
+    {   // quick reject: a body that stays clear of every wall by more than its bounding radius has no TOI event
+        float bound = 0.0f;
+        for (int f = 0; f < F; ++f) { const float *T = x.objTab + f * OT_WORDS; if (ot_body(T) == m) bound = fmaxf(bound, T[OT_BOUND]); }
+        bound += 4.0f * B2_POLYGON_RADIUS;
+        const float xe = x.pos[b].x, ye = x.pos[b].y;
+        const float m0 = fminf(fminf(c0x - p.xmin, p.xmax - c0x), fminf(c0y - p.ymin, p.ymax - c0y));
+        const float m1 = fminf(fminf(xe - p.xmin, p.xmax - xe), fminf(ye - p.ymin, p.ymax - ye));
+        if (m0 > bound && m1 > bound) return;
+    }
+    float alpha0 = 0.0f;
+    for (int ev = 0; ev < B2_MAX_SUBSTEPS; ++ev) {
+        const V2 c1 = mk2(x.pos[b].x, x.pos[b].y);
+        const float a1 = x.objA[m];
+        float minAlpha = 1.0f;
+        for (int f = 0; f < F; ++f) {
+            const float *T = x.objTab + f * OT_WORDS;
+            if (ot_body(T) != m) continue;
+            for (int wl = 0; wl < 4; ++wl) {
+                float t = 0.0f, alpha = 1.0f;
+                const bool hit = ot_kind(T) == KB_SHAPE_CIRCLE ? kb_toi_wall(p, wl, T[OT_RADIUS], c0.x, c0.y, c1.x, c1.y, t)
+                                                               : toi_wall_poly(p, wl, T, B, c0, a0, c1, a1, t);
+                if (hit) alpha = fminf(alpha0 + (1.0f - alpha0) * t, 1.0f);
+                if (alpha < minAlpha) minAlpha = alpha;
+            }
+        }
+        if (1.0f - 10.0f * B2_EPSILON < minAlpha) break;
+        const float beta = (minAlpha - alpha0) / (1.0f - alpha0);      // b2Body::Advance
+        c0.x += beta * (c1.x - c0.x); c0.y += beta * (c1.y - c0.y); a0 += beta * (a1 - a0);
+        alpha0 = minAlpha;
+        x.pos[b].x = c0.x; x.pos[b].y = c0.y; x.objA[m] = a0;
+        unsigned touch = 0u;                                            // bit f * 4 + wl
+        for (int f = 0; f < F; ++f) {
+            if (ot_body(x.objTab + f * OT_WORDS) != m) continue;
+            for (int wl = 0; wl < 4; ++wl) {
+                const int t = npair + f * 4 + wl;
+                float *row = ows + (f * KB_OWS_COLS + 8 + wl) * KB_OWS_WORDS;
+                float o[KB_OWS_WORDS] = {-1.0f, -1.0f, -1.0f, -1.0f, -1.0f, -1.0f};
+                if (mc_manifold(x, p, F, t, ows)) {
+                    touch |= 1u << (f * 4 + wl);
+                    const int cnt = (mci(x, MC_TYPE, t) >> 2) & 3, ids = mci(x, MC_ID, t);
+                    o[0] = (float)(ids & 255); o[1] = mcf(x, MC_NI0, t); o[2] = mcf(x, MC_TI0, t);
+                    if (cnt == 2) { o[3] = (float)((ids >> 8) & 255); o[4] = mcf(x, MC_NI1, t); o[5] = mcf(x, MC_TI1, t); }
+                    mcf(x, MC_NI0, t) = 0.0f; mcf(x, MC_NI1, t) = 0.0f; mcf(x, MC_TI0, t) = 0.0f; mcf(x, MC_TI1, t) = 0.0f;
+                }
+#pragma unroll
+                for (int k = 0; k < KB_OWS_WORDS; ++k) row[k] = o[k];
+            }
+        }
+        for (int it = 0; it < 20; ++it) {                              // SolveTOIPositionConstraints
+            float minSep = 0.0f;
+            for (unsigned m_ = touch; m_; m_ &= m_ - 1) minSep = fminf(minSep, mc_solve_position(x, npair + __builtin_ctz(m_), B2_TOI_BAUMGARTE));
+            if (minSep >= -1.5f * B2_LINEAR_SLOP) break;
+        }
+        c0 = mk2(x.pos[b].x, x.pos[b].y); a0 = x.objA[m];             // leap of faith to the new safe state
+        for (unsigned m_ = touch; m_; m_ &= m_ - 1) mc_init_velocity(x, npair + __builtin_ctz(m_));
+        for (int it = 0; it < vel_iters; ++it)
+            for (unsigned m_ = touch; m_; m_ &= m_ - 1) mc_solve_velocity(x, npair + __builtin_ctz(m_));
+        const float hh = (1.0f - minAlpha) * h;                         // integrate the rest of the step
+        float vx = x.vel[b].x, vy = x.vel[b].y, w = x.objW[m];
+        const float tx = hh * vx, ty = hh * vy;
+        if (tx * tx + ty * ty > B2_MAX_TRANSLATION_SQ) {
+            const float ratio = B2_MAX_TRANSLATION / sqrtf(tx * tx + ty * ty);
+            vx *= ratio; vy *= ratio;
+        }
+        const float rot = hh * w;
+        if (rot * rot > B2_MAX_ROTATION_SQ) w *= B2_MAX_ROTATION / fabsf(rot);
+        x.vel[b].x = vx; x.vel[b].y = vy; x.objW[m] = w;
+        x.pos[b].x += hh * vx; x.pos[b].y += hh * vy; x.objA[m] += hh * w;
+    }
 }
 
 // ---- kilobot - polygon object contact (class 10; Box2D: A = the polygon, B = the kilobot, one point, friction 0) --

@@ -737,7 +737,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                     const int t = __builtin_ctzll(m_);
                     const int isl = mci(ox, MC_ISL, t);
                     if (!act[isl]) continue;
-                    const float minSep = mc_solve_position(ox, t);
+                    const float minSep = mc_solve_position(ox, t, B2_BAUMGARTE);
                     if (minSep < -3.0f * B2_LINEAR_SLOP) { nxt[isl] = 1; viol = true; }
                 }
             return viol;
@@ -1547,7 +1547,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
         // the event logic exists once in the kernel instead of once per unrolled bot slot.
         if (p.toi_walls) {
             float *cTh0 = reinterpret_cast<float *>(lInfo), *cTh = lAcc, *cW = reinterpret_cast<float *>(lCbk);
-            int cand[BPT], candObj = -1;
+            int cand[BPT];
             if (tid == 0) misc[M_NCON] = 0;
             __syncthreads();
 #pragma unroll
@@ -1565,26 +1565,25 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
                 cand[q] = i;
                 lPair[i] = (unsigned)b; cTh0[i] = sth0[q]; cTh[i] = th[q]; cW[i] = bw[q];
             }
-            if (tid < M && objBody[tid * BT_WORDS + BT_KIND] == 0.0f) {   // circles only: no continuous step for polygons
-                const int i = (int)atomicAdd(&misc[M_NCON], 1u);
-                if (i < capL_ / 2) { candObj = i; lPair[i] = (unsigned)(N + tid); cTh0[i] = objA0[tid]; cTh[i] = objA[tid]; cW[i] = objW[tid]; }
-                else atomicOr(&misc[M_STATUS], 8u);
-            }
             __syncthreads();
             const int ncand = min((int)misc[M_NCON], capL_ / 2);
             for (int i = tid; i < ncand; i += nt) {
                 const int b = (int)lPair[i];
-                const bool isObj = b >= N;
-                const float R = isObj ? objBody[(b - N) * BT_WORDS + BT_RADIUS] : p.r_bot, im = isObj ? objBody[(b - N) * BT_WORDS + BT_IM] : p.im_bot;
+                const float R = p.r_bot, im = p.im_bot;
                 float x_ = pos[b].x, y_ = pos[b].y, a_ = cTh[i], vx_ = vel[b].x, vy_ = vel[b].y, w_ = cW[i];
                 kb_toi_walls_body(p, R, im, start[b].x, start[b].y, cTh0[i], x_, y_, a_, vx_, vy_, w_);
                 pos[b].x = x_; pos[b].y = y_; vel[b].x = vx_; vel[b].y = vy_; cTh[i] = a_; cW[i] = w_;
+            }
+            if (OBJ && tid < M) {   // objects: the TOI sub-solve runs on the manifold-constraint records of their wall contacts
+                Arena ar;
+                ar.xmin = p.xmin; ar.ymin = p.ymin; ar.xmax = p.xmax; ar.ymax = p.ymax;
+                toi_walls_object(ox, ar, F, tid, start[N + tid].x, start[N + tid].y, objA0[tid], p.h, p.vel_iters,
+                                 g.ows_acc + (size_t)e * (MAXOBJ * KB_OWS_COLS * KB_OWS_WORDS));
             }
             __syncthreads();
 #pragma unroll
             for (int q = 0; q < BPT; ++q)
                 if (cand[q] >= 0) { th[q] = cTh[cand[q]]; bw[q] = cW[cand[q]]; }
-            if (candObj >= 0) { objA[tid] = cTh[candObj]; objW[tid] = cW[candObj]; }
         }
         // The state of an object between substeps is its body origin (what one-substep launches store and load, and
         // what the specification's substep does): bodies whose centre of mass is off the origin go through the same

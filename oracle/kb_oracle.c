@@ -24,13 +24,15 @@
  *     kilobots_env.py:46-51 with exact axis normals.
  *   - no sleeping (world is created with doSleep=True, kilobots_env.py:45).
  *   - continuous step (b2World::SolveTOI) only against the static walls, which is all Box2D does for
- *     non-bullet bodies; b2TimeOfImpact's control flow is followed with the closed-form linear distance
- *     of a circle centre to an axis-aligned wall instead of GJK + separating-axis evaluation.
+ *     non-bullet bodies; b2TimeOfImpact's control flow is followed with closed-form wall distances (circle
+ *     centre; support vertex of a polygon, i.e. the e_faceA separation function on the wall) instead of GJK.
+ *     Kilobots: frictionless point contact.  Objects: the TOI sub-solve runs on the manifold constraints of the
+ *     body's wall contacts (friction, block solver, rotation), see toi_walls_object.
  *   - pushable objects are circles, boxes or single convex polygons (body.py:129-192, 217-262) with Box2D's
  *     full contact model among themselves and against the walls (manifolds with feature ids, Coulomb friction
  *     sqrt(f1 f2), two-point block solver, rotation); kilobot contacts are frictionless in the reference
  *     (kilobot.py:26) and central on the kilobot side.  Bodies may carry several convex fixtures (LForm, TForm, CForm,
- *     body.py:277-334) with b2Body::ResetMassData's centre of mass; no continuous step for polygons.
+ *     body.py:277-334) with b2Body::ResetMassData's centre of mass.
  */
 #include "kb_oracle.h"
 
@@ -672,6 +674,29 @@ static void mc_warm(const kbo_state *st, int e, mc_t *c) {
     }
 }
 
+/* manifold of fixture f against wall wl at the current pose of its body (impulses zero); 0: not touching */
+static int wall_manifold(const derived_t *d, const work_t *w, int f, int wl, mc_t *out) {
+    const shape_t *sh = &d->shape[f];
+    const int N = w->N, m = d->fix_body[f];
+    mc_t c; memset(&c, 0, sizeof(c));
+    c.a = -1 - wl; c.b = N + m; c.owner = f; c.col = 8 + wl; c.friction = d->mu_ow;
+    c.radA = B2_POLYGON_RADIUS; c.radB = sh->radius;
+    if (sh->kind == KBO_SHAPE_CIRCLE) {                                        /* b2CollideEdgeAndCircle, region AB */
+        float nx, ny; float dist = wall_dist(d, wl, w->px[N + m], w->py[N + m], &nx, &ny);
+        float rwo = B2_POLYGON_RADIUS + sh->radius;
+        if (dist * dist > rwo * rwo) return 0;
+        if (dist < 0.0f) { nx = -nx; ny = -ny; }
+        c.m.type = 1; c.m.count = 1; c.m.localNormal = V2(nx, ny); c.m.localPoint = wall_point(d, wl);
+        c.m.lp[0] = V2(0.0f, 0.0f); c.m.id[0] = 0;
+    } else {
+        xf_t xb = body_xf(w, c.b);
+        collide_wall_poly(&c.m, d, wl, sh, &xb);
+        if (c.m.count == 0) return 0;
+    }
+    *out = c;
+    return 1;
+}
+
 /* all object-object and object-wall manifolds of one env, in canonical order: fixture pairs (f1 < f2, different
  * bodies) lexicographically, then (fixture, wall) */
 static void detect_mc(const derived_t *d, const kbo_state *st, int e, work_t *w) {
@@ -716,23 +741,8 @@ static void detect_mc(const derived_t *d, const kbo_state *st, int e, work_t *w)
         }
     for (int f = 0; f < F; ++f)
         for (int wl = 0; wl < 4; ++wl) {
-            const shape_t *sh = &d->shape[f];
-            const int m = d->fix_body[f];
-            mc_t c; memset(&c, 0, sizeof(c));
-            c.a = -1 - wl; c.b = N + m; c.owner = f; c.col = 8 + wl; c.friction = d->mu_ow;
-            c.radA = B2_POLYGON_RADIUS; c.radB = sh->radius;
-            if (sh->kind == KBO_SHAPE_CIRCLE) {                                        /* b2CollideEdgeAndCircle, region AB */
-                float nx, ny; float dist = wall_dist(d, wl, w->px[N + m], w->py[N + m], &nx, &ny);
-                float rwo = B2_POLYGON_RADIUS + sh->radius;
-                if (dist * dist > rwo * rwo) continue;
-                if (dist < 0.0f) { nx = -nx; ny = -ny; }
-                c.m.type = 1; c.m.count = 1; c.m.localNormal = V2(nx, ny); c.m.localPoint = wall_point(d, wl);
-                c.m.lp[0] = V2(0.0f, 0.0f); c.m.id[0] = 0;
-            } else {
-                xf_t xb = body_xf(w, c.b);
-                collide_wall_poly(&c.m, d, wl, sh, &xb);
-                if (c.m.count == 0) continue;
-            }
+            mc_t c;
+            if (!wall_manifold(d, w, f, wl, &c)) continue;
             mc_warm(st, e, &c);
             w->mc[w->nmc++] = c;
         }
@@ -1115,7 +1125,7 @@ static void mc_solve_velocity(const derived_t *d, work_t *w, mc_t *c) {
 }
 
 /* b2ContactSolver::SolvePositionConstraints for one contact; returns its minimum separation */
-static float mc_solve_position(const derived_t *d, work_t *w, mc_t *c) {
+static float mc_solve_position(const derived_t *d, work_t *w, mc_t *c, float baumgarte) {
     bstate_t A = body_get(d, w, c->a), B = body_get(d, w, c->b);
     float minSeparation = 0.0f;
     for (int j = 0; j < c->m.count; ++j) {
@@ -1144,7 +1154,7 @@ static float mc_solve_position(const derived_t *d, work_t *w, mc_t *c) {
         }
         v2 rA = v_sub(point, A.c), rB = v_sub(point, B.c);
         minSeparation = fminf(minSeparation, separation);
-        float C = clampf(B2_BAUMGARTE * (separation + B2_LINEAR_SLOP), -B2_MAX_LINEAR_CORRECTION, 0.0f);
+        float C = clampf(baumgarte * (separation + B2_LINEAR_SLOP), -B2_MAX_LINEAR_CORRECTION, 0.0f);
         float rnA = v_cross(rA, normal), rnB = v_cross(rB, normal);
         float K = A.m + B.m + A.i * rnA * rnA + B.i * rnB * rnB;
         float impulse = K > 0.0f ? -C / K : 0.0f;
@@ -1154,6 +1164,137 @@ static float mc_solve_position(const derived_t *d, work_t *w, mc_t *c) {
     }
     body_put_pos(w, c->a, &A); body_put_pos(w, c->b, &B);
     return minSeparation;
+}
+
+/* b2TimeOfImpact for polygon fixture f of a body sweeping from (c0, a0) to (c1, a1) against wall wl: the separation
+ * function is e_faceA with the wall as the face, i.e. the signed distance of the deepest vertex from the wall line;
+ * Box2D's control flow (conservative advancement, push-back over the vertices, bisection / secant root finder).
+ * Returns 1 and *t when the state is e_touching. */
+static int toi_wall_poly(const derived_t *d, int wl, int f, int m, v2 c0, float a0, v2 c1, float a1, float *tout) {
+    const shape_t *sh = &d->shape[f];
+    const float total = B2_POLYGON_RADIUS + B2_POLYGON_RADIUS;
+    const float target = fmaxf(B2_LINEAR_SLOP, total - 3.0f * B2_LINEAR_SLOP);
+    const float tol = 0.25f * B2_LINEAR_SLOP;
+    float nx, ny;
+    {                                                                 /* b2Sweep::Normalize */
+        const float twoPi = 2.0f * B2_PI;
+        const float dd = twoPi * floorf(a0 / twoPi);
+        a0 -= dd; a1 -= dd;
+    }
+    wall_dist(d, wl, 0.0f, 0.0f, &nx, &ny);
+    const v2 axis = V2(-nx, -ny);                                     /* -normal of the face (wall = proxy A) */
+#define XF_AT(t) xf_of_body(d, m, V2((1.0f - (t)) * c0.x + (t) * c1.x, (1.0f - (t)) * c0.y + (t) * c1.y), (1.0f - (t)) * a0 + (t) * a1)
+#define VERT_AT(xf, i) wall_dist(d, wl, xf_mul(&(xf), sh->v[i]).x, xf_mul(&(xf), sh->v[i]).y, &nx, &ny)
+    float t1 = 0.0f;
+    for (int iter = 0; iter < 20; ++iter) {
+        xf_t x1 = XF_AT(t1);
+        float dist = 3.402823466e+38f;
+        for (int i = 0; i < sh->n; ++i) dist = fminf(dist, VERT_AT(x1, i));
+        if (dist <= 0.0f) return 0;                                   /* overlapped */
+        if (dist < target + tol) { *tout = t1; return 1; }            /* touching */
+        float t2 = 1.0f;
+        int done = 0;
+        for (int push = 0; push < 8; ++push) {
+            xf_t x2 = XF_AT(t2);
+            /* FindMinSeparation, e_faceA: support vertex of the polygon along -normal in its own frame */
+            const v2 axisB = V2(x2.c * axis.x + x2.s * axis.y, -x2.s * axis.x + x2.c * axis.y);
+            int idx = 0; float best = v_dot(sh->v[0], axisB);
+            for (int i = 1; i < sh->n; ++i) { float val = v_dot(sh->v[i], axisB); if (val > best) { best = val; idx = i; } }
+            float s2 = VERT_AT(x2, idx);
+            if (s2 > target + tol) return 0;                          /* separated at the end of the step */
+            if (s2 > target - tol) { t1 = t2; break; }                /* advance the sweeps */
+            float s1 = VERT_AT(x1, idx);                               /* Evaluate(idx, t1) */
+            if (s1 < target - tol) return 0;                          /* failed */
+            if (s1 <= target + tol) { *tout = t1; return 1; }         /* touching */
+            float r1 = t1, r2 = t2;
+            for (int root = 0; root < 50; ++root) {                   /* 1D root finder on this vertex */
+                float t = (root & 1) ? r1 + (target - s1) * (r2 - r1) / (s2 - s1) : 0.5f * (r1 + r2);
+                xf_t xt = XF_AT(t);
+                float sv = VERT_AT(xt, idx);
+                if (fabsf(sv - target) < tol) { t2 = t; break; }
+                if (sv > target) { r1 = t; s1 = sv; } else { r2 = t; s2 = sv; }
+            }
+            (void)done;
+        }
+    }
+#undef XF_AT
+#undef VERT_AT
+    return 0;                                                         /* failed (iteration cap) */
+}
+
+/* b2World::SolveTOI + b2Island::SolveTOI for ONE pushable object (body N + m) against the arena walls, with the
+ * contact model of the manifold constraints (friction, block solver, rotation); impulses start at zero (no warm
+ * starting in the TOI sub-solve).  The body's state in the work arrays is (pose after b2Island::Solve, velocity). */
+static void toi_walls_object(const kbo_config *cfg, const derived_t *d, kbo_state *st, int e, work_t *w, int m) {
+    const int N = w->N, b = N + m;
+    const float h = d->h;
+    float alpha0 = 0.0f;
+    v2 c0 = V2(w->x0[b], w->y0[b]);
+    float a0 = w->a0[b];
+    for (int ev = 0; ev < B2_MAX_SUBSTEPS; ++ev) {
+        const v2 c1 = V2(w->px[b], w->py[b]);
+        const float a1 = w->ang[b];
+        float minAlpha = 1.0f;
+        for (int f = 0; f < d->nfix; ++f) {
+            if (d->fix_body[f] != m) continue;
+            for (int wl = 0; wl < 4; ++wl) {
+                float t, alpha = 1.0f;
+                int hit = d->shape[f].kind == KBO_SHAPE_CIRCLE
+                        ? toi_wall(d, wl, d->shape[f].radius, c0.x, c0.y, c1.x, c1.y, &t)
+                        : toi_wall_poly(d, wl, f, m, c0, a0, c1, a1, &t);
+                if (hit) alpha = fminf(alpha0 + (1.0f - alpha0) * t, 1.0f);
+                if (alpha < minAlpha) minAlpha = alpha;
+            }
+        }
+        if (1.0f - 10.0f * B2_EPSILON < minAlpha) break;
+        /* b2Body::Advance */
+        const float beta = (minAlpha - alpha0) / (1.0f - alpha0);
+        c0.x += beta * (c1.x - c0.x); c0.y += beta * (c1.y - c0.y); a0 += beta * (a1 - a0);
+        alpha0 = minAlpha;
+        w->px[b] = c0.x; w->py[b] = c0.y; w->ang[b] = a0;
+        /* the contacts of the body with the static walls at the TOI pose (b2Contact::Update) */
+        /* (the TOI contact itself always touches: target separation 0.005 < the 0.02 skin of the manifold test.)
+         * b2Contact::Update also re-matches the stored impulses to the new manifold's ids; the TOI solve itself starts
+         * from zero impulses and stores nothing. */
+        mc_t tc[4 * KBO_MAX_OBJECTS];
+        int ntc = 0;
+        for (int f = 0; f < d->nfix; ++f) {
+            if (d->fix_body[f] != m) continue;
+            for (int wl = 0; wl < 4; ++wl) {
+                float *row = st->ows_acc + (((size_t)e * KBO_MAX_OBJECTS + f) * OWS + 8 + wl) * OWW;
+                if (wall_manifold(d, w, f, wl, &tc[ntc])) {
+                    mc_t *c = &tc[ntc++];
+                    mc_warm(st, e, c);
+                    for (int k = 0; k < OWW; ++k) row[k] = -1.0f;
+                    for (int j = 0; j < c->m.count; ++j) { row[3 * j] = (float)c->m.id[j]; row[3 * j + 1] = c->nimp[j]; row[3 * j + 2] = c->timp[j]; }
+                    c->nimp[0] = c->nimp[1] = c->timp[0] = c->timp[1] = 0.0f;
+                } else {
+                    for (int k = 0; k < OWW; ++k) row[k] = -1.0f;
+                }
+            }
+        }
+        /* b2ContactSolver::SolveTOIPositionConstraints, 20 iterations */
+        for (int it = 0; it < 20; ++it) {
+            float minSep = 0.0f;
+            for (int i = 0; i < ntc; ++i) minSep = fminf(minSep, mc_solve_position(d, w, &tc[i], B2_TOI_BAUMGARTE));
+            if (minSep >= -1.5f * B2_LINEAR_SLOP) break;
+        }
+        c0 = V2(w->px[b], w->py[b]); a0 = w->ang[b];                /* leap of faith to the new safe state */
+        /* velocity constraints without warm starting */
+        for (int i = 0; i < ntc; ++i) mc_init_velocity(d, w, &tc[i]);
+        for (int it = 0; it < cfg->vel_iters; ++it)
+            for (int i = 0; i < ntc; ++i) mc_solve_velocity(d, w, &tc[i]);
+        /* integrate the rest of the step */
+        const float hh = (1.0f - minAlpha) * h;
+        float tx = hh * w->vx[b], ty = hh * w->vy[b];
+        if (tx * tx + ty * ty > B2_MAX_TRANSLATION_SQ) {
+            float ratio = B2_MAX_TRANSLATION / sqrtf(tx * tx + ty * ty);
+            w->vx[b] *= ratio; w->vy[b] *= ratio;
+        }
+        float rot = hh * w->bw[b];
+        if (rot * rot > B2_MAX_ROTATION_SQ) w->bw[b] *= B2_MAX_ROTATION / fabsf(rot);
+        w->px[b] += hh * w->vx[b]; w->py[b] += hh * w->vy[b]; w->ang[b] += hh * w->bw[b];
+    }
 }
 
 /* b2Island::Solve for one env (all islands; islands only matter for the position-iteration early-out) */
@@ -1368,7 +1509,7 @@ static void world_step_env(const kbo_config *cfg, const derived_t *d, kbo_state 
             mc_t *c = &w->mc[i];
             int isl = w->parent[c->b];
             if (!w->active[isl]) continue;
-            float minSep = mc_solve_position(d, w, c);
+            float minSep = mc_solve_position(d, w, c, B2_BAUMGARTE);
             if (minSep < -3.0f * B2_LINEAR_SLOP) { w->next_active[isl] = 1; any = 1; }
         }
         memcpy(w->active, w->next_active, (size_t)T);
@@ -1379,12 +1520,7 @@ static void world_step_env(const kbo_config *cfg, const derived_t *d, kbo_state 
         for (int b = 0; b < N; ++b)
             toi_walls_body(cfg, d, d->r_bot, d->im_bot, w->x0[b], w->y0[b], w->a0[b], &w->px[b], &w->py[b],
                            &st->theta[(size_t)e * N + b], &w->vx[b], &w->vy[b], &w->bw[b]);
-        for (int f = 0; f < d->nfix; ++f) {
-            if (d->shape[f].kind != KBO_SHAPE_CIRCLE) continue;       /* polygons: no continuous step (see header) */
-            const int m = d->fix_body[f];
-            toi_walls_body(cfg, d, d->r_obj[f], d->im_obj[m], w->x0[N + m], w->y0[N + m], w->a0[N + m], &w->px[N + m],
-                           &w->py[N + m], &w->ang[N + m], &w->vx[N + m], &w->vy[N + m], &w->bw[N + m]);
-        }
+        for (int m = 0; m < w->M; ++m) toi_walls_object(cfg, d, st, e, w, m);
     }
 }
 

@@ -304,3 +304,54 @@ def test_two_fixture_body_against_wall_and_box():
     assert sim.ox[0, 1] / W > 0.85 and sim.ox[0, 1] / W < 1.0 - 0.05 + 0.002
     assert (sim.ows_acc[0, :3, :, 0] >= 0).any()          # manifolds between fixtures / walls were active
     del m
+
+
+def _vertex_margin(sim, hw, hh):
+    """smallest wall distance (world units) over the vertices of box object 0"""
+    x, y, a = sim.ox[0, 0], sim.oy[0, 0], sim.otheta[0, 0]
+    v = np.array([[-hw, -hh], [hw, -hh], [hw, hh], [-hw, hh]]) * W
+    wx = x + np.cos(a) * v[:, 0] - np.sin(a) * v[:, 1]
+    wy = y + np.sin(a) * v[:, 0] + np.cos(a) * v[:, 1]
+    return min((1.0 * W - np.abs(wx)).min(), (0.75 * W - np.abs(wy)).min())
+
+
+@pytest.mark.parametrize('angle,spin', [(0.3, 3.0), (0.0, 0.0), (np.pi / 4, -5.0), (2.0, 0.5)])
+def test_continuous_step_stops_a_thrown_box_at_the_wall(angle, spin):
+    """b2World::SolveTOI for a polygon body: a box flying at 1.2 units per substep crosses the 0.015 penetration the
+    discrete solver tolerates, so a TOI event puts it back at the target separation (core polygon 0.005 from the wall
+    line, tolerance 0.00125); without the continuous step its corner ends up far beyond the wall."""
+    margins = {}
+    for toi in (0, 1):
+        sim = _sim(toi_walls=toi)
+        _park_bots(sim, where=(-0.5, 0.0))
+        sim.set_objects_m([[[0.8, 0.1]]], [[angle]])
+        sim.ovx[...] = 12.0
+        sim.ovy[...] = 1.0
+        sim.ow[...] = spin
+        worst = 1e9
+        for _ in range(8):
+            sim.step(1)
+            worst = min(worst, _vertex_margin(sim, 0.075, 0.075))
+        margins[toi] = worst
+        assert sim.status[0] == 0
+    assert margins[1] > 0.005 - 0.00125 - 1e-4
+    assert margins[0] < -0.05
+    # the TOI sub-solve removed the approach velocity (the remaining time is integrated with the solved velocity)
+    assert sim.ovx[0, 0] < 1.0
+
+
+def test_continuous_step_of_a_box_has_wall_friction():
+    """The TOI contacts are ordinary Box2D contacts: sliding along the wall during the sub-solve is braked by friction
+    sqrt(f_obj f_wall), so the tangential velocity after the impact is lower than free flight alone would leave it."""
+    out = {}
+    for mu in (0.0, 0.8):
+        sim = _sim(toi_walls=1, wall_friction=mu, obj_friction=0.5)
+        _park_bots(sim, where=(-0.5, 0.0))
+        sim.set_objects_m([[[0.8, 0.0]]], [[0.0]])
+        sim.ovx[...] = 12.0
+        sim.ovy[...] = 4.0
+        sim.step(5)
+        out[mu] = float(sim.ovy[0, 0])
+        assert sim.ovx[0, 0] < 0.5                            # it did hit the wall
+    assert np.isclose(out[0.0], 4.0 * KL ** 5, rtol=1e-4)
+    assert out[0.8] < out[0.0] - 0.5

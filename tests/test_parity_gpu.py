@@ -237,6 +237,58 @@ def test_continuous_step_against_walls(toi):
         assert deepest < 0.0165 - 0.0008                                     # discrete step alone tunnels ~1-2 mm
 
 
+def _deepest_vertex_margin(osim, verts_w):
+    """smallest wall distance (world units) of any vertex of single-fixture polygon objects with body-frame vertices verts_w"""
+    om = osim.objects_m()
+    c, s_ = np.cos(om[..., 2])[..., None], np.sin(om[..., 2])[..., None]
+    vx = om[..., 0:1] * 25.0 + c * verts_w[:, 0] - s_ * verts_w[:, 1]
+    vy = om[..., 1:2] * 25.0 + s_ * verts_w[:, 0] + c * verts_w[:, 1]
+    return min((25.0 - np.abs(vx)).min(), (18.75 - np.abs(vy)).min())
+
+
+@pytest.mark.parametrize('toi', [0, 1])
+def test_continuous_step_of_polygon_objects(toi):
+    """b2World::SolveTOI for polygon bodies: spinning boxes thrown at the walls and into the corners at 0.5 - 2 units per
+    substep.  The TOI sub-solve runs on the manifold constraints (friction, block solver); bit-exact against the oracle
+    in single-substep and fused launches, and with toi_walls=1 no vertex ends a substep beyond the TOI target."""
+    E, N, M = 6, 4, 4
+    xy = np.tile(np.array([[0.0, 0.0], [0.05, 0.0], [0.0, 0.05], [0.05, 0.05]])[None], (E, 1, 1))
+    shapes = [('box', 0.15, 0.15)] * M
+    rng = np.random.default_rng(41)
+    objs = np.tile(np.array([[0.6, 0.3], [-0.6, 0.35], [0.5, -0.4], [-0.55, -0.35]])[None], (E, 1, 1)) + rng.uniform(-0.05, 0.05, (E, M, 2))
+    oth = rng.uniform(-3.0, 3.0, (E, M))
+    sp = rng.uniform(5.0, 20.0, (E, M)).astype(np.float32)
+    dirs = rng.uniform(-0.6, 0.6, (E, M)) + np.array([0.0, np.pi, -0.7, np.pi + 0.7])[None]     # outwards, the last two into corners
+    v0, vy0 = (sp * np.cos(dirs)).astype(np.float32), (sp * np.sin(dirs)).astype(np.float32)
+    w0 = rng.uniform(-6.0, 6.0, (E, M)).astype(np.float32)
+    hw = 0.075 * 25.0
+    verts = np.array([[-hw, -hw], [hw, -hw], [hw, hw], [-hw, hw]])
+    pairs = []
+    for fused in (False, True):
+        osim, gsim = make_pair(E, N, xy=xy, th=np.zeros((E, N)), num_objects=M, toi_walls=toi, **_shape_kw(shapes))
+        osim.set_objects_m(objs, oth)
+        gsim.set_objects_m(objs, oth)
+        osim.ovx[...] = v0; osim.ovy[...] = vy0; osim.ow[...] = w0
+        gsim.ovx.copy_(dev(v0)); gsim.ovy.copy_(dev(vy0)); gsim.ow.copy_(dev(w0))
+        pairs.append((osim, gsim))
+    (o1, g1), (o2, g2) = pairs
+    deepest = 1e9
+    for k in range(30):
+        o1.step(1)
+        g1.step(1)
+        assert_same(o1, g1, 'object toi=%d substep %d' % (toi, k), OBJ_FIELDS)
+        deepest = min(deepest, _deepest_vertex_margin(o1, verts))
+    o2.step(30)
+    g2.step(30)
+    assert_same(o2, g2, 'object toi=%d fused' % toi, OBJ_FIELDS)
+    assert_same(o1, g2, 'object toi=%d fused == single' % toi, OBJ_FIELDS)
+    assert int(cpu(g1.status).max()) == 0
+    if toi:
+        assert deepest > 0.005 - 0.00125 - 1e-4          # TOI target - tolerance (core polygon to wall line)
+    else:
+        assert deepest < -0.1                            # the discrete step alone lets corners through the wall
+
+
 @pytest.mark.parametrize('mode', [O.DRIVE_SIMPLE_PHOTOTAXIS, O.DRIVE_PHOTOTAXIS])
 def test_light_driven_modes(mode):
     E, N = 8, 48
