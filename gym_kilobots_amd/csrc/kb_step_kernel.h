@@ -1569,7 +1569,8 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
             const int ncand = min((int)misc[M_NCON], capL_ / 2);
             for (int i = tid; i < ncand; i += nt) {
                 const int b = (int)lPair[i];
-                const float R = p.r_bot, im = p.im_bot;
+                float R = p.r_bot, im = p.im_bot;
+                asm volatile("" : "+v"(R), "+v"(im));   // per-lane copies: keeps the two constants out of the scalar file over the event loop
                 float x_ = pos[b].x, y_ = pos[b].y, a_ = cTh[i], vx_ = vel[b].x, vy_ = vel[b].y, w_ = cW[i];
                 kb_toi_walls_body(p, R, im, start[b].x, start[b].y, cTh0[i], x_, y_, a_, vx_, vy_, w_);
                 pos[b].x = x_; pos[b].y = y_; vel[b].x = vx_; vel[b].y = vy_; cTh[i] = a_; cW[i] = w_;
