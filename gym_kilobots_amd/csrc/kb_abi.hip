@@ -356,9 +356,9 @@ int kb_step(kb_sim *sim, const float *d_actions, const float *d_light_action, in
     case KB_DRIVE_VELOCITY: {
         // the flagship size has its own instantiation with a compile-time LDS layout
         const long cap1024 = 4L * 1024 + 64;
-        const bool fixed = p.N == 1024 && !obj && p.light_type == KB_LIGHT_NONE && sim->threads == 64 * MAX_WAVES &&
-                           p.NP == 1024 && p.NB == 1024 + KB_MAX_OBJECTS + 4 && p.capL == CAP_LDS && p.cap == (int)((cap1024 + 7) & ~7L) &&
-                           BPT * 64 * MAX_WAVES == 1024;
+        const bool fixed = p.N == 1024 && p.light_type == KB_LIGHT_NONE && sim->threads == 64 * MAX_WAVES &&
+                           p.NP == 1024 && p.NB == 1024 + KB_MAX_OBJECTS + 4 && (obj || p.capL == CAP_LDS) &&
+                           (obj || p.cap == (int)((cap1024 + 7) & ~7L)) && BPT * 64 * MAX_WAVES == 1024;
         fn = kb_pick_velocity(fixed ? KB_PICK_FIXED_1024 : p.light_type, obj);
     } break;
     case KB_DRIVE_ACCEL: fn = kb_pick_accel(p.light_type, obj); break;

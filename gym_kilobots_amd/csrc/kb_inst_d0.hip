@@ -3,7 +3,8 @@
 
 namespace kb {
 kb_step_fn kb_pick_velocity(int light_type, bool objects) {
-    if (light_type == KB_PICK_FIXED_1024) return kb_step_kernel<KB_DRIVE_VELOCITY, KB_LIGHT_NONE, false, 1024>;
+    if (light_type == KB_PICK_FIXED_1024)
+        return objects ? kb_step_kernel<KB_DRIVE_VELOCITY, KB_LIGHT_NONE, true, 1024> : kb_step_kernel<KB_DRIVE_VELOCITY, KB_LIGHT_NONE, false, 1024>;
     if (light_type == KB_LIGHT_CIRCULAR) return objects ? kb_step_kernel<KB_DRIVE_VELOCITY, KB_LIGHT_CIRCULAR, true> : kb_step_kernel<KB_DRIVE_VELOCITY, KB_LIGHT_CIRCULAR, false>;
     if (light_type == KB_LIGHT_NONE) return objects ? kb_step_kernel<KB_DRIVE_VELOCITY, KB_LIGHT_NONE, true> : kb_step_kernel<KB_DRIVE_VELOCITY, KB_LIGHT_NONE, false>;
     // GradientLight, MomentumLight, CompositeLight: one general kernel

@@ -6,8 +6,9 @@
 namespace kb {
 
 // One instantiation per (drive law, light model): keeps only that law's code (and registers) in the kernel.
-// FN > 0: specialisation for num_bots == FN without objects and the full workgroup (64 * KB_MAX_WAVES threads): every
-// LDS offset, array size and trip count is a compile-time constant instead of a value kept in scalar registers.
+// FN > 0: specialisation for num_bots == FN and the full workgroup (64 * KB_MAX_WAVES threads): every LDS offset, array
+// size and trip count is a compile-time constant instead of a value kept in scalar registers (with objects the size
+// of the contact staging area, and so the offsets behind it, stay run-time values: they depend on the fixture count).
 template <int DRIVE_MODE, int LIGHT_TYPE, bool OBJ, int FN = 0>
 __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_step_kernel(const Params p) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -22,7 +23,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
     const float h = p.h;
 
     const int NB = FN ? ((FN + 3) & ~3) + KB_MAX_OBJECTS + 4 : p.NB;
-    const int capL_ = FN ? (4 * FN + 64 < CAP_LDS ? 4 * FN + 64 : CAP_LDS) : p.capL;   // (FN >= 32: cap = 4 FN + 64, see kb_create)
+    const int capL_ = (FN && !OBJ) ? (4 * FN + 64 < CAP_LDS ? 4 * FN + 64 : CAP_LDS) : p.capL;   // (FN >= 32: cap = 4 FN + 64, see kb_create)
     // LDS arrays (offsets: namespace lds in kb_common.h)
     // positions, velocities and start-of-substep positions as (x, y) pairs: one 8-byte LDS access per body
     float2 *pos = (float2 *)(smem + lds::body32(NB, 0)), *vel = (float2 *)(smem + lds::body32(NB, 2));
@@ -201,7 +202,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
         {   // the thread index is re-read every substep: predicates derived from it are then evaluated where they are
             // used (one compare) instead of being hoisted out of the substep loop and kept in spilled scalar registers
             int t_ = threadIdx.x;
-            if (FN == 0) asm volatile("" : "+v"(t_));     // (the fixed-size instantiation has registers to spare)
+            if (FN == 0 || OBJ) asm volatile("" : "+v"(t_));     // (the fixed-size instantiation without objects has registers to spare)
             tid = t_; lane = t_ & 63; wave = t_ >> 6;
         }
         // ---- light.step: SinglePositionLight.step, light.py:59-75 (uniform per env) ----
