@@ -199,7 +199,11 @@ int kb_create(const kb_config *cfg, kb_sim **out) {
     p.cap = (int)cap;
     // with objects the LDS staging area gives up a few entries to the manifold-constraint records, so that two envs
     // of 1024 kilobots still share a CU
-    const int capLmax = cfg->num_objects > 0 ? CAP_LDS - 8 * mc_candidates(nfix) : CAP_LDS;
+    int capLmax = cfg->num_objects > 0 ? CAP_LDS - 8 * mc_candidates(nfix) : CAP_LDS;
+    // small swarms: stage what a packed cluster can produce (a hexagonal packing has < 3 contacts per kilobot, + walls) rather than all pairs, so
+    // that more one-wave envs fit a CU; a spawn that overlaps more than that takes the global staging slice
+    const int typical = 3 * p.N + 64 > 256 ? 3 * p.N + 64 : 256;
+    if (capLmax > typical) capLmax = typical;
     p.capL = p.cap < capLmax ? p.cap : capLmax;
     p.NP = (p.N + 3) & ~3;
     p.NB = p.NP + KB_MAX_OBJECTS + 4;
@@ -279,14 +283,30 @@ int kb_create(const kb_config *cfg, kb_sim **out) {
     p.ka_obj = 1.0f / (1.0f + p.h * cfg->obj_angular_damping);
     p.solver_mode = cfg->solver_mode;
     p.toi_walls = cfg->toi_walls;
+    {   // trade a few staging entries for one more env per CU when the LDS footprint is just above a divisor of 160 KiB
+        const int LDS_CU = 160 * 1024;
+        const int fit = LDS_CU / lds::total(p.NB, p.capL, p.NP, p.ncell, p.nmc);
+        const int lo = 5 * p.N / 2 + 64 > 256 ? 5 * p.N / 2 + 64 : 256;
+        int c = p.capL;
+        while (c - 8 >= lo && lds::total(p.NB, c, p.NP, p.ncell, p.nmc) > LDS_CU / (fit + 1)) c -= 8;
+        if (fit >= 1 && lds::total(p.NB, c, p.NP, p.ncell, p.nmc) <= LDS_CU / (fit + 1)) p.capL = c;
+    }
     p.lds_total = lds::total(p.NB, p.capL, p.NP, p.ncell, p.nmc);
     if (p.lds_total > 160 * 1024) {
         delete s;
         return fail(KB_ELDS, "kb_create: configuration needs more than 160 KiB of LDS per env");
     }
-    s->threads = ((p.N + BPT - 1) / BPT + 63) & ~63;   // N <= BPT * threads
-    if (s->threads < 64) s->threads = 64;
-    if (s->threads > 64 * MAX_WAVES) { delete s; return fail(KB_EINVAL, "kb_create: num_bots exceeds bots-per-thread x workgroup size of this build"); }
+    if (p.N > BPT * 64 * MAX_WAVES) { delete s; return fail(KB_EINVAL, "kb_create: num_bots exceeds bots-per-thread x workgroup size of this build"); }
+    {   // Workgroup size (measured on MI355X, 64 ... 1024 kilobots): one kilobot per thread and a power-of-two wave count
+        // (3 / 5 / 6 / 7-wave workgroups spread unevenly over the four SIMDs and lose a resident env), unless that costs
+        // a resident env (LDS fit vs 16 waves per CU) while many lanes would idle.  kb_set_block_threads overrides.
+        int T = 64;
+        while (T < p.N && T < 64 * MAX_WAVES) T <<= 1;
+        const int fit = 160 * 1024 / p.lds_total;
+        const int resident = fit < 16 / (T / 64) ? fit : 16 / (T / 64);
+        if (T > 64 && resident < fit && p.N * 100 < T * 85) T >>= 1;
+        s->threads = T;
+    }
     *out = s;
     return KB_OK;
 }
