@@ -144,7 +144,8 @@ typedef struct kb_buffers {
     int32_t *status;                    /* required: [num_envs]; bit0 contact capacity overflow,
                                            bit1 warm-start slot overflow, bit2 a device staging limit was hit (more than 64 kilobots
                                            on one fixture, 255 kilobot-object contacts in one env, or 63 partners in one cell pair),
-                                           bit3 more than 512 bodies near the walls in one substep (TOI skipped for the rest) */
+                                           bit3 more kilobots near the walls in one substep than half the LDS contact staging holds
+                                           (512 at 1024 kilobots; the continuous step is skipped for the rest) */
     void *scratch;                      /* required: kb_scratch_bytes() bytes; contact staging of envs whose
                                            contacts do not fit the LDS staging area (contents are transient) */
     float *ows_acc;                     /* objects: [num_envs][8][KB_OWS_COLS][KB_OWS_WORDS] manifold impulses of the
