@@ -76,6 +76,7 @@ class KilobotsEnv(object):
         self._kilobots = []
         self._objects = []
         self._light = None
+        self._state_cache = None     # (world.version, state dict) of the last device read
         self._screen = None
         self.render_mode = 'human'
         self.video_path = None
@@ -141,10 +142,20 @@ class KilobotsEnv(object):
             return {'kilobots': np.array([k.get_state() for k in self._kilobots]),
                     'objects': np.array([o.get_state() for o in self._objects]),
                     'light': self._light.get_state() if self._light else None}
+        # env.step asks for the state three times (kilobots_env.py:166,201,204): the device is read once per change.
+        # (Writes through the body / light views and the env's own launches bump world.version; code that writes the
+        # sim's tensors directly calls env.world.touch().)
+        if self._state_cache is not None and self._state_cache[0] == self.world.version:
+            return {k: (None if v is None else v.copy()) for k, v in self._state_cache[1].items()}
+        state = self._read_state()
+        self._state_cache = (self.world.version, state)
+        return {k: (None if v is None else v.copy()) for k, v in state.items()}
+
+    def _read_state(self):
         poses = self._sim.poses()            # one kernel + one copy instead of 3N SWIG reads
-        kb = poses[0].double().cpu().numpy() if self.num_envs == 1 else poses.double().cpu().numpy()
+        kb = (poses[0] if self.num_envs == 1 else poses).cpu().numpy().astype(np.float64)
         if self._sim.drive_mode == nat.DRIVE_ACCEL:
-            vw = torch.stack([self._sim.v, self._sim.w], -1).double().cpu().numpy()
+            vw = torch.stack([self._sim.v, self._sim.w], -1).cpu().numpy().astype(np.float64)
             kb = np.concatenate([kb, vw[0] if self.num_envs == 1 else vw], -1)
         light = None
         if self._light is not None:
@@ -156,9 +167,9 @@ class KilobotsEnv(object):
                 parts = [self._sim.light_x, self._sim.light_y]
                 l = torch.stack([p_.reshape(self.num_envs, -1) for p_ in parts], -1).double().cpu().numpy()
                 light = l.reshape(self.num_envs, -1)
-        objs = np.array([o.get_state() for o in self._objects])
+        objs = np.array([])
         if self._objects:
-            op = self._sim.object_poses().double().cpu().numpy()
+            op = self._sim.object_poses().cpu().numpy().astype(np.float64)
             objs = op[0] if self.num_envs == 1 else op
         return {'kilobots': kb, 'objects': objs, 'light': light}
 
@@ -321,6 +332,7 @@ class KilobotsEnv(object):
                     dst.copy_(val.reshape(dst.shape).to(dst.device))
             lt._world = self.world
         self.world.backend = sim
+        self.world.touch()
         self.world.env_index = 0
 
     def reset(self):
@@ -352,6 +364,7 @@ class KilobotsEnv(object):
             la = self._light_action_tensor(action)
         # the whole `for i in range(steps_per_action)` loop (kilobots_env.py:168-190) is one launch
         self._sim.step(self.__steps_per_action, light_action=la)
+        self.world.touch()
         self.__sim_steps += self.__steps_per_action
         next_state = self.get_state()
         observation = self.get_observation()
@@ -362,6 +375,7 @@ class KilobotsEnv(object):
 
     def _step_world(self):
         self._sim.step(1, flags=nat.STEP_NO_DRIVE)
+        self.world.touch()
 
     def render(self, mode=None):
         raise NotImplementedError('rendering (pygame viewer) is outside the accelerated hot path; '

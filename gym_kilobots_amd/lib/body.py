@@ -16,6 +16,10 @@ class World:
         self.objects = []
         self.backend = None
         self.env_index = 0
+        self.version = 0        # bumped by every write to the device state that goes through the body / light views
+
+    def touch(self):
+        self.version += 1
 
     def _register(self, body):
         from .kilobot import Kilobot
@@ -68,6 +72,7 @@ class Body:
 
     def _set(self, name, value):
         getattr(self._world.backend, name)[self._world.env_index, self._index] = float(value)
+        self._world.touch()
 
     @property
     def width(self):

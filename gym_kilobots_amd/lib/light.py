@@ -66,6 +66,7 @@ class SinglePositionLight(Light):
             t[e] = float(value)
         else:
             t[e, self._slot or 0] = float(value)
+        self._world.touch()
 
     def get_position(self):
         if self._live():
@@ -152,6 +153,7 @@ class GradientLight(Light):
         self._gradient_angle = np.array([float(angle)])
         if self._live():
             self._world.backend.light_x[self._world.env_index] = float(angle)
+            self._world.touch()
 
     @property
     def _gradient_vec(self):

@@ -397,3 +397,32 @@ def test_debug_view_f4(tmp_path):
     out = kb_plotting.save_env_png(be, str(tmp_path / 'env.png'), env_index=1, light_radii=[0.3], title='env 1')
     import os
     assert os.path.getsize(out) > 2000
+
+
+def test_state_is_read_once_per_change_and_never_stale():
+    """env.step asks for the state three times; the device is read once per change.  Writes through the body / light
+    views, steps and resets invalidate the cached read; callers get copies."""
+    env = PhotoEnv(sim_factory=OracleBackend)
+    env.reset()
+    reads = []
+    real = env._read_state
+    env._read_state = lambda: (reads.append(1), real())[1]
+    s0 = env.get_state()
+    s0b = env.get_state()
+    assert len(reads) <= 1 and np.array_equal(s0['kilobots'], s0b['kilobots'])
+    s0['kilobots'][0, 0] = 123.0                                 # a copy: the next caller is not affected
+    assert env.get_state()['kilobots'][0, 0] != 123.0
+    n = len(reads)
+    obs, *_ = env.step(np.array([0.01, 0.0]))
+    assert len(reads) == n + 1                                   # one read for state, next_state and observation
+    assert not np.array_equal(obs['kilobots'], s0b['kilobots']) and not np.array_equal(obs['light'], s0b['light'])
+    env.kilobots[1].set_pose((0.2, 0.1, 0.5))                    # body view write
+    np.testing.assert_allclose(env.get_state()['kilobots'][1], (0.2, 0.1, 0.5), atol=1e-6)
+    env._light.set_position(np.array([-0.3, 0.2]))               # light view write
+    np.testing.assert_allclose(env.get_state()['light'], (-0.3, 0.2), atol=1e-6)
+    env.sim.x[0, 0] = 5.0                                        # direct tensor write: the caller says so
+    env.world.touch()
+    assert abs(env.get_state()['kilobots'][0, 0] - 0.2) < 1e-6
+    first = env.reset()
+    assert np.array_equal(first['kilobots'], env.get_state()['kilobots'])
+    assert abs(first['kilobots'][0, 0] - 0.0) < 1e-6
