@@ -78,6 +78,12 @@ struct kb_sim {
     int threads;
 };
 
+// dynamic LDS of one env: the bucket tables scale with the waves of the workgroup, the object tables exist only in
+// scenes with objects (namespace lds, kb_common.h)
+static int lds_bytes_for(const kb::Params &p, int threads, int capL) {
+    return kb::lds::total(kb::lds::fixed(p.M > 0, threads / 64), p.NB, capL, p.NP, p.ncell, p.nmc);
+}
+
 extern "C" {
 
 const char *kb_last_error(void) { return g_err; }
@@ -283,29 +289,29 @@ int kb_create(const kb_config *cfg, kb_sim **out) {
     p.ka_obj = 1.0f / (1.0f + p.h * cfg->obj_angular_damping);
     p.solver_mode = cfg->solver_mode;
     p.toi_walls = cfg->toi_walls;
-    {   // trade a few staging entries for one more env per CU when the LDS footprint is just above a divisor of 160 KiB
-        const int LDS_CU = 160 * 1024;
-        const int fit = LDS_CU / lds::total(p.NB, p.capL, p.NP, p.ncell, p.nmc);
-        const int lo = 5 * p.N / 2 + 64 > 256 ? 5 * p.N / 2 + 64 : 256;
-        int c = p.capL;
-        while (c - 8 >= lo && lds::total(p.NB, c, p.NP, p.ncell, p.nmc) > LDS_CU / (fit + 1)) c -= 8;
-        if (fit >= 1 && lds::total(p.NB, c, p.NP, p.ncell, p.nmc) <= LDS_CU / (fit + 1)) p.capL = c;
-    }
-    p.lds_total = lds::total(p.NB, p.capL, p.NP, p.ncell, p.nmc);
-    if (p.lds_total > 160 * 1024) {
-        delete s;
-        return fail(KB_ELDS, "kb_create: configuration needs more than 160 KiB of LDS per env");
-    }
     if (p.N > BPT * 64 * MAX_WAVES) { delete s; return fail(KB_EINVAL, "kb_create: num_bots exceeds bots-per-thread x workgroup size of this build"); }
+    const int LDS_CU = 160 * 1024;
     {   // Workgroup size (measured on MI355X, 64 ... 1024 kilobots): one kilobot per thread and a power-of-two wave count
         // (3 / 5 / 6 / 7-wave workgroups spread unevenly over the four SIMDs and lose a resident env), unless that costs
         // a resident env (LDS fit vs 16 waves per CU) while many lanes would idle.  kb_set_block_threads overrides.
         int T = 64;
         while (T < p.N && T < 64 * MAX_WAVES) T <<= 1;
-        const int fit = 160 * 1024 / p.lds_total;
+        const int fit = LDS_CU / lds_bytes_for(p, T, p.capL);
         const int resident = fit < 16 / (T / 64) ? fit : 16 / (T / 64);
         if (T > 64 && resident < fit && p.N * 100 < T * 85) T >>= 1;
         s->threads = T;
+    }
+    {   // trade a few staging entries for one more env per CU when the LDS footprint is just above a divisor of 160 KiB
+        const int fit = LDS_CU / lds_bytes_for(p, s->threads, p.capL);
+        const int lo = 5 * p.N / 2 + 64 > 256 ? 5 * p.N / 2 + 64 : 256;
+        int c = p.capL;
+        while (c - 8 >= lo && lds_bytes_for(p, s->threads, c) > LDS_CU / (fit + 1)) c -= 8;
+        if (fit >= 1 && lds_bytes_for(p, s->threads, c) <= LDS_CU / (fit + 1)) p.capL = c;
+    }
+    p.lds_total = lds_bytes_for(p, s->threads, p.capL);
+    if (p.lds_total > LDS_CU) {
+        delete s;
+        return fail(KB_ELDS, "kb_create: configuration needs more than 160 KiB of LDS per env");
     }
     *out = s;
     return KB_OK;
@@ -389,8 +395,10 @@ int kb_step(kb_sim *sim, const float *d_actions, const float *d_light_action, in
     }
     if (!fn) return fail(KB_EINVAL, "kb_step: no kernel for this drive mode / light type");
     if (p.lds_total > 64 * 1024 && sim->attr_fn != reinterpret_cast<const void *>(fn)) {
+        // the attribute belongs to the kernel, not to this sim: raise it to the hardware limit, so that sims of
+        // different sizes sharing one instantiation never lower it under each other
         hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, p.lds_total);
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e2 != hipSuccess) return fail(KB_EHIP, "kb_step: hipFuncSetAttribute: %s", hipGetErrorString(e2));
         sim->attr_fn = reinterpret_cast<const void *>(fn);
     }
@@ -421,7 +429,10 @@ int kb_block_threads(const kb_sim *sim) { return sim ? sim->threads : KB_EINVAL;
 int kb_set_block_threads(kb_sim *sim, int threads) {
     if (!sim || threads < 64 || threads > 64 * MAX_WAVES || (threads & 63)) return fail(KB_EINVAL, "kb_set_block_threads: multiple of 64 up to the build maximum");
     if (sim->p.N > BPT * threads) return fail(KB_EINVAL, "kb_set_block_threads: need num_bots <= bots-per-thread x threads");
+    const int need = lds_bytes_for(sim->p, threads, sim->p.capL);
+    if (need > 160 * 1024) return fail(KB_ELDS, "kb_set_block_threads: more than 160 KiB of LDS per env at this workgroup size");
     sim->threads = threads;
+    sim->p.lds_total = need;
     return KB_OK;
 }
 

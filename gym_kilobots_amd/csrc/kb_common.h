@@ -67,44 +67,51 @@ enum { M_NCON = 0, M_TOTAL = 1, M_ANY = 2, M_STATUS = 3, M_MAXISL = 4, M_PROF = 
 static_assert(M_COUNT <= 64, "misc area");
 
 // ---- LDS layout ----------------------------------------------------------------------------------
-// Fixed-size arrays sit at compile-time offsets; the arrays that scale with the scene are grouped by stride so
-// that every offset is (constant + k * stride) of four scene sizes.  The kernel recomputes offsets where they
-// are used instead of keeping ~35 of them alive in scalar registers for the whole launch.
+// The small arrays come first: a few of fixed size, the bucket tables of the contact sort (they scale with the waves of
+// the workgroup) and -- only in kernels with objects -- the object tables; `fixed(obj, nw)` is where the arrays that
+// scale with the scene start.  Those are grouped by stride, so that every offset is (base + k * stride) of four scene
+// sizes.  The kernel recomputes offsets where they are used instead of keeping ~35 of them alive in scalar registers
+// for the whole launch; in the fixed-size instantiations all of this folds to constants.
 namespace lds {
 constexpr int A16(int x) { return (x + 15) & ~15; }
 constexpr int MISC = 0;
 constexpr int WSUM = MISC + A16(4 * 64);
-constexpr int BKSTART = WSUM + A16(4 * 16);
-constexpr int BKFILL = BKSTART + A16(4 * (MAX_BUCKETS + 1));
-constexpr int BKMAXRANK = BKFILL + A16(4 * MAX_BUCKETS);
-constexpr int BKLIST = BKMAXRANK + A16(4 * MAX_WAVES * NUM_CLS);
-constexpr int NLIST = BKLIST + A16(2 * MAX_BUCKETS);
-constexpr int OBJTAB = NLIST + 16;                                    // object table: mass, shape
-constexpr int OBJBODY = OBJTAB + A16(4 * OT_WORDS_C * KB_MAX_OBJECTS);  // body table
+constexpr int NLIST = WSUM + A16(4 * 16);
+constexpr int BKMAXRANK = NLIST + 16;
+constexpr int BKSTART = BKMAXRANK + A16(4 * MAX_WAVES * NUM_CLS);
+// buckets of a workgroup of nw waves (the tables double as scratch of the island placement: >= 64 entries)
+__host__ __device__ constexpr int nbk(int nw) { return nw * BK_PER_WAVE < 64 ? 64 : nw * BK_PER_WAVE; }
+__host__ __device__ constexpr int bkfill(int nw) { return BKSTART + A16(4 * (nbk(nw) + 1)); }
+__host__ __device__ constexpr int bklist(int nw) { return bkfill(nw) + A16(4 * nbk(nw)); }
+__host__ __device__ constexpr int objtab(int nw) { return bklist(nw) + A16(2 * nbk(nw)); }   // object table: mass, shape
+// object areas, relative to objtab(nw)
+constexpr int OBJBODY = A16(4 * OT_WORDS_C * KB_MAX_OBJECTS);            // body table
 constexpr int OBJCNT = OBJBODY + A16(4 * BT_WORDS_C * KB_MAX_OBJECTS);
 constexpr int OBJLIST = OBJCNT + A16(4 * KB_MAX_OBJECTS);
-constexpr int OBJW = OBJLIST + A16(2 * KB_MAX_OBJECTS * OBJ_LIST);          // angular velocity, angle, angle at the start of the substep
+constexpr int OBJW = OBJLIST + A16(2 * KB_MAX_OBJECTS * OBJ_LIST);       // angular velocity, angle, angle at the start of the substep
 constexpr int OBJA = OBJW + A16(4 * KB_MAX_OBJECTS);
 constexpr int OBJA0 = OBJA + A16(4 * KB_MAX_OBJECTS);
-constexpr int MCMASK = OBJA0 + A16(4 * KB_MAX_OBJECTS);                // per wave: which manifold constraints it owns (u64)
-constexpr int FIXED = MCMASK + A16(8 * (MAX_WAVES + 1));
+constexpr int MCMASK = OBJA0 + A16(4 * KB_MAX_OBJECTS);                  // per wave: which manifold constraints it owns (u64)
+constexpr int OBJ_AREA = MCMASK + A16(8 * (MAX_WAVES + 1));
+__host__ __device__ constexpr int fixed(bool obj, int nw) { return objtab(nw) + (obj ? OBJ_AREA : 0); }
 // per-body 32-bit arrays (stride 4 * NB): px py vx vy x0 y0 dirCnt parent
 constexpr int BODY32_COUNT = 8;
 // per-contact 32-bit arrays (stride 4 * capL): sPair sInfo sAcc oldAcc;  16-bit (stride 2 * capL): cbk order oldKey
 constexpr int CON32_COUNT = 4, CON16_COUNT = 3;
 // per-bot 16-bit arrays (stride 2 * NP): wsOff newOff next cellOf;  8-bit (stride NP): wsCnt wsCntNew
 constexpr int BOT16_COUNT = 4, BOT8_COUNT = 2;
-__host__ __device__ inline int body32(int NB, int k) { return FIXED + 4 * NB * k; }
-__host__ __device__ inline int con32(int NB, int capL, int k) { return body32(NB, BODY32_COUNT) + 4 * capL * k; }
-__host__ __device__ inline int con16(int NB, int capL, int k) { return con32(NB, capL, CON32_COUNT) + 2 * capL * k; }
-__host__ __device__ inline int bot16(int NB, int capL, int NP, int k) { return con16(NB, capL, CON16_COUNT) + 2 * NP * k; }
-__host__ __device__ inline int bot8(int NB, int capL, int NP, int k) { return bot16(NB, capL, NP, BOT16_COUNT) + NP * k; }
-__host__ __device__ inline int active(int NB, int capL, int NP) { return bot8(NB, capL, NP, BOT8_COUNT); }
-__host__ __device__ inline int islwave(int NB, int capL, int NP) { return active(NB, capL, NP) + 2 * NB; }   // u8 per body: wave that sweeps its island
-__host__ __device__ inline int head(int NB, int capL, int NP) { return (islwave(NB, capL, NP) + NB + 15) & ~15; }
-__host__ __device__ inline int mcarea(int NB, int capL, int NP, int ncell) { return (head(NB, capL, NP) + 2 * ncell + 4 + 15) & ~15; }
+// (fx = fixed(obj, nw))
+__host__ __device__ inline int body32(int fx, int NB, int k) { return fx + 4 * NB * k; }
+__host__ __device__ inline int con32(int fx, int NB, int capL, int k) { return body32(fx, NB, BODY32_COUNT) + 4 * capL * k; }
+__host__ __device__ inline int con16(int fx, int NB, int capL, int k) { return con32(fx, NB, capL, CON32_COUNT) + 2 * capL * k; }
+__host__ __device__ inline int bot16(int fx, int NB, int capL, int NP, int k) { return con16(fx, NB, capL, CON16_COUNT) + 2 * NP * k; }
+__host__ __device__ inline int bot8(int fx, int NB, int capL, int NP, int k) { return bot16(fx, NB, capL, NP, BOT16_COUNT) + NP * k; }
+__host__ __device__ inline int active(int fx, int NB, int capL, int NP) { return bot8(fx, NB, capL, NP, BOT8_COUNT); }
+__host__ __device__ inline int islwave(int fx, int NB, int capL, int NP) { return active(fx, NB, capL, NP) + 2 * NB; }   // u8 per body: wave that sweeps its island
+__host__ __device__ inline int head(int fx, int NB, int capL, int NP) { return (islwave(fx, NB, capL, NP) + NB + 15) & ~15; }
+__host__ __device__ inline int mcarea(int fx, int NB, int capL, int NP, int ncell) { return (head(fx, NB, capL, NP) + 2 * ncell + 4 + 15) & ~15; }
 // manifold-constraint records (objects only): MC_FIELDS words x nmc candidates, field-major
-__host__ __device__ inline int total(int NB, int capL, int NP, int ncell, int nmc) { return (mcarea(NB, capL, NP, ncell) + 4 * MC_FIELDS_C * nmc + 15) & ~15; }
+__host__ __device__ inline int total(int fx, int NB, int capL, int NP, int ncell, int nmc) { return (mcarea(fx, NB, capL, NP, ncell) + 4 * MC_FIELDS_C * nmc + 15) & ~15; }
 }  // namespace lds
 
 struct Params {

@@ -25,32 +25,33 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
     const int NB = FN ? ((FN + 3) & ~3) + KB_MAX_OBJECTS + 4 : p.NB;
     const int capL_ = (FN && !OBJ) ? (4 * FN + 64 < CAP_LDS ? 4 * FN + 64 : CAP_LDS) : p.capL;   // (FN >= 32: cap = 4 FN + 64, see kb_create)
     // LDS arrays (offsets: namespace lds in kb_common.h)
+    const int fx = lds::fixed(OBJ, nw), ot_ = lds::objtab(nw);
     // positions, velocities and start-of-substep positions as (x, y) pairs: one 8-byte LDS access per body
-    float2 *pos = (float2 *)(smem + lds::body32(NB, 0)), *vel = (float2 *)(smem + lds::body32(NB, 2));
-    float2 *start = (float2 *)(smem + lds::body32(NB, 4));
-    unsigned *dirCnt = (unsigned *)(smem + lds::body32(NB, 6)), *parent = (unsigned *)(smem + lds::body32(NB, 7));
+    float2 *pos = (float2 *)(smem + lds::body32(fx, NB, 0)), *vel = (float2 *)(smem + lds::body32(fx, NB, 2));
+    float2 *start = (float2 *)(smem + lds::body32(fx, NB, 4));
+    unsigned *dirCnt = (unsigned *)(smem + lds::body32(fx, NB, 6)), *parent = (unsigned *)(smem + lds::body32(fx, NB, 7));
     unsigned *islCnt = dirCnt;  // alias: dirCnt is dead once the contacts are emitted
-    unsigned *lPair = (unsigned *)(smem + lds::con32(NB, capL_, 0)), *lInfo = (unsigned *)(smem + lds::con32(NB, capL_, 1));
-    float *lAcc = (float *)(smem + lds::con32(NB, capL_, 2)), *oldAcc = (float *)(smem + lds::con32(NB, capL_, 3));
-    unsigned short *lCbk = (unsigned short *)(smem + lds::con16(NB, capL_, 0)), *lOrder = (unsigned short *)(smem + lds::con16(NB, capL_, 1));
-    unsigned short *oldKey = (unsigned short *)(smem + lds::con16(NB, capL_, 2));
-    unsigned short *wsOff = (unsigned short *)(smem + lds::bot16(NB, capL_, NP, 0)), *newOff = (unsigned short *)(smem + lds::bot16(NB, capL_, NP, 1));
-    unsigned short *nextb = (unsigned short *)(smem + lds::bot16(NB, capL_, NP, 2)), *cellOf = (unsigned short *)(smem + lds::bot16(NB, capL_, NP, 3));
-    unsigned char *wsCnt = smem + lds::bot8(NB, capL_, NP, 0), *wsCntNew = smem + lds::bot8(NB, capL_, NP, 1);
-    unsigned char *active = smem + lds::active(NB, capL_, NP);
-    unsigned char *islWave = smem + lds::islwave(NB, capL_, NP);   // wave that sweeps the island rooted at body b
-    unsigned short *head = (unsigned short *)(smem + lds::head(NB, capL_, NP));   // per-cell list heads (EMPTY16 = empty)
+    unsigned *lPair = (unsigned *)(smem + lds::con32(fx, NB, capL_, 0)), *lInfo = (unsigned *)(smem + lds::con32(fx, NB, capL_, 1));
+    float *lAcc = (float *)(smem + lds::con32(fx, NB, capL_, 2)), *oldAcc = (float *)(smem + lds::con32(fx, NB, capL_, 3));
+    unsigned short *lCbk = (unsigned short *)(smem + lds::con16(fx, NB, capL_, 0)), *lOrder = (unsigned short *)(smem + lds::con16(fx, NB, capL_, 1));
+    unsigned short *oldKey = (unsigned short *)(smem + lds::con16(fx, NB, capL_, 2));
+    unsigned short *wsOff = (unsigned short *)(smem + lds::bot16(fx, NB, capL_, NP, 0)), *newOff = (unsigned short *)(smem + lds::bot16(fx, NB, capL_, NP, 1));
+    unsigned short *nextb = (unsigned short *)(smem + lds::bot16(fx, NB, capL_, NP, 2)), *cellOf = (unsigned short *)(smem + lds::bot16(fx, NB, capL_, NP, 3));
+    unsigned char *wsCnt = smem + lds::bot8(fx, NB, capL_, NP, 0), *wsCntNew = smem + lds::bot8(fx, NB, capL_, NP, 1);
+    unsigned char *active = smem + lds::active(fx, NB, capL_, NP);
+    unsigned char *islWave = smem + lds::islwave(fx, NB, capL_, NP);   // wave that sweeps the island rooted at body b
+    unsigned short *head = (unsigned short *)(smem + lds::head(fx, NB, capL_, NP));   // per-cell list heads (EMPTY16 = empty)
     unsigned *misc = (unsigned *)(smem + lds::MISC), *wsum = (unsigned *)(smem + lds::WSUM);
-    unsigned *bkStart = (unsigned *)(smem + lds::BKSTART), *bkFill = (unsigned *)(smem + lds::BKFILL);
+    unsigned *bkStart = (unsigned *)(smem + lds::BKSTART), *bkFill = (unsigned *)(smem + lds::bkfill(nw));
     unsigned *bkMaxRank = (unsigned *)(smem + lds::BKMAXRANK);
-    unsigned short *bkList = (unsigned short *)(smem + lds::BKLIST);
+    unsigned short *bkList = (unsigned short *)(smem + lds::bklist(nw));
     unsigned char *nList = smem + lds::NLIST;
-    float *objTab = (float *)(smem + lds::OBJTAB);                       // fixture table (kb_objects.h: OT_*)
-    float *objBody = (float *)(smem + lds::OBJBODY);                     // body table (kb_objects.h: BT_*)
-    unsigned *objCnt = (unsigned *)(smem + lds::OBJCNT);                 // kilobots touching object m
-    unsigned short *objList = (unsigned short *)(smem + lds::OBJLIST);   // ... and who they are
-    float *objW = (float *)(smem + lds::OBJW), *objA = (float *)(smem + lds::OBJA), *objA0 = (float *)(smem + lds::OBJA0);
-    unsigned long long *mcMask = (unsigned long long *)(smem + lds::MCMASK);   // manifold constraints owned by wave w
+    float *objTab = (float *)(smem + ot_);                       // fixture table (kb_objects.h: OT_*)
+    float *objBody = (float *)(smem + ot_ + lds::OBJBODY);                     // body table (kb_objects.h: BT_*)
+    unsigned *objCnt = (unsigned *)(smem + ot_ + lds::OBJCNT);                 // kilobots touching object m
+    unsigned short *objList = (unsigned short *)(smem + ot_ + lds::OBJLIST);   // ... and who they are
+    float *objW = (float *)(smem + ot_ + lds::OBJW), *objA = (float *)(smem + ot_ + lds::OBJA), *objA0 = (float *)(smem + ot_ + lds::OBJA0);
+    unsigned long long *mcMask = (unsigned long long *)(smem + ot_ + lds::MCMASK);   // manifold constraints owned by wave w
     const int M = OBJ ? p.M : 0;   // OBJ = false: every object loop below folds away
     // inverse mass / radius of a body id: kilobot < N, object N + m, wall >= WALL_CODE (static, edge skin radius)
     auto bim = [&](int id) __attribute__((always_inline)) -> float {
@@ -65,7 +66,7 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
     };
     ObjCtx ox;
     ox.pos = pos; ox.vel = vel; ox.objW = objW; ox.objA = objA; ox.objTab = objTab; ox.objBody = objBody;
-    ox.mc = (float *)(smem + lds::mcarea(NB, capL_, NP, p.ncell));
+    ox.mc = (float *)(smem + lds::mcarea(fx, NB, capL_, NP, p.ncell));
     ox.N = N; ox.MCN = p.nmc; ox.mu_oo = p.mu_oo; ox.mu_ow = p.mu_ow;
     const int NMC = OBJ ? p.nmc : 0;      // manifold-constraint candidates (fixture pairs, fixture-wall)
     const int F = OBJ ? p.F : 0;          // fixtures of the objects (>= M)
