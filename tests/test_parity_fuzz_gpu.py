@@ -58,6 +58,16 @@ def test_random_scene(seed):
     if mode in (O.DRIVE_SIMPLE_PHOTOTAXIS, O.DRIVE_PHOTOTAXIS) or rng.random() < 0.3:
         light = int(rng.choice([O.LIGHT_CIRCULAR, O.LIGHT_GRADIENT, O.LIGHT_MOMENTUM]))
     kw = dict(solver_mode=int(rng.choice([0, 0, 0, 1, 2, 3, 4])), toi_walls=int(rng.random() < 0.8))
+    # arena size (grid dimensions, LDS footprint, workgroups per CU) and iteration counts: from their own stream, so that
+    # the scenes of the seeds keep their layout
+    rng2 = np.random.default_rng(777000 + seed)
+    W, H = 2.0, 1.5
+    if rng2.random() < 0.5:
+        W, H = [(1.0, 0.8), (1.2, 0.9), (3.0, 2.0), (0.6, 0.6), (2.0, 0.5)][int(rng2.integers(0, 5))]
+        kw.update(world_width=W, world_height=H)
+    if rng2.random() < 0.3:
+        kw.update(vel_iters=int(rng2.choice([6, 3, 1])), pos_iters=int(rng2.choice([4, 2, 1, 0])))
+    sx, sy = W / 2.0, H / 1.5
     with_objects = rng.random() < 0.6
     nobj = 0
     if with_objects:
@@ -66,11 +76,12 @@ def test_random_scene(seed):
     sigma = float(rng.choice([0.03, 0.08, 0.2, 0.5]))
     if os.environ.get('KB_FUZZ_BIG'):
         sigma = float(rng.choice([0.12, 0.2, 0.3, 0.5]))
-    xy = np.clip(rng.normal(scale=sigma, size=(E, N, 2)) + rng.uniform(-0.5, 0.5, (E, 1, 2)), [-0.97, -0.72], [0.97, 0.72])
+    xy = np.clip(rng.normal(scale=sigma, size=(E, N, 2)) + rng.uniform(-0.5, 0.5, (E, 1, 2)) * [sx, sy],
+                 [-W / 2 + 0.03, -H / 2 + 0.03], [W / 2 - 0.03, H / 2 - 0.03])
     th = rng.uniform(-np.pi, np.pi, (E, N))
     osim, gsim = make_pair(E, N, mode, light, xy=xy, th=th, **kw)
     if nobj:
-        objs = rng.uniform([-0.8, -0.55], [0.8, 0.55], (E, nobj, 2))
+        objs = rng.uniform([-0.8, -0.55], [0.8, 0.55], (E, nobj, 2)) * [sx, sy]
         oth = rng.uniform(-np.pi, np.pi, (E, nobj))
         osim.set_objects_m(objs, oth)
         gsim.set_objects_m(objs, oth)
@@ -78,7 +89,7 @@ def test_random_scene(seed):
         osim.ovx[...] = v0
         gsim.ovx.copy_(dev(v0))
     if light != O.LIGHT_NONE:
-        lx = rng.uniform(-0.5, 0.5, osim.light_x.shape).astype(np.float32)
+        lx = (rng.uniform(-0.5, 0.5, osim.light_x.shape) * min(sx, sy)).astype(np.float32)
         osim.light_x[...] = lx
         gsim.light_x.copy_(dev(lx))
     fields = ('x', 'y', 'theta') + (OBJ_FIELDS[3:] if nobj else ())
