@@ -80,8 +80,13 @@ struct kb_sim {
 
 // dynamic LDS of one env: the bucket tables scale with the waves of the workgroup, the object tables exist only in
 // scenes with objects (namespace lds, kb_common.h)
+static bool uses_fixed_1024(const kb::Params &p, int threads) {   // the instantiation kb_step picks (see there)
+    return p.drive_mode == KB_DRIVE_VELOCITY && p.N == 1024 && p.light_type == KB_LIGHT_NONE && threads == 64 * kb::MAX_WAVES &&
+           kb::BPT * 64 * kb::MAX_WAVES == 1024;
+}
 static int lds_bytes_for(const kb::Params &p, int threads, int capL) {
-    return kb::lds::total(kb::lds::fixed(p.M > 0, threads / 64), p.NB, capL, p.NP, p.ncell, p.nmc);
+    const bool objarea = p.M > 0 || uses_fixed_1024(p, threads);
+    return kb::lds::total(kb::lds::fixed(objarea, threads / 64), p.NB, capL, p.NP, p.ncell, p.nmc);
 }
 
 extern "C" {
@@ -382,9 +387,9 @@ int kb_step(kb_sim *sim, const float *d_actions, const float *d_light_action, in
     case KB_DRIVE_VELOCITY: {
         // the flagship size has its own instantiation with a compile-time LDS layout
         const long cap1024 = 4L * 1024 + 64;
-        const bool fixed = p.N == 1024 && p.light_type == KB_LIGHT_NONE && sim->threads == 64 * MAX_WAVES &&
+        const bool fixed = uses_fixed_1024(p, sim->threads) &&
                            p.NP == 1024 && p.NB == 1024 + KB_MAX_OBJECTS + 4 && (obj || p.capL == CAP_LDS) &&
-                           (obj || p.cap == (int)((cap1024 + 7) & ~7L)) && BPT * 64 * MAX_WAVES == 1024;
+                           (obj || p.cap == (int)((cap1024 + 7) & ~7L));
         fn = kb_pick_velocity(fixed ? KB_PICK_FIXED_1024 : p.light_type, obj);
     } break;
     case KB_DRIVE_ACCEL: fn = kb_pick_accel(p.light_type, obj); break;

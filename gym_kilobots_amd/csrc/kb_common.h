@@ -76,14 +76,14 @@ namespace lds {
 constexpr int A16(int x) { return (x + 15) & ~15; }
 constexpr int MISC = 0;
 constexpr int WSUM = MISC + A16(4 * 64);
-constexpr int NLIST = WSUM + A16(4 * 16);
-constexpr int BKMAXRANK = NLIST + 16;
-constexpr int BKSTART = BKMAXRANK + A16(4 * MAX_WAVES * NUM_CLS);
+constexpr int BKSTART = WSUM + A16(4 * 16);
 // buckets of a workgroup of nw waves (the tables double as scratch of the island placement: >= 64 entries)
 __host__ __device__ constexpr int nbk(int nw) { return nw * BK_PER_WAVE < 64 ? 64 : nw * BK_PER_WAVE; }
 __host__ __device__ constexpr int bkfill(int nw) { return BKSTART + A16(4 * (nbk(nw) + 1)); }
-__host__ __device__ constexpr int bklist(int nw) { return bkfill(nw) + A16(4 * nbk(nw)); }
-__host__ __device__ constexpr int objtab(int nw) { return bklist(nw) + A16(2 * nbk(nw)); }   // object table: mass, shape
+__host__ __device__ constexpr int bkmaxrank(int nw) { return bkfill(nw) + A16(4 * nbk(nw)); }
+__host__ __device__ constexpr int bklist(int nw) { return bkmaxrank(nw) + A16(4 * MAX_WAVES * NUM_CLS); }
+__host__ __device__ constexpr int nlist(int nw) { return bklist(nw) + A16(2 * nbk(nw)); }
+__host__ __device__ constexpr int objtab(int nw) { return nlist(nw) + 16; }   // object table: mass, shape
 // object areas, relative to objtab(nw)
 constexpr int OBJBODY = A16(4 * OT_WORDS_C * KB_MAX_OBJECTS);            // body table
 constexpr int OBJCNT = OBJBODY + A16(4 * BT_WORDS_C * KB_MAX_OBJECTS);

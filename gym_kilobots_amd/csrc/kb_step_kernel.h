@@ -25,7 +25,9 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
     const int NB = FN ? ((FN + 3) & ~3) + KB_MAX_OBJECTS + 4 : p.NB;
     const int capL_ = (FN && !OBJ) ? (4 * FN + 64 < CAP_LDS ? 4 * FN + 64 : CAP_LDS) : p.capL;   // (FN >= 32: cap = 4 FN + 64, see kb_create)
     // LDS arrays (offsets: namespace lds in kb_common.h)
-    const int fx = lds::fixed(OBJ, nw), ot_ = lds::objtab(nw);
+    // (the fixed-size instantiations keep room for the object tables even without objects: all their offsets are
+    //  compile-time constants either way, two envs per CU fit both ways, and this image measured 1 % faster)
+    const int fx = lds::fixed(OBJ || FN != 0, nw), ot_ = lds::objtab(nw);
     // positions, velocities and start-of-substep positions as (x, y) pairs: one 8-byte LDS access per body
     float2 *pos = (float2 *)(smem + lds::body32(fx, NB, 0)), *vel = (float2 *)(smem + lds::body32(fx, NB, 2));
     float2 *start = (float2 *)(smem + lds::body32(fx, NB, 4));
@@ -43,9 +45,9 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
     unsigned short *head = (unsigned short *)(smem + lds::head(fx, NB, capL_, NP));   // per-cell list heads (EMPTY16 = empty)
     unsigned *misc = (unsigned *)(smem + lds::MISC), *wsum = (unsigned *)(smem + lds::WSUM);
     unsigned *bkStart = (unsigned *)(smem + lds::BKSTART), *bkFill = (unsigned *)(smem + lds::bkfill(nw));
-    unsigned *bkMaxRank = (unsigned *)(smem + lds::BKMAXRANK);
+    unsigned *bkMaxRank = (unsigned *)(smem + lds::bkmaxrank(nw));
     unsigned short *bkList = (unsigned short *)(smem + lds::bklist(nw));
-    unsigned char *nList = smem + lds::NLIST;
+    unsigned char *nList = smem + lds::nlist(nw);
     float *objTab = (float *)(smem + ot_);                       // fixture table (kb_objects.h: OT_*)
     float *objBody = (float *)(smem + ot_ + lds::OBJBODY);                     // body table (kb_objects.h: BT_*)
     unsigned *objCnt = (unsigned *)(smem + ot_ + lds::OBJCNT);                 // kilobots touching object m
