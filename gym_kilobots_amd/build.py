@@ -57,6 +57,31 @@ def _build(lib, extra, tag, verbose):
     return lib
 
 
+def lint_codegen(verbose=False):
+    """Compile the kernel units to gfx950 assembly and run tools/lint_spills.py over them: the register allocator of
+    ROCm 7.2 was caught placing VGPR spill stores under a narrowed EXEC mask (wrong results, see DESIGN.md
+    "Robustness").  Returns the list of findings (empty = clean)."""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import lint_spills
+    asmdir = os.path.join(HERE, '_obj', 'asm')
+    os.makedirs(asmdir, exist_ok=True)
+    units = [s_ for s_ in sources() if os.path.basename(s_).startswith('kb_inst_')]
+
+    def emit(src):
+        out = os.path.join(asmdir, os.path.basename(src)[:-4] + '.s')
+        cmd = [os.environ.get('HIPCC', 'hipcc')] + FLAGS + ['-I', INC, '-I', CSRC, '--cuda-device-only', '-S', src, '-o', out]
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
+        return out
+    with ThreadPoolExecutor(max_workers=min(6, len(units))) as ex:
+        asm = list(ex.map(emit, units))
+    findings = []
+    for a in asm:
+        findings += lint_spills.lint(a)
+    return findings
+
+
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
