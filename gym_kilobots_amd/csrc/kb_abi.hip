@@ -382,6 +382,7 @@ int kb_step(kb_sim *sim, const float *d_actions, const float *d_light_action, in
     p.n_substeps = n_substeps;
     p.flags = flags;
     const bool obj = p.M > 0;
+    const int objsel = obj ? (sim->threads <= 64 ? 2 : 1) : 0;     // one-wave workgroups with objects: the 256-VGPR instantiation
     kb_step_fn fn = nullptr;
     switch (p.drive_mode) {
     case KB_DRIVE_VELOCITY: {
@@ -390,12 +391,12 @@ int kb_step(kb_sim *sim, const float *d_actions, const float *d_light_action, in
         const bool fixed = uses_fixed_1024(p, sim->threads) &&
                            p.NP == 1024 && p.NB == 1024 + KB_MAX_OBJECTS + 4 && (obj || p.capL == CAP_LDS) &&
                            (obj || p.cap == (int)((cap1024 + 7) & ~7L));
-        fn = kb_pick_velocity(fixed ? KB_PICK_FIXED_1024 : p.light_type, obj);
+        fn = kb_pick_velocity(fixed ? KB_PICK_FIXED_1024 : p.light_type, fixed ? (int)obj : objsel);
     } break;
-    case KB_DRIVE_ACCEL: fn = kb_pick_accel(p.light_type, obj); break;
-    case KB_DRIVE_MOTORS: fn = kb_pick_motors(p.light_type, obj); break;
-    case KB_DRIVE_SIMPLE_PHOTOTAXIS: fn = kb_pick_simple_phototaxis(p.light_type, obj); break;
-    case KB_DRIVE_PHOTOTAXIS: fn = kb_pick_phototaxis(p.light_type, obj); break;
+    case KB_DRIVE_ACCEL: fn = kb_pick_accel(p.light_type, objsel); break;
+    case KB_DRIVE_MOTORS: fn = kb_pick_motors(p.light_type, objsel); break;
+    case KB_DRIVE_SIMPLE_PHOTOTAXIS: fn = kb_pick_simple_phototaxis(p.light_type, objsel); break;
+    case KB_DRIVE_PHOTOTAXIS: fn = kb_pick_phototaxis(p.light_type, objsel); break;
     default: break;
     }
     if (!fn) return fail(KB_EINVAL, "kb_step: no kernel for this drive mode / light type");

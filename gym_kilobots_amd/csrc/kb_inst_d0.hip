@@ -2,12 +2,12 @@
 #include "kb_step_kernel.h"
 
 namespace kb {
-kb_step_fn kb_pick_velocity(int light_type, bool objects) {
+kb_step_fn kb_pick_velocity(int light_type, int objects) {
     if (light_type == KB_PICK_FIXED_1024)
         return objects ? kb_step_kernel<KB_DRIVE_VELOCITY, KB_LIGHT_NONE, true, 1024> : kb_step_kernel<KB_DRIVE_VELOCITY, KB_LIGHT_NONE, false, 1024>;
-    if (light_type == KB_LIGHT_CIRCULAR) return objects ? kb_step_kernel<KB_DRIVE_VELOCITY, KB_LIGHT_CIRCULAR, true> : kb_step_kernel<KB_DRIVE_VELOCITY, KB_LIGHT_CIRCULAR, false>;
-    if (light_type == KB_LIGHT_NONE) return objects ? kb_step_kernel<KB_DRIVE_VELOCITY, KB_LIGHT_NONE, true> : kb_step_kernel<KB_DRIVE_VELOCITY, KB_LIGHT_NONE, false>;
+    if (light_type == KB_LIGHT_CIRCULAR) return kb_pick_obj<KB_DRIVE_VELOCITY, KB_LIGHT_CIRCULAR>(objects);
+    if (light_type == KB_LIGHT_NONE) return kb_pick_obj<KB_DRIVE_VELOCITY, KB_LIGHT_NONE>(objects);
     // GradientLight, MomentumLight, CompositeLight: one general kernel
-    return objects ? kb_step_kernel<KB_DRIVE_VELOCITY, KB_LIGHT_GENERAL, true> : kb_step_kernel<KB_DRIVE_VELOCITY, KB_LIGHT_GENERAL, false>;
+    return kb_pick_obj<KB_DRIVE_VELOCITY, KB_LIGHT_GENERAL>(objects);
 }
 }  // namespace kb

@@ -2,9 +2,9 @@
 #include "kb_step_kernel.h"
 
 namespace kb {
-kb_step_fn kb_pick_simple_phototaxis(int light_type, bool objects) {
-    if (light_type == KB_LIGHT_CIRCULAR) return objects ? kb_step_kernel<KB_DRIVE_SIMPLE_PHOTOTAXIS, KB_LIGHT_CIRCULAR, true> : kb_step_kernel<KB_DRIVE_SIMPLE_PHOTOTAXIS, KB_LIGHT_CIRCULAR, false>;
+kb_step_fn kb_pick_simple_phototaxis(int light_type, int objects) {
+    if (light_type == KB_LIGHT_CIRCULAR) return kb_pick_obj<KB_DRIVE_SIMPLE_PHOTOTAXIS, KB_LIGHT_CIRCULAR>(objects);
     // GradientLight, MomentumLight, CompositeLight: one general kernel
-    return objects ? kb_step_kernel<KB_DRIVE_SIMPLE_PHOTOTAXIS, KB_LIGHT_GENERAL, true> : kb_step_kernel<KB_DRIVE_SIMPLE_PHOTOTAXIS, KB_LIGHT_GENERAL, false>;
+    return kb_pick_obj<KB_DRIVE_SIMPLE_PHOTOTAXIS, KB_LIGHT_GENERAL>(objects);
 }
 }  // namespace kb

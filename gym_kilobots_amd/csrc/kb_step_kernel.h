@@ -9,8 +9,13 @@ namespace kb {
 // FN > 0: specialisation for num_bots == FN and the full workgroup (64 * KB_MAX_WAVES threads): every LDS offset, array
 // size and trip count is a compile-time constant instead of a value kept in scalar registers (with objects the size
 // of the contact staging area, and so the offsets behind it, stay run-time values: they depend on the fixture count).
-template <int DRIVE_MODE, int LIGHT_TYPE, bool OBJ, int FN = 0>
-__global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_step_kernel(const Params p) {
+// WIDE: instantiation for one-wave workgroups (swarms of up to 64 kilobots) in scenes with objects: launch bounds of two
+// waves per SIMD give it 256 VGPRs, i.e. no register spills at all, where the LDS footprint of such scenes allows at most
+// 7 - 8 envs per CU anyway (and spill code is where the toolchain bug of DESIGN.md "Robustness" lives).  Measured: + 13 %
+// at 64 kilobots + 4 boxes; two-wave workgroups would lose a third of their residency, so they keep the 128-register
+// instantiation.
+template <int DRIVE_MODE, int LIGHT_TYPE, bool OBJ, int FN = 0, bool WIDE = false>
+__global__ void __launch_bounds__(WIDE ? 64 : 64 * KB_MAX_WAVES, WIDE ? 2 : KB_MIN_WAVES_PER_SIMD) kb_step_kernel(const Params p) {
     extern __shared__ __align__(16) unsigned char smem[];
     int e = blockIdx.x;
     int tid = threadIdx.x;
@@ -1649,5 +1654,13 @@ __global__ void __launch_bounds__(64 * KB_MAX_WAVES, KB_MIN_WAVES_PER_SIMD) kb_s
     }
 }
 
+
+// instantiation chooser of the kb_inst_d*.hip units: objects = 0 none, 1 with objects, 2 with objects and a one-wave
+// workgroup (the WIDE instantiation)
+template <int DRIVE_MODE, int LIGHT_TYPE>
+static kb_step_fn kb_pick_obj(int objects) {
+    if (objects == 2) return kb_step_kernel<DRIVE_MODE, LIGHT_TYPE, true, 0, true>;
+    return objects ? kb_step_kernel<DRIVE_MODE, LIGHT_TYPE, true> : kb_step_kernel<DRIVE_MODE, LIGHT_TYPE, false>;
+}
 
 }  // namespace kb
