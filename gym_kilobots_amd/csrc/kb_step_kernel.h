@@ -981,14 +981,23 @@ __global__ void __launch_bounds__(WIDE ? 64 : 64 * KB_MAX_WAVES, WIDE ? 2 : KB_M
                                 (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(lo);
             }
             // ---- full load of the contacts ----
+            // Kernels with objects (except the spill-free WIDE ones): lanes without a contact in slot j load a copy of the
+            // wave's first contact and drop it again, so that the slot loads run under the full EXEC mask.  (These kernels
+            // spill registers; the toolchain
+            // was caught storing slot 0's spilled values under the narrowed mask of `if (rvalid[1])` and reloading them
+            // under the full one -- DESIGN.md "Robustness".  Without a lane-dependent region around the loads there is no
+            // narrowed mask to get wrong here.)
+            const bool anyContact = (unsigned)__builtin_amdgcn_readfirstlane((int)mycnt) > 0u;
+            constexpr bool FULLMASK = OBJ && !WIDE;
+            const int cSafe = (FULLMASK && anyContact) ? (int)lOrder[mybase] : 0;
 #pragma unroll
             for (int j = 0; j < KREG; ++j) {
                 ra[j] = 0; rb[j] = 0; rslot[j] = 255; risl[j] = 0;
                 racc[j] = 0.0f; rnx[j] = 1.0f; rny[j] = 0.0f; rflip[j] = false;
                 rima[j] = 0.0f; rimb[j] = 0.0f; rra[j] = 0.0f; rrb[j] = 0.0f; rnm[j] = 0.0f;
                 rpoly[j] = false; rrAx[j] = 0.0f; rrAy[j] = 0.0f; rlnx[j] = 0.0f; rlny[j] = 0.0f; rlpx[j] = 0.0f; rlpy[j] = 0.0f;
-                if (rvalid[j]) {
-                    const int c = rc[j];
+                if (FULLMASK ? anyContact : rvalid[j]) {
+                    const int c = (FULLMASK && !rvalid[j]) ? cSafe : rc[j];
                     const unsigned pr = lPair[c], inf = lInfo[c];
                     const int a = pr & 0xFFFF, b = pr >> 16;
                     ra[j] = a; rb[j] = b; rslot[j] = (inf >> 16) & 0xFF; racc[j] = lAcc[c];
@@ -1031,6 +1040,12 @@ __global__ void __launch_bounds__(WIDE ? 64 : 64 * KB_MAX_WAVES, WIDE ? 2 : KB_M
                             const float inv = 1.0f / len;
                             rnx[j] = dx * inv; rny[j] = dy * inv;
                         }
+                    }
+                    if (FULLMASK && !rvalid[j]) {    // not a contact of this lane: back to the neutral values
+                        ra[j] = 0; rb[j] = 0; rslot[j] = 255; risl[j] = 0;
+                        racc[j] = 0.0f; rnx[j] = 1.0f; rny[j] = 0.0f; rflip[j] = false;
+                        rima[j] = 0.0f; rimb[j] = 0.0f; rra[j] = 0.0f; rrb[j] = 0.0f; rnm[j] = 0.0f;
+                        rpoly[j] = false; rrAx[j] = 0.0f; rrAy[j] = 0.0f; rlnx[j] = 0.0f; rlny[j] = 0.0f; rlpx[j] = 0.0f; rlpy[j] = 0.0f;
                     }
                 }
             }
