@@ -30,48 +30,9 @@ def cmp(tag):
     return bad
 cmp('after reset')
 la = torch.tensor([[0.01, 0.0]], dtype=torch.float32)
-def oracle_after_iterations(k_iters):
-    # copy of the oracle sim with pos_iters = k_iters, stepped once from the current state: x after k position iterations
-    import copy, ctypes
-    from oracle import oracle as O
-    src = os_.o
-    cfg = copy.copy(src.cfg); cfg.pos_iters = k_iters
-    dst = O.OracleSim(cfg)
-    for name, val in vars(src).items():
-        if isinstance(val, np.ndarray) and isinstance(getattr(dst, name, None), np.ndarray) and getattr(dst, name).shape == val.shape:
-            getattr(dst, name)[...] = val
-    dst.step(1, light_action=la.numpy())
-    return dst.x.copy()
 for k in range(10):
-    pre = [oracle_after_iterations(i) for i in range(6)] if os.environ.get('DUMPP') else None
     gs.step(1, light_action=la.cuda()); os_.step(1, light_action=la)
-    if pre is not None:
-        bufs = [gs.light_value, gs.light_gx, gs.light_gy, gs.cmd_vx, gs.cmd_vy, gs.cmd_w]
-        for i in range(6):
-            gx = bufs[i].cpu().numpy().reshape(-1)[:40]
-            d = np.abs(gx.astype(np.float64) - pre[i].reshape(-1)[:40])
-            print('substep %d: after %d position iterations: max |x_gpu - x_oracle| = %.3e at bot %d; bots differing: %s' % (k, i, d.max(), int(d.argmax()), np.nonzero(d > 0)[0].tolist()))
-    if os.environ.get('DUMPQ'):
-        u = lambda t: t.cpu().numpy().view(np.uint32).reshape(-1)[:40]
-        a0 = np.concatenate([u(gs.light_value), u(gs.cmd_vy)[:24]]); b0 = np.concatenate([u(gs.light_gx), u(gs.cmd_w)[:24]])
-        a1 = u(gs.light_gy); b1 = u(gs.cmd_vx)
-        def dec(a, b, n):
-            out = []
-            for l in range(n):
-                if not (b[l] >> 31): continue
-                out.append((l, int(a[l] & 0xFFFFFF) // 8, int(b[l] & 0xFFFFFF) // 8, 'circ' if a[l] >> 31 else 'POLY', 'bot' if (a[l] >> 30) & 1 else 'WALL'))
-            return out
-        print('substep', k, 'slot0 (lane, a, b, kind, a-kind):', dec(a0, b0, 64))
-        print('substep', k, 'slot1:', dec(a1, b1, 40))
     bad = cmp('substep %d' % k)
-    if os.environ.get('DUMPV'):
-        v = gs.cmd_vx.cpu().numpy().view(np.uint32).reshape(-1)[:40].reshape(10, 4)
-        print('substep', k, 'status %08x' % (int(gs.status.cpu().numpy()[0]) & 0xffffffff)); gs.status.zero_()
-        print('substep', k, 'ron masks per position iteration (slot0 lo hi, slot1 lo hi):')
-        for it in range(10):
-            print('   it %d  %08x%08x  %08x%08x' % (it, v[it, 1], v[it, 0], v[it, 3], v[it, 2]))
-        print('   depth counters slot0', gs.cmd_vy.cpu().numpy().view(np.int32).reshape(-1)[:40].tolist())
-        print('   depth counters slot1', gs.cmd_w.cpu().numpy().view(np.int32).reshape(-1)[:40].tolist())
     try:
         from tests.test_parity_gpu import assert_ws_same
         assert_ws_same(os_.o, gs, 'substep %d' % k)
