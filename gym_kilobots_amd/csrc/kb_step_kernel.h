@@ -14,7 +14,9 @@ namespace kb {
 // 7 - 8 envs per CU anyway (and spill code is where the toolchain bug of DESIGN.md "Robustness" lives).  Measured: + 13 %
 // at 64 kilobots + 4 boxes; two-wave workgroups would lose a third of their residency, so they keep the 128-register
 // instantiation.
-template <int DRIVE_MODE, int LIGHT_TYPE, bool OBJ, int FN = 0, bool WIDE = false>
+// POLY = false: instantiation for scenes whose objects are all discs (BASELINE config 4): the kilobot - polygon contact
+// code and its per-slot registers fold away (half the register spills, + 9 % at cfg4).
+template <int DRIVE_MODE, int LIGHT_TYPE, bool OBJ, int FN = 0, bool WIDE = false, bool POLY = true>
 __global__ void __launch_bounds__(WIDE ? 64 : 64 * KB_MAX_WAVES, WIDE ? 2 : KB_MIN_WAVES_PER_SIMD) kb_step_kernel(const Params p) {
     extern __shared__ __align__(16) unsigned char smem[];
     int e = blockIdx.x;
@@ -69,7 +71,7 @@ __global__ void __launch_bounds__(WIDE ? 64 : 64 * KB_MAX_WAVES, WIDE ? 2 : KB_M
     };
     // is body id a polygon object (kilobot - polygon contacts carry a lever arm on the object)
     auto bpoly = [&](int id) __attribute__((always_inline)) -> bool {
-        return OBJ && id >= N && id < WALL_CODE && objBody[(id - N) * BT_WORDS + BT_KIND] != 0.0f;
+        return OBJ && POLY && id >= N && id < WALL_CODE && objBody[(id - N) * BT_WORDS + BT_KIND] != 0.0f;
     };
     ObjCtx ox;
     ox.pos = pos; ox.vel = vel; ox.objW = objW; ox.objA = objA; ox.objTab = objTab; ox.objBody = objBody;

@@ -443,13 +443,20 @@ def test_object_object_and_object_wall_contacts():
     assert osim.objects_m()[0, 1, 0] > 0.92 and int(cpu(gsim.status).max()) == 0
 
 
-def test_cfg4_slice_1024_bots_4_objects():
-    """BASELINE config 4 geometry on 2 envs (lattice of 1024 bots overlapping four discs at reset)."""
+@pytest.mark.parametrize('mode', [0, 1, 2, 3])
+def test_cfg4_slice_1024_bots_4_objects(mode):
+    """BASELINE config 4 geometry on 2 envs (lattice of 1024 bots overlapping four discs at reset); velocity control,
+    no light, 1024 kilobots, discs only: the disc-only fixed-size instantiation, in every solver path.  One disc is
+    thrown at the wall (continuous step of an object) and one at its neighbour (object-object manifold)."""
     E, N = 2, 1024
     xy, th = scenes.lattice_spawn(E, N, seed=71)
     th = scenes.toward_objects_theta(xy)
     objs = np.tile(scenes.CFG4_OBJECTS[None], (E, 1, 1))
-    osim, gsim = make_pair(E, N, xy=xy, th=th, objects=objs)
+    osim, gsim = make_pair(E, N, xy=xy, th=th, objects=objs, solver_mode=mode)
+    v0 = np.zeros((E, objs.shape[1]), np.float32)
+    v0[:, 0], v0[:, 1] = 9.0, -4.0
+    osim.ovx[...] = v0
+    gsim.ovx.copy_(dev(v0))
     osim.step(1, flags=O.STEP_NO_DRIVE)
     gsim.step(1, flags=O.STEP_NO_DRIVE)             # reset(): step to resolve the initial overlaps
     assert_same(osim, gsim, 'cfg4 resolve', OBJ_FIELDS)
@@ -460,8 +467,8 @@ def test_cfg4_slice_1024_bots_4_objects():
         osim.set_actions(a)
         osim.step(10)
         gsim.step(10, actions=dev(a))
-        assert_same(osim, gsim, 'cfg4 step %d' % k, OBJ_FIELDS)
-        assert_ws_same(osim, gsim, 'cfg4 step %d' % k)
+        assert_same(osim, gsim, 'cfg4 mode %d step %d' % (mode, k), OBJ_FIELDS)
+        assert_ws_same(osim, gsim, 'cfg4 mode %d step %d' % (mode, k))
     assert osim.count_contacts(0, True)[2] > 10
     assert int(cpu(gsim.status).max()) == 0
 
