@@ -48,7 +48,7 @@ def _build(lib, extra, tag, verbose):
     objdir = os.path.join(HERE, '_obj', tag)
     os.makedirs(objdir, exist_ok=True)
     jobs = [(s, os.path.join(objdir, os.path.basename(s)[:-4] + '.o'), extra, verbose) for s in sources()]
-    with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
+    with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
         objs = list(ex.map(_compile, jobs))
     cmd = [os.environ.get('HIPCC', 'hipcc'), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + objs
     if verbose:
@@ -74,7 +74,7 @@ def lint_codegen(verbose=False):
             print(' '.join(cmd))
         subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
         return out
-    with ThreadPoolExecutor(max_workers=min(6, len(units))) as ex:
+    with ThreadPoolExecutor(max_workers=min(8, len(units))) as ex:
         asm = list(ex.map(emit, units))
     findings = []
     for a in asm:
@@ -107,7 +107,7 @@ def build_variant(name, defines, only=None, verbose=False):
             reuse.append(os.path.join(HERE, '_obj', 'rel', base + '.o'))
             continue
         jobs.append((s, os.path.join(objdir, base + '.o'), list(defines), verbose))
-    with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         objs = list(ex.map(_compile, jobs))
     subprocess.check_call([os.environ.get('HIPCC', 'hipcc'), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + objs + reuse)
     return lib

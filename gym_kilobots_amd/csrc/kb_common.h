@@ -401,6 +401,7 @@ typedef void (*kb_step_fn)(const Params);
 constexpr int KB_PICK_FIXED_1024 = -1024;   // kb_pick_velocity: the num_bots == 1024 specialisations (no light; without / with objects)
 // one translation unit per drive law (kb_inst_d*.hip) instantiates its kernels and hands out the right one
 kb_step_fn kb_pick_velocity(int light_type, int objects);   // objects: 0 none, 1 yes, 2 yes + one-wave workgroup
+kb_step_fn kb_pick_velocity_discs(int light_type, int objects);   // objects: 5 discs, 6 discs + one-wave workgroup
 kb_step_fn kb_pick_accel(int light_type, int objects);   // objects: 0 none, 1 yes, 2 yes + one-wave workgroup
 kb_step_fn kb_pick_motors(int light_type, int objects);   // objects: 0 none, 1 yes, 2 yes + one-wave workgroup
 kb_step_fn kb_pick_simple_phototaxis(int light_type, int objects);   // objects: 0 none, 1 yes, 2 yes + one-wave workgroup
