@@ -385,7 +385,11 @@ int kb_step(kb_sim *sim, const float *d_actions, const float *d_light_action, in
     p.n_substeps = n_substeps;
     p.flags = flags;
     const bool obj = p.M > 0;
-    const int objsel = obj ? (sim->threads <= 64 ? 2 : 1) : 0;     // one-wave workgroups with objects: the 256-VGPR instantiation
+    int objsel = obj ? (sim->threads <= 64 ? 2 : 1) : 0;     // one-wave workgroups with objects: the 256-VGPR instantiation
+    // scenes whose objects are all discs: instantiations without the kilobot - polygon contact code (5 / 6)
+    bool discs = obj;
+    for (int f = 0; f < p.F; ++f) discs = discs && ot_kind(p.otab[f]) == KB_SHAPE_CIRCLE;
+    if (discs) objsel += 4;
     kb_step_fn fn = nullptr;
     switch (p.drive_mode) {
     case KB_DRIVE_VELOCITY: {
@@ -394,10 +398,7 @@ int kb_step(kb_sim *sim, const float *d_actions, const float *d_light_action, in
         const bool fixed = uses_fixed_1024(p, sim->threads) &&
                            p.NP == 1024 && p.NB == 1024 + KB_MAX_OBJECTS + 4 && (obj || p.capL == CAP_LDS) &&
                            (obj || p.cap == (int)((cap1024 + 7) & ~7L));
-        // scenes whose objects are all discs: instantiations without the kilobot - polygon contact code (this drive law only)
-        bool discs = obj;
-        for (int f = 0; f < p.F; ++f) discs = discs && ot_kind(p.otab[f]) == KB_SHAPE_CIRCLE;
-        fn = kb_pick_velocity(fixed ? KB_PICK_FIXED_1024 : p.light_type, discs ? (fixed || objsel == 1 ? 5 : 6) : (fixed ? (int)obj : objsel));
+        fn = kb_pick_velocity(fixed ? KB_PICK_FIXED_1024 : p.light_type, fixed ? (discs ? 5 : (int)obj) : objsel);
     } break;
     case KB_DRIVE_ACCEL: fn = kb_pick_accel(p.light_type, objsel); break;
     case KB_DRIVE_MOTORS: fn = kb_pick_motors(p.light_type, objsel); break;

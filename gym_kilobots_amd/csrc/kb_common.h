@@ -402,9 +402,13 @@ constexpr int KB_PICK_FIXED_1024 = -1024;   // kb_pick_velocity: the num_bots ==
 // one translation unit per drive law (kb_inst_d*.hip) instantiates its kernels and hands out the right one
 kb_step_fn kb_pick_velocity(int light_type, int objects);   // objects: 0 none, 1 yes, 2 yes + one-wave workgroup
 kb_step_fn kb_pick_velocity_discs(int light_type, int objects);   // objects: 5 discs, 6 discs + one-wave workgroup
-kb_step_fn kb_pick_accel(int light_type, int objects);   // objects: 0 none, 1 yes, 2 yes + one-wave workgroup
-kb_step_fn kb_pick_motors(int light_type, int objects);   // objects: 0 none, 1 yes, 2 yes + one-wave workgroup
-kb_step_fn kb_pick_simple_phototaxis(int light_type, int objects);   // objects: 0 none, 1 yes, 2 yes + one-wave workgroup
-kb_step_fn kb_pick_phototaxis(int light_type, int objects);   // objects: 0 none, 1 yes, 2 yes + one-wave workgroup
+kb_step_fn kb_pick_accel(int light_type, int objects);
+kb_step_fn kb_pick_accel_discs(int light_type, int objects);   // objects: 0 none, 1 yes, 2 yes + one-wave workgroup
+kb_step_fn kb_pick_motors(int light_type, int objects);
+kb_step_fn kb_pick_motors_discs(int light_type, int objects);   // objects: 0 none, 1 yes, 2 yes + one-wave workgroup
+kb_step_fn kb_pick_simple_phototaxis(int light_type, int objects);
+kb_step_fn kb_pick_simple_phototaxis_discs(int light_type, int objects);   // objects: 0 none, 1 yes, 2 yes + one-wave workgroup
+kb_step_fn kb_pick_phototaxis(int light_type, int objects);
+kb_step_fn kb_pick_phototaxis_discs(int light_type, int objects);   // objects: 0 none, 1 yes, 2 yes + one-wave workgroup
 
 }  // namespace kb

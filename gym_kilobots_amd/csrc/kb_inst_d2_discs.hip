@@ -1,0 +1,16 @@
+// kernel instantiations for drive law KB_DRIVE_MOTORS in scenes whose objects are all discs: the kilobot - polygon
+// contact code and its per-slot registers fold away (POLY = false)
+#include "kb_step_kernel.h"
+
+namespace kb {
+template <int LIGHT_TYPE>
+static kb_step_fn pick(int objects) {    // 5: objects, 6: objects + one-wave workgroup
+    return objects == 6 ? kb_step_kernel<KB_DRIVE_MOTORS, LIGHT_TYPE, true, 0, true, false>
+                        : kb_step_kernel<KB_DRIVE_MOTORS, LIGHT_TYPE, true, 0, false, false>;
+}
+kb_step_fn kb_pick_motors_discs(int light_type, int objects) {
+    if (light_type == KB_LIGHT_CIRCULAR) return pick<KB_LIGHT_CIRCULAR>(objects);
+    if (light_type == KB_LIGHT_NONE) return pick<KB_LIGHT_NONE>(objects);
+    return pick<KB_LIGHT_GENERAL>(objects);
+}
+}  // namespace kb

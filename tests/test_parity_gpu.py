@@ -426,6 +426,44 @@ def test_objects_pushed_by_a_crowd(mode):
     assert np.abs(osim.objects_m()[..., :2] - objs).max() > 1e-4        # the discs were actually pushed
 
 
+@pytest.mark.parametrize('drive', [O.DRIVE_VELOCITY, O.DRIVE_ACCEL, O.DRIVE_MOTORS, O.DRIVE_SIMPLE_PHOTOTAXIS, O.DRIVE_PHOTOTAXIS])
+@pytest.mark.parametrize('N', [40, 200])
+def test_disc_objects_in_every_drive_mode(drive, N):
+    """Scenes whose objects are all discs run the instantiations without the polygon contact code (one per drive law, as a
+    one-wave 256-VGPR kernel at 40 kilobots and as a regular one at 200): bit-exact against the oracle, discs pushed,
+    thrown at a wall and at each other."""
+    E = 3
+    xy, th = scenes.gaussian_spawn(E, N, sigma=0.25, seed=140 + N)
+    th = scenes.toward_objects_theta(xy)
+    objs = np.tile(scenes.CFG4_OBJECTS[None, :3], (E, 1, 1))
+    light = O.LIGHT_CIRCULAR if drive in (O.DRIVE_SIMPLE_PHOTOTAXIS, O.DRIVE_PHOTOTAXIS) else O.LIGHT_NONE
+    kw = dict(light_lo=(-1.1, -0.825), light_hi=(1.1, 0.825), light_radius=0.6) if light != O.LIGHT_NONE else {}
+    osim, gsim = make_pair(E, N, drive, light, xy=xy, th=th, objects=objs, **kw)
+    v0 = np.tile(np.array([8.0, -5.0, 0.0], np.float32)[None], (E, 1))
+    osim.ovx[...] = v0
+    gsim.ovx.copy_(dev(v0))
+    rng = np.random.RandomState(3)
+    if drive == O.DRIVE_MOTORS:
+        ml = np.where(rng.rand(E, N) < 0.5, 255, 0).astype(np.uint8)
+        osim.motor_l[...], osim.motor_r[...] = ml, 255 - ml
+        gsim.motor_l.copy_(dev(ml)); gsim.motor_r.copy_(dev((255 - ml).astype(np.uint8)))
+    for k in range(5):
+        kws_o, kws_g = {}, {}
+        if light != O.LIGHT_NONE:
+            la = rng.uniform(-0.02, 0.02, size=(E, 2)).astype(np.float32)
+            kws_o, kws_g = dict(light_action=la), dict(light_action=dev(la))
+        if drive in (O.DRIVE_VELOCITY, O.DRIVE_ACCEL):
+            a = scenes.random_actions(E, N, seed=150 + k)
+            osim.set_actions(a)
+            kws_g['actions'] = dev(a)
+        osim.step(10, **kws_o)
+        gsim.step(10, **kws_g)
+        assert_same(osim, gsim, 'discs drive %d N %d step %d' % (drive, N, k), OBJ_FIELDS)
+        assert_ws_same(osim, gsim, 'discs drive %d N %d step %d' % (drive, N, k))
+    assert int(cpu(gsim.status).max()) == 0
+    assert np.abs(osim.objects_m()[..., :2] - objs).max() > 1e-3
+
+
 def test_object_object_and_object_wall_contacts():
     E, N = 2, 6
     xy = np.tile(np.array([[0.55, 0.02 * (i - 2.5)] for i in range(6)])[None], (E, 1, 1))
