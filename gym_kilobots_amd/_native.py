@@ -19,6 +19,7 @@ MAX_POLY_VERTS = 4
 SHAPE_CIRCLE, SHAPE_BOX, SHAPE_POLYGON = range(3)
 OWS_COLS, OWS_WORDS = 12, 6
 MAX_BOTS = 1024
+DAMPING_PADE, DAMPING_LINEAR = 0, 1
 WORLD_SCALE = 25.0    # reference gym_kilobots/lib/body.py:7
 
 
@@ -48,7 +49,13 @@ class KbConfig(C.Structure):
         ('obj_verts', ((C.c_float * 2) * MAX_POLY_VERTS) * MAX_OBJECTS),
         ('wall_friction', C.c_float),
         ('num_fixtures', C.c_int32), ('obj_fixture_body', C.c_int32 * MAX_OBJECTS),
+        ('damping_model', C.c_int32), ('sense_radius', C.c_float), ('contact_capacity', C.c_int32),
     ]
+
+
+class KbResetParams(C.Structure):
+    _fields_ = [('seed', C.c_uint64), ('env_offset', C.c_int32), ('mean', C.c_float * 2), ('std', C.c_float),
+                ('random_theta', C.c_int32), ('random_velocity', C.c_int32), ('resolve', C.c_int32)]
 
 
 _P = C.c_void_p
@@ -58,14 +65,14 @@ BUFFER_FIELDS = ['x', 'y', 'theta', 'v', 'w', 'acc_v', 'acc_w', 'motor_l', 'moto
                  'light_x', 'light_y', 'light_vx', 'light_vy',
                  'ox', 'oy', 'otheta', 'ovx', 'ovy', 'ow',
                  'ws_key', 'ws_acc', 'ws_cnt',
-                 'light_value', 'light_gx', 'light_gy', 'cmd_vx', 'cmd_vy', 'cmd_w', 'status', 'scratch', 'ows_acc']
+                 'light_value', 'light_gx', 'light_gy', 'cmd_vx', 'cmd_vy', 'cmd_w', 'status', 'scratch', 'ows_acc', 'nbr_count']
 
 
 class KbBuffers(C.Structure):
     _fields_ = [(n, _P) for n in BUFFER_FIELDS]
 
 
-EXPORTS = ['kb_create', 'kb_destroy', 'kb_bind', 'kb_set_actions', 'kb_step', 'kb_get_poses',
+EXPORTS = ['kb_create', 'kb_destroy', 'kb_bind', 'kb_set_actions', 'kb_step', 'kb_get_poses', 'kb_sense', 'kb_reset',
            'kb_lds_bytes', 'kb_contact_capacity', 'kb_scratch_bytes', 'kb_light_action_dim', 'kb_light_count', 'kb_block_threads', 'kb_set_block_threads',
            'kb_last_error', 'kb_version']
 
@@ -74,6 +81,22 @@ _lib = None
 
 class KilobotsHipError(RuntimeError):
     pass
+
+
+STATUS_BITS = {
+    1: 'contact capacity overflow: contacts were dropped (raise kb_config.contact_capacity or spread the spawn)',
+    2: 'warm-start slot overflow: a kilobot touches more partners than kb_config.ws_slots, their impulses are not carried over',
+    4: 'a device staging limit was hit (more than 64 kilobots on one fixture, 255 kilobot-object contacts in one env or 63 partners in one cell pair)',
+    8: 'continuous step skipped for some kilobots: more kilobots near the walls in one substep than the staging area holds',
+}
+
+
+class KilobotsStatusError(KilobotsHipError):
+    """A capacity limit of the device step was hit: the trajectories of the flagged envs are degraded."""
+
+
+def describe_status(bits):
+    return '; '.join(msg for b, msg in sorted(STATUS_BITS.items()) if bits & b) or 'ok'
 
 
 def load():
@@ -98,6 +121,10 @@ def load():
     lib.kb_step.restype = C.c_int
     lib.kb_get_poses.argtypes = [_P, _P, _P]
     lib.kb_get_poses.restype = C.c_int
+    lib.kb_sense.argtypes = [_P, C.c_float, _P, _P]
+    lib.kb_sense.restype = C.c_int
+    lib.kb_reset.argtypes = [_P, C.POINTER(KbResetParams), _P]
+    lib.kb_reset.restype = C.c_int
     for name in ('kb_lds_bytes', 'kb_contact_capacity', 'kb_block_threads', 'kb_light_action_dim', 'kb_light_count'):
         getattr(lib, name).argtypes = [_P]
         getattr(lib, name).restype = C.c_int
@@ -138,12 +165,15 @@ def default_config(num_envs, num_bots, drive_mode=DRIVE_VELOCITY, light_type=LIG
     c.light_act_lo[0] = c.light_act_lo[1] = -0.01
     c.light_act_hi[0] = c.light_act_hi[1] = 0.01
     c.light_max_velocity = inf
-    c.ws_slots = 8
+    c.ws_slots = 32     # contacts per kilobot whose impulse is carried over (Box2D keeps every b2Contact; 32 covers a dense overlapping spawn)
     c.obj_density, c.obj_friction = 2.0, 0.01
     c.obj_linear_damping = c.obj_angular_damping = 0.8
     c.toi_walls = 1      # b2World continuousPhysics defaults to true
     c.wall_friction = 0.2  # b2FixtureDef default (the arena chain, kilobots_env.py:46-51)
     c.solver_mode = 0
+    c.damping_model = DAMPING_PADE
+    c.sense_radius = 0.0
+    c.contact_capacity = 0
     c.light_count = 1
     for i in range(MAX_LIGHTS):
         c.light_kind[i] = LIGHT_CIRCULAR

@@ -20,6 +20,7 @@ PROF_LIB = os.path.join(HERE, 'libkilobots_hip_prof.so')
 
 # -ffp-contract=off: the step is specified as a sequence of individually rounded fp32 operations
 # (DESIGN.md); fused multiply-adds would make results depend on compiler scheduling.
+EXPECTED_HIPCC = 'HIP version: 7.2'     # toolchain of the round-1/2 parity and fuzz runs
 FLAGS = ['--offload-arch=gfx950', '-O3', '-ffp-contract=off', '-fno-fast-math', '-fPIC', '-std=c++17']
 
 
@@ -37,30 +38,76 @@ def needs_build(lib=LIB):
 
 def _compile(args):
     src, obj, extra, verbose = args
-    cmd = [os.environ.get('HIPCC', 'hipcc')] + FLAGS + extra + ['-I', INC, '-I', CSRC, '-c', src, '-o', obj]
+    # -save-temps=obj keeps the gfx950 assembly of exactly the object that gets linked next to it: the codegen lint
+    # (tools/lint_spills.py) reads that file
+    cmd = [os.environ.get('HIPCC', 'hipcc')] + FLAGS + extra + ['-I', INC, '-I', CSRC, '-save-temps=obj', '-c', src, '-o', obj]
     if verbose:
         print(' '.join(cmd))
-    subprocess.check_call(cmd)
+    subprocess.check_call(cmd, stderr=subprocess.DEVNULL if not verbose else None)
     return obj
 
 
-def _build(lib, extra, tag, verbose):
+def _device_asm(objdir, src):
+    return os.path.join(objdir, os.path.basename(src)[:-4] + '-hip-amdgcn-amd-amdhsa-gfx950.s')
+
+
+def hipcc_version():
+    try:
+        out = subprocess.run([os.environ.get('HIPCC', 'hipcc'), '--version'], stdout=subprocess.PIPE, stderr=subprocess.STDOUT).stdout.decode()
+        return ' | '.join(l.strip() for l in out.split('\n') if 'HIP version' in l or 'clang version' in l)
+    except Exception as err:      # noqa: BLE001
+        return 'unknown (%s)' % err
+
+
+def _lint_asm(paths):
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import lint_spills
+    findings = []
+    for a in paths:
+        findings += lint_spills.lint(a)
+    return findings
+
+
+def _build(lib, extra, tag, verbose, lint=True):
     objdir = os.path.join(HERE, '_obj', tag)
     os.makedirs(objdir, exist_ok=True)
     jobs = [(s, os.path.join(objdir, os.path.basename(s)[:-4] + '.o'), extra, verbose) for s in sources()]
     with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
         objs = list(ex.map(_compile, jobs))
+    info = {'hipcc': hipcc_version(), 'flags': FLAGS + list(extra), 'lint': 'skipped'}
+    if lint:
+        # The register allocator of ROCm 7.2 (clang 22) was caught placing VGPR spill stores under a narrowed EXEC mask
+        # (wrong physics, DESIGN.md "Robustness").  Every build is checked for that code shape and FAILS on a finding:
+        # a different hipcc must not produce a silently miscompiled library.
+        asm = [_device_asm(objdir, s_) for s_ in sources() if os.path.basename(s_).startswith('kb_inst_')]
+        missing = [a for a in asm if not os.path.exists(a)]
+        if missing:
+            raise RuntimeError('codegen lint: hipcc did not leave the device assembly (%s); refusing to link an unchecked library' % missing[0])
+        findings = _lint_asm(asm)
+        if findings:
+            if os.path.exists(lib):
+                os.remove(lib)
+            raise RuntimeError('codegen lint failed with %s: %d VGPR spill store(s) ahead of the EXEC restore of their block, e.g. %s'
+                               % (info['hipcc'], len(findings), findings[0]))
+        info['lint'] = 'clean (%d kernel units)' % len(asm)
+        if EXPECTED_HIPCC not in info['hipcc']:
+            print('WARNING: built with "%s"; the parity suite and the 20 000-scene fuzz were run with %s. '
+                  'Run `python -m pytest tests -m gpu` and tools/debug_fuzz_seed.py sweeps before trusting this build.'
+                  % (info['hipcc'], EXPECTED_HIPCC), file=sys.stderr)
     cmd = [os.environ.get('HIPCC', 'hipcc'), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + objs
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd)
+    import json
+    json.dump(info, open(os.path.join(objdir, 'build_info.json'), 'w'), indent=1)
     return lib
 
 
 def lint_codegen(verbose=False):
     """Compile the kernel units to gfx950 assembly and run tools/lint_spills.py over them: the register allocator of
     ROCm 7.2 was caught placing VGPR spill stores under a narrowed EXEC mask (wrong results, see DESIGN.md
-    "Robustness").  Returns the list of findings (empty = clean)."""
+    "Robustness").  Returns the list of findings (empty = clean).  (build() runs the same lint on the assembly of the
+    objects it links and fails on a finding; this entry point re-derives the assembly from the sources.)"""
     sys.path.insert(0, os.path.join(ROOT, 'tools'))
     import lint_spills
     asmdir = os.path.join(HERE, '_obj', 'asm')
@@ -91,7 +138,7 @@ def build(force=False, verbose=False):
 def build_profile(verbose=False):
     """Diagnostic build with in-kernel cycle stamps per phase (tools/phase_profile.py); never shipped
     as the product library: it writes its stamps behind the status buffer."""
-    return _build(PROF_LIB, ['-DKB_PROFILE'], 'prof', verbose)
+    return _build(PROF_LIB, ['-DKB_PROFILE'], 'prof', verbose, lint=False)
 
 
 def build_variant(name, defines, only=None, verbose=False):

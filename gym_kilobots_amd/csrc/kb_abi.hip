@@ -60,7 +60,90 @@ __global__ void kb_get_poses_kernel(const float *x, const float *y, const float 
 }
 
 
+// IR-range neighbour sensing on the current poses (kb_sense): one workgroup per env builds the cell lists of the
+// broadphase grid in LDS and runs the sensing pass of the step kernel on them
+__global__ void __launch_bounds__(256) kb_sense_kernel(const Params p, const int s, const float R2, unsigned *out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int e = blockIdx.x, tid = threadIdx.x, nt = blockDim.x, N = p.N;
+    float2 *pos = reinterpret_cast<float2 *>(smem);
+    unsigned *cnt16 = reinterpret_cast<unsigned *>(smem + 8 * p.NP);
+    unsigned short *nextb = reinterpret_cast<unsigned short *>(smem + 10 * p.NP);
+    unsigned short *cellOf = nextb + p.NP;
+    unsigned short *head = cellOf + p.NP;
+    const size_t o = (size_t)e * N;
+    for (int c = tid; c < p.ncell; c += nt) head[c] = EMPTY16;
+    for (int b = tid; b < p.NP / 2; b += nt) cnt16[b] = 0;
+    __syncthreads();
+    for (int b = tid; b < N; b += nt) {
+        const float bx = p.buf.x[o + b], by = p.buf.y[o + b];
+        pos[b].x = bx; pos[b].y = by;
+        int cx = (int)floorf((bx - p.xmin) * p.inv_cell);
+        int cy = (int)floorf((by - p.ymin) * p.inv_cell);
+        cx = cx < 0 ? 0 : (cx >= p.gw ? p.gw - 1 : cx);
+        cy = cy < 0 ? 0 : (cy >= p.gh ? p.gh - 1 : cy);
+        const int cell = cy * p.gw + cx;
+        cellOf[b] = (unsigned short)cell;
+        nextb[b] = (unsigned short)kb_exch16(head, cell, (unsigned)b);
+    }
+    __syncthreads();
+    kb_sense_pass(pos, head, nextb, cellOf, cnt16, N, nt, tid, p.gw, p.gh, s, R2);
+    __syncthreads();
+    for (int b = tid; b < N; b += nt) out[o + b] = (unsigned)reinterpret_cast<unsigned short *>(cnt16)[b];
+}
+
+// KilobotsEnv.reset spawn (kb_reset): one thread per kilobot, Philox4x32-10 keyed by the seed, counter (global env, bot)
+struct ResetArgs {
+    unsigned k0, k1;
+    int env_offset, random_theta, random_velocity;
+    float mean_x, mean_y, std, lo_x, lo_y, hi_x, hi_y;
+};
+__global__ void kb_reset_kernel(const Params p, const ResetArgs a) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t T = (size_t)p.E * p.N;
+    if (i >= T) return;
+    const int e = (int)(i / p.N), b = (int)(i % p.N);
+    U4 c;
+    c.x = (unsigned)(a.env_offset + e); c.y = (unsigned)b; c.z = 0u; c.w = 0u;
+    const U4 r = kb_philox4x32_10(c, a.k0, a.k1);
+    // Box-Muller on u1 in (0, 1], u2 in [0, 1)
+    const float u1 = (float)((r.x >> 8) + 1u) * (1.0f / 16777216.0f);
+    const float u2 = (float)(r.y >> 8) * (1.0f / 16777216.0f);
+    const float rad = sqrtf(-2.0f * kb_logf(u1));
+    float sn, cs;
+    kb_sincosf(6.28318530717958647692f * u2, sn, cs);
+    float xm = a.mean_x + a.std * (rad * cs), ym = a.mean_y + a.std * (rad * sn);
+    xm = fminf(fmaxf(xm, a.lo_x), a.hi_x); ym = fminf(fmaxf(ym, a.lo_y), a.hi_y);   // yaml_kilobots_env.py:350-351
+    p.buf.x[i] = xm * WORLD_SCALE; p.buf.y[i] = ym * WORLD_SCALE;
+    float th = 0.0f;                                                                   // body.py:28-29
+    if (a.random_theta) th = ((float)(r.z >> 8) * (1.0f / 16777216.0f) * 2.0f - 1.0f) * 3.14159265358979323846f;
+    p.buf.theta[i] = th;
+    p.buf.ws_cnt[i] = 0;
+    if (p.drive_mode == KB_DRIVE_VELOCITY || p.drive_mode == KB_DRIVE_ACCEL) {
+        float v = 0.0f, w = 0.0f;
+        if (a.random_velocity) {                                                       // kilobot.py:225-229
+            v = (float)(r.w & 0xFFFFu) * (1.0f / 65536.0f) * 0.01f;
+            w = ((float)(r.w >> 16) * (1.0f / 65536.0f) * 2.0f - 1.0f) * (0.5f * 3.14159265358979323846f);
+        }
+        p.buf.v[i] = v; p.buf.w[i] = w;
+    }
+    if (p.drive_mode == KB_DRIVE_ACCEL) { p.buf.acc_v[i] = 0.0f; p.buf.acc_w[i] = 0.0f; }
+    if (p.drive_mode == KB_DRIVE_MOTORS || p.drive_mode == KB_DRIVE_PHOTOTAXIS) { p.buf.motor_l[i] = 255; p.buf.motor_r[i] = 0; }   // turn_left
+    if (p.drive_mode == KB_DRIVE_PHOTOTAXIS) {
+        p.buf.pt_threshold[i] = -INFINITY; p.buf.pt_update[i] = 0; p.buf.pt_nochange[i] = 0; p.buf.pt_dir[i] = 0;
+    }
+    if (b == 0) p.buf.status[e] = 0;
+    if (p.M > 0) {      // forget the objects' manifold impulses as well
+        float *ows = p.buf.ows_acc + (size_t)e * (MAXOBJ * KB_OWS_COLS * KB_OWS_WORDS);
+        for (int k = b; k < MAXOBJ * KB_OWS_COLS * KB_OWS_WORDS; k += p.N) ows[k] = -1.0f;
+    }
+}
+
 thread_local char g_err[512] = "";
+
+float kb_clampf_host(float a, float lo, float hi) { return fmaxf(lo, fminf(a, hi)); }
+// reach of the sensing stencil in cells: cell indices are monotone in the coordinate, and two kilobots within Rw differ
+// by at most floor(Rw / cell) + 1 cells (the small margin covers the rounding of the cell computation)
+int sense_reach(float Rw, float inv_cell) { return (int)floorf(Rw * inv_cell + 1e-3f) + 1; }
 
 int fail(int code, const char *fmt, const char *detail = "") {
     snprintf(g_err, sizeof(g_err), fmt, detail);
@@ -151,6 +234,9 @@ int kb_create(const kb_config *cfg, kb_sim **out) {
         return fail(KB_EINVAL, "kb_create: phototaxis drive modes need a light");
     if (cfg->ws_slots < 1 || cfg->ws_slots > 64) return fail(KB_EINVAL, "kb_create: 1 <= ws_slots <= 64 required");
     if (cfg->solver_mode < 0 || cfg->solver_mode > 4) return fail(KB_EINVAL, "kb_create: solver_mode must be 0..4");
+    if (cfg->damping_model != KB_DAMPING_PADE && cfg->damping_model != KB_DAMPING_LINEAR) return fail(KB_EINVAL, "kb_create: damping_model must be KB_DAMPING_PADE or KB_DAMPING_LINEAR");
+    if (!(cfg->sense_radius >= 0.0f)) return fail(KB_EINVAL, "kb_create: sense_radius must be >= 0");
+    if (cfg->contact_capacity < 0 || cfg->contact_capacity > 65528) return fail(KB_EINVAL, "kb_create: 0 <= contact_capacity <= 65528 required");
     if (!(cfg->dt > 0.0f) || cfg->vel_iters < 0 || cfg->pos_iters < 0 || !(cfg->world_width > 0.0f) ||
         !(cfg->world_height > 0.0f) || !(cfg->bot_radius > 0.0f) || !(cfg->bot_density > 0.0f))
         return fail(KB_EINVAL, "kb_create: non-positive dt / size / radius / density");
@@ -181,8 +267,13 @@ int kb_create(const kb_config *cfg, kb_sim **out) {
     p.r_bot = cfg->bot_radius * WORLD_SCALE;
     const float m = cfg->bot_density * B2_PI * p.r_bot * p.r_bot;  // b2CircleShape::ComputeMass
     p.im_bot = m > 0.0f ? 1.0f / m : 0.0f;
-    p.kl_bot = 1.0f / (1.0f + p.h * cfg->bot_linear_damping);
-    p.ka_bot = 1.0f / (1.0f + p.h * cfg->bot_angular_damping);
+    // b2Island::Solve damping factor per step: Pade (Box2D >= 2.3.1) or the older clamped linear form
+    auto damp = [&](float c) -> float {
+        if (cfg->damping_model == KB_DAMPING_LINEAR) return kb_clampf_host(1.0f - p.h * c, 0.0f, 1.0f);
+        return 1.0f / (1.0f + p.h * c);
+    };
+    p.kl_bot = damp(cfg->bot_linear_damping);
+    p.ka_bot = damp(cfg->bot_angular_damping);
     p.light_radius = cfg->light_radius;
     p.lcount = cfg->light_type == KB_LIGHT_COMPOSITE ? cfg->light_count : 1;
     p.ladim = cfg->light_type == KB_LIGHT_NONE ? 0 : (cfg->light_type == KB_LIGHT_GRADIENT ? 1 : 2 * p.lcount);
@@ -206,6 +297,7 @@ int kb_create(const kb_config *cfg, kb_sim **out) {
     if (cap > 2304) cap = 2304;
     if (cap < 4L * p.N + 64) cap = 4L * p.N + 64;
     cap += 40L * cfg->num_objects;
+    if (cfg->contact_capacity > 0) cap = cfg->contact_capacity;
     cap = (cap + 7) & ~7L;
     p.cap = (int)cap;
     // with objects the LDS staging area gives up a few entries to the manifold-constraint records, so that two envs
@@ -290,8 +382,14 @@ int kb_create(const kb_config *cfg, kb_sim **out) {
     p.mu_oo = sqrtf(cfg->obj_friction * cfg->obj_friction);
     p.mu_ow = sqrtf(cfg->obj_friction * cfg->wall_friction);
     p.nmc = mc_candidates(p.F);
-    p.kl_obj = 1.0f / (1.0f + p.h * cfg->obj_linear_damping);
-    p.ka_obj = 1.0f / (1.0f + p.h * cfg->obj_angular_damping);
+    p.kl_obj = damp(cfg->obj_linear_damping);
+    p.ka_obj = damp(cfg->obj_angular_damping);
+    p.sense_s = 0; p.sense_r2 = 0.0f;
+    if (cfg->sense_radius > 0.0f) {
+        const float Rw = cfg->sense_radius * WORLD_SCALE;
+        p.sense_s = sense_reach(Rw, p.inv_cell);
+        p.sense_r2 = Rw * Rw;
+    }
     p.solver_mode = cfg->solver_mode;
     p.toi_walls = cfg->toi_walls;
     if (p.N > BPT * 64 * MAX_WAVES) { delete s; return fail(KB_EINVAL, "kb_create: num_bots exceeds bots-per-thread x workgroup size of this build"); }
@@ -353,6 +451,7 @@ int kb_bind(kb_sim *sim, const kb_buffers *b) {
         return fail(KB_EINVAL, "kb_bind: light_value, light_gx, light_gy must be given together");
     if ((b->cmd_vx != nullptr) != (b->cmd_vy != nullptr) || (b->cmd_vx != nullptr) != (b->cmd_w != nullptr))
         return fail(KB_EINVAL, "kb_bind: cmd_vx, cmd_vy, cmd_w must be given together");
+    if (sim->cfg.sense_radius > 0.0f && !b->nbr_count) return fail(KB_ENOTBOUND, "kb_bind: nbr_count is required when sense_radius > 0");
     sim->p.buf = *b;
     sim->bound = true;
     return KB_OK;
@@ -419,6 +518,39 @@ int kb_step(kb_sim *sim, const float *d_actions, const float *d_light_action, in
                        (hipStream_t)stream, p);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return fail(KB_EHIP, "kb_step: %s", hipGetErrorString(err));
+    return KB_OK;
+}
+
+int kb_sense(kb_sim *sim, float radius_m, uint32_t *d_count, void *stream) {
+    if (!sim || !d_count) return fail(KB_EINVAL, "kb_sense: NULL argument");
+    if (!sim->bound) return fail(KB_ENOTBOUND, "kb_sense: kb_bind() first");
+    if (!(radius_m > 0.0f)) return fail(KB_EINVAL, "kb_sense: radius must be positive");
+    const Params &p = sim->p;
+    const float Rw = radius_m * WORLD_SCALE;
+    const size_t lds = (size_t)14 * p.NP + 2 * (size_t)p.ncell + 16;
+    hipLaunchKernelGGL(kb_sense_kernel, dim3((unsigned)p.E), dim3(256), lds, (hipStream_t)stream, p, sense_reach(Rw, p.inv_cell), Rw * Rw, d_count);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return fail(KB_EHIP, "kb_sense: %s", hipGetErrorString(err));
+    return KB_OK;
+}
+
+int kb_reset(kb_sim *sim, const kb_reset_params *rp, void *stream) {
+    if (!sim || !rp) return fail(KB_EINVAL, "kb_reset: NULL argument");
+    if (!sim->bound) return fail(KB_ENOTBOUND, "kb_reset: kb_bind() first");
+    if (!(rp->std >= 0.0f)) return fail(KB_EINVAL, "kb_reset: std must be >= 0");
+    const Params &p = sim->p;
+    ResetArgs a;
+    a.k0 = (unsigned)(rp->seed & 0xFFFFFFFFull); a.k1 = (unsigned)(rp->seed >> 32);
+    a.env_offset = rp->env_offset; a.random_theta = rp->random_theta; a.random_velocity = rp->random_velocity;
+    a.mean_x = rp->mean[0]; a.mean_y = rp->mean[1]; a.std = rp->std;
+    // world_bounds -/+ 0.02 (yaml_kilobots_env.py:350-351), metres
+    a.lo_x = -0.5f * sim->cfg.world_width + 0.02f; a.hi_x = 0.5f * sim->cfg.world_width - 0.02f;
+    a.lo_y = -0.5f * sim->cfg.world_height + 0.02f; a.hi_y = 0.5f * sim->cfg.world_height - 0.02f;
+    const size_t T = (size_t)p.E * p.N;
+    hipLaunchKernelGGL(kb_reset_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, a);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return fail(KB_EHIP, "kb_reset: %s", hipGetErrorString(err));
+    if (rp->resolve) return kb_step(sim, nullptr, nullptr, 1, KB_STEP_NO_DRIVE, stream);
     return KB_OK;
 }
 

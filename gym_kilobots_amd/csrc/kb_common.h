@@ -133,6 +133,8 @@ struct Params {
     float mu_oo, mu_ow;                       // b2MixFriction: object-object, object-wall
     int nmc;                                  // manifold-constraint candidates: pairs + 4 walls per object
     int lds_total;
+    int sense_s;                              // IR neighbour sensing: reach of the stencil in cells (0 = off)
+    float sense_r2;                           // ... and the squared radius in world units
 };
 
 
@@ -364,6 +366,79 @@ __device__ __forceinline__ unsigned kb_exch16(unsigned short *base, int idx, uns
         old = seen;
     }
     return (old >> sh) & 0xFFFFu;
+}
+
+// IR-range neighbour sensing off the cell lists of the broadphase: kilobot a walks the half stencil of reach s
+// (own cell: partners with a higher id; the cells to the east in its row; every cell of the s rows above), so that every
+// pair is met exactly once, and both ends of a pair within range are counted.  cnt16: u16 counters packed in pairs
+// (LDS atomics are 32-bit; a count is at most N - 1 < 65536, so no carry crosses the halves); zeroed by the caller.
+// Out of line: the kernels that never sense do not pay registers for it.
+__device__ __noinline__ void kb_sense_pass(const float2 *pos, const unsigned short *head, const unsigned short *nextb,
+                                           const unsigned short *cellOf, unsigned *cnt16, int N, int nt, int tid,
+                                           int gw, int gh, int s, float R2) {
+    for (int a = tid; a < N; a += nt) {
+        const int cell = cellOf[a];
+        const int cx = cell % gw, cy = cell / gw;
+        const float2 pa = pos[a];
+        unsigned mine = 0;
+        for (int dy = 0; dy <= s; ++dy) {
+            const int oy = cy + dy;
+            if (oy >= gh) break;
+            for (int dx = (dy == 0 ? 0 : -s); dx <= s; ++dx) {
+                const int ox = cx + dx;
+                if (ox < 0 || ox >= gw) continue;
+                const bool own = dy == 0 && dx == 0;
+                for (unsigned b = head[oy * gw + ox]; b != (unsigned)EMPTY16;) {
+                    const float2 pb = pos[b];
+                    const unsigned nb = nextb[b];
+                    if (!(own && (int)b <= a)) {
+                        const float ex = pb.x - pa.x, ey = pb.y - pa.y;
+                        const float dd = ex * ex + ey * ey;
+                        if (!(dd > R2)) {
+                            mine++;
+                            atomicAdd(&cnt16[b >> 1], 1u << (16 * (b & 1u)));
+                        }
+                    }
+                    b = nb;
+                }
+            }
+        }
+        if (mine) atomicAdd(&cnt16[a >> 1], mine << (16 * (a & 1)));
+    }
+}
+
+// ---- counter-based random numbers for kb_reset: Philox4x32-10 (Salmon et al., SC'11), Cephes logf ------------------
+struct U4 { unsigned x, y, z, w; };
+__host__ __device__ inline unsigned kb_mulhi32(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * (unsigned long long)b) >> 32); }
+__host__ __device__ inline U4 kb_philox4x32_10(U4 c, unsigned k0, unsigned k1) {
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = kb_mulhi32(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const unsigned hi1 = kb_mulhi32(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        U4 n;
+        n.x = hi1 ^ c.y ^ k0; n.y = lo1; n.z = hi0 ^ c.w ^ k1; n.w = lo0;
+        c = n;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+// natural logarithm of a positive normal float: Cephes single-precision algorithm (frexp by bit manipulation, degree-8
+// minimax polynomial); own implementation so that the device and the oracle give the same bits.
+__device__ __forceinline__ float kb_logf(float xx) {
+    unsigned bits = __float_as_uint(xx);
+    int e = (int)((bits >> 23) & 255u) - 126;
+    float x = __uint_as_float((bits & 0x807FFFFFu) | 0x3F000000u);     // mantissa in [0.5, 1)
+    if (x < 0.707106781186547524f) { e -= 1; x = x + x - 1.0f; }
+    else x = x - 1.0f;
+    float z = x * x;
+    float y = ((((((((7.0376836292E-2f * x - 1.1514610310E-1f) * x + 1.1676998740E-1f) * x - 1.2420140846E-1f) * x
+                  + 1.4249322787E-1f) * x - 1.6668057665E-1f) * x + 2.0000714765E-1f) * x - 2.4999993993E-1f) * x
+               + 3.3333331174E-1f) * x * z;
+    const float fe = (float)e;
+    if (e) y += -2.12194440e-4f * fe;
+    y += -0.5f * z;
+    z = x + y;
+    if (e) z += 0.693359375f * fe;
+    return z;
 }
 
 __device__ __forceinline__ int dir_dx(int k) { return (k == 1 || k == 3) ? 1 : (k == 4 ? -1 : 0); }

@@ -333,6 +333,7 @@ __global__ void __launch_bounds__(WIDE ? 64 : 64 * KB_MAX_WAVES, WIDE ? 2 : KB_M
             const int cell = cy * p.gw + cx;
             cellOf[b] = (unsigned short)cell;
             nextb[b] = (unsigned short)kb_exch16(head, cell, (unsigned)b);
+            if (p.sense_s > 0) newOff[b] = 0;       // (dead until the scan behind the label pass: the neighbour counters of the sensing pass)
         }
         if (tid < M) { start[N + tid].x = pos[N + tid].x; start[N + tid].y = pos[N + tid].y; objA0[tid] = objA[tid]; }
         if (tid < M) {   // b2Island::Solve damping of the objects; they keep their velocity between substeps
@@ -345,6 +346,10 @@ __global__ void __launch_bounds__(WIDE ? 64 : 64 * KB_MAX_WAVES, WIDE ? 2 : KB_M
         KB_STAMP_PRE(16);
         __syncthreads();
         KB_STAMP(0);
+        // ---- IR-range neighbour sensing (kb_config.sense_radius): at the sensing point of the substep, like the light
+        //      (kilobots_env.py:174-180), off the cell lists that the contact search uses ----
+        if (p.sense_s > 0 && drive)
+            kb_sense_pass(pos, head, nextb, cellOf, reinterpret_cast<unsigned *>(newOff), N, nt, tid, p.gw, p.gh, p.sense_s, p.sense_r2);
         // object-object / object-wall manifolds (b2Contact::Update) + their velocity-constraint set-up: candidate t
         // is lane t of wave 0; the record lives in LDS, the previous substep's impulses come from g.ows_acc
         if (OBJ && wave == 0) {
@@ -465,7 +470,9 @@ __global__ void __launch_bounds__(WIDE ? 64 : 64 * KB_MAX_WAVES, WIDE ? 2 : KB_M
             } else {
                 const unsigned key32 = key16 >= (unsigned)WALL_CODE ? KEY_WALL + (key16 - WALL_CODE)
                                      : (key16 >= (unsigned)OBJ_CODE ? KEY_OBJ + (key16 - OBJ_CODE) : key16);
-                for (int s = 0; s < cnt; ++s)
+                // (entries behind the contact capacity were never stored: an env that overflowed lists more per-bot
+                //  entries than its slice holds, and the next env's slice starts right behind it)
+                for (int s = 0; s < cnt && off + s < p.cap; ++s)
                     if (g.ws_key[wo + off + s] == key32) return g.ws_acc[wo + off + s];
             }
             return -1.0f;   // accumulated impulses are >= 0
@@ -598,6 +605,7 @@ __global__ void __launch_bounds__(WIDE ? 64 : 64 * KB_MAX_WAVES, WIDE ? 2 : KB_M
             islWave[b] = (unsigned char)((unsigned)b % (unsigned)nw);
             head[cellOf[b]] = EMPTY16;
             active[b] = 1; active[NB + b] = 0;
+            if (p.sense_s > 0 && drive) g.nbr_count[o + b] = (unsigned)newOff[b];
         }
         if (tid < 64) bkStart[tid] = 0;     // size-class counters of the island placement
         if (tid < 32) bkFill[tid] = 0;

@@ -60,7 +60,12 @@ class KilobotsEnv(object):
                             np.array([cls.world_width / 2, cls.world_height / 2]))
         return super(KilobotsEnv, cls).__new__(cls)
 
-    def __init__(self, num_envs=1, device=None, sim_factory=None, **kwargs):
+    def __init__(self, num_envs=1, device=None, sim_factory=None, on_status='raise', **kwargs):
+        # on_status: what reset() / step() do when the device step reports a capacity overflow (dropped contacts, lost
+        # warm-start impulses, staging limits: include/kilobots_hip.h, kb_buffers.status): 'raise' | 'warn' | 'ignore'
+        if on_status not in ('raise', 'warn', 'ignore'):
+            raise ValueError("on_status must be 'raise', 'warn' or 'ignore'")
+        self._on_status = on_status
         self.__sim_steps = 0
         self.__reset_counter = 0
         self.__seed = 0
@@ -229,6 +234,7 @@ class KilobotsEnv(object):
         for k in kbs:
             if not isinstance(k, Kilobot):
                 raise TypeError('kilobots must derive from gym_kilobots_amd.lib.Kilobot')
+            k._assert_device_law()
         mode = kinds.pop()
         light_type = nat.LIGHT_NONE
         overrides = dict(world_width=self.world_width, world_height=self.world_height, dt=self.sim_step,
@@ -343,7 +349,22 @@ class KilobotsEnv(object):
         self._upload_scene()
         # step to resolve (kilobots_env.py:156-157): one world.Step with the bodies at rest
         self._step_world()
+        self._check_status('reset()')
         return self.get_observation()
+
+    def _check_status(self, where):
+        """Capacity overflows of the device step are never silent: raise / warn with the decoded bits."""
+        if self._on_status == 'ignore' or self._sim is None:
+            return
+        bits = self._sim.status_bits()
+        if not bits:
+            return
+        msg = '%s: device step status 0x%x: %s' % (where, bits, nat.describe_status(bits))
+        if self._on_status == 'raise':
+            raise nat.KilobotsStatusError(msg)
+        import warnings
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)
+        self._sim.status.zero_()          # warn once per occurrence
 
     def _light_action_tensor(self, action):
         adim = self._light.action_space.shape[0]
@@ -367,6 +388,7 @@ class KilobotsEnv(object):
         self.world.touch()
         self.__sim_steps += self.__steps_per_action
         next_state = self.get_state()
+        self._check_status('step()')
         observation = self.get_observation()
         reward = self.get_reward(state, action, next_state)
         done = self.has_finished(next_state, action)

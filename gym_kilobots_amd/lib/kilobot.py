@@ -85,6 +85,23 @@ class Kilobot(Circle):
     def step(self, time_step):
         raise NotImplementedError('kilobots are stepped in bulk by the env (one HIP launch per substep batch)')
 
+    def _assert_device_law(self):
+        """The reference's extension point is a user subclass overriding _loop / _setup / step (kilobot.py:86-88,164-168):
+        Python run per kilobot per substep.  The device step only knows the five drive laws of the reference; a subclass
+        that programs its own behaviour would silently not run, so it is refused when the scene is uploaded."""
+        cls = type(self)
+        for name in ('_loop', 'step'):
+            impl = getattr(cls, name)
+            owner = next(c for c in cls.__mro__ if name in c.__dict__)
+            noop = name == '_loop' and getattr(impl, '__code__', None) is not None and \
+                impl.__code__.co_code == MotorKilobot._loop.__code__.co_code and not impl.__code__.co_names
+            if owner.__module__ != __name__ and not noop:
+                raise NotImplementedError(
+                    '%s.%s is user code: per-kilobot Python (%s) does not run on the device. The HIP step implements the drive laws '
+                    'of Kilobot (motors), SimplePhototaxisKilobot, SimpleVelocityControlKilobot, SimpleAccelerationControlKilobot '
+                    'and PhototaxisKilobot; derive from one of them without overriding %s, or drive the swarm through '
+                    'set_motors / set_action between env.step calls.' % (cls.__name__, name, impl.__qualname__, name))
+
     @classmethod
     def get_radius(cls):
         return cls._radius

@@ -9,6 +9,7 @@ import numpy as np
 import torch
 
 from . import _native as nat
+from ._native import STATUS_BITS, KilobotsStatusError, describe_status  # noqa: F401
 from ._native import (DRIVE_VELOCITY, DRIVE_ACCEL, DRIVE_MOTORS, DRIVE_SIMPLE_PHOTOTAXIS,  # noqa: F401
                       DRIVE_PHOTOTAXIS, LIGHT_NONE, LIGHT_CIRCULAR, STEP_NO_DRIVE, WORLD_SCALE)
 
@@ -28,6 +29,8 @@ class KilobotSim:
             raise nat.KilobotsHipError('KilobotSim needs a ROCm GPU (torch.cuda.is_available() is False); '
                                        'there is no CPU fallback')
         self.device = torch.device(device if device is not None else 'cuda:%d' % torch.cuda.current_device())
+        if self.device.index is None:
+            self.device = torch.device('cuda:%d' % torch.cuda.current_device())
         self.cfg = nat.default_config(num_envs, num_bots, drive_mode, light_type, **cfg_overrides)
         self.num_envs, self.num_bots = num_envs, num_bots
         self.drive_mode, self.light_type = drive_mode, light_type
@@ -71,6 +74,10 @@ class KilobotSim:
             self.ox, self.oy, self.otheta = f(E, M), f(E, M), f(E, M)
             self.ovx, self.ovy, self.ow = f(E, M), f(E, M), f(E, M)
             self.ows_acc = torch.full((E, nat.MAX_OBJECTS, nat.OWS_COLS, nat.OWS_WORDS), -1.0, dtype=torch.float32, device=dev)
+        # IR-range neighbour sensing (kb_config.sense_radius): counts of the last substep's sensing point
+        self.nbr_count = None
+        if self.cfg.sense_radius > 0.0:
+            self.nbr_count = torch.zeros(E, N, dtype=torch.int32, device=dev)
         self.light_value = self.light_gx = self.light_gy = None
         self.cmd_vx = self.cmd_vy = self.cmd_w = None
         if debug_outputs:
@@ -154,25 +161,69 @@ class KilobotSim:
     def poses(self):
         """[num_envs, num_bots, 3] float32 (x [m], y [m], theta): get_state()['kilobots'] of every env."""
         out = torch.empty(self.num_envs, self.num_bots, 3, dtype=torch.float32, device=self.device)
-        nat.check(self._lib.kb_get_poses(self._h, C.c_void_p(out.data_ptr()), self._stream()), 'kb_get_poses')
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.kb_get_poses(self._h, C.c_void_p(out.data_ptr()), self._stream()), 'kb_get_poses')
         return out
 
+    def status_bits(self):
+        """OR of the status flags of all envs (one device read; synchronises the stream)."""
+        s = self.status
+        return int(sum(b for b in STATUS_BITS if bool((s & b).any().item())))
+
+    def check_status(self, mode='raise', where=''):
+        """Surface capacity overflows of the device step: mode 'raise' | 'warn' | 'ignore'.  Returns the bits."""
+        if mode == 'ignore':
+            return 0
+        bits = self.status_bits()
+        if bits:
+            bad = int((self.status != 0).sum().item())
+            msg = '%sdevice step status 0x%x in %d of %d envs: %s' % (where and where + ': ', bits, bad, self.num_envs, describe_status(bits))
+            if mode == 'raise':
+                raise KilobotsStatusError(msg)
+            import warnings
+            warnings.warn(msg, RuntimeWarning, stacklevel=3)
+        return bits
+
+    def sense(self, radius_m, out=None):
+        """IR-range neighbour sensing on the current poses: [num_envs, num_bots] int32 counts of the kilobots within
+        radius_m (centre to centre) of each kilobot (kb_sense; no reference counterpart)."""
+        if out is None:
+            out = torch.empty(self.num_envs, self.num_bots, dtype=torch.int32, device=self.device)
+        if not (out.is_cuda and out.dtype == torch.int32 and out.is_contiguous() and tuple(out.shape) == (self.num_envs, self.num_bots)):
+            raise ValueError('out must be a contiguous int32 cuda tensor of shape (num_envs, num_bots)')
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.kb_sense(self._h, float(radius_m), C.c_void_p(out.data_ptr()), self._stream()), 'kb_sense')
+        return out
+
+    def reset(self, seed=0, mean=(0.0, 0.0), std=0.1, random_theta=False, random_velocity=False, resolve=True, env_offset=0):
+        """KilobotsEnv.reset of every env on the device (kb_reset): Gaussian spawn clipped to the bounds -/+ 0.02 m
+        (yaml_kilobots_env.py:346-352), Philox4x32-10 keyed by (seed; env_offset + env, bot), then the step to resolve."""
+        rp = nat.KbResetParams()
+        rp.seed, rp.env_offset = int(seed) & 0xFFFFFFFFFFFFFFFF, int(env_offset)
+        rp.mean[0], rp.mean[1], rp.std = float(mean[0]), float(mean[1]), float(std)
+        rp.random_theta, rp.random_velocity, rp.resolve = int(bool(random_theta)), int(bool(random_velocity)), int(bool(resolve))
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.kb_reset(self._h, C.byref(rp), self._stream()), 'kb_reset')
+
     # ------------------------------------------------------------------ stepping
-    @staticmethod
-    def _ptr(t, shape, name):
+    def _ptr(self, t, shape, name):
         if t is None:
             return None
         if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == tuple(shape)):
             raise ValueError('%s must be a contiguous float32 cuda tensor of shape %s' % (name, tuple(shape)))
+        if t.device != self.device:
+            raise ValueError('%s lives on %s, the simulator on %s' % (name, t.device, self.device))
         return C.c_void_p(t.data_ptr())
 
     def set_actions(self, actions):
         """set_action of every kilobot (clamped); actions [E, N, 2] cuda float32 or None (= zeros)."""
         p = self._ptr(actions, (self.num_envs, self.num_bots, 2), 'actions')
-        nat.check(self._lib.kb_set_actions(self._h, p, self._stream()), 'kb_set_actions')
+        with torch.cuda.device(self.device):    # the launch goes to the CURRENT HIP device: make it the sim's
+            nat.check(self._lib.kb_set_actions(self._h, p, self._stream()), 'kb_set_actions')
 
     def step(self, n_substeps=1, actions=None, light_action=None, flags=0):
         """n_substeps iterations of the reference substep loop in one kernel launch (asynchronous)."""
         pa = self._ptr(actions, (self.num_envs, self.num_bots, 2), 'actions')
         pl = self._ptr(light_action, (self.num_envs, self._lib.kb_light_action_dim(self._h)), 'light_action')
-        nat.check(self._lib.kb_step(self._h, pa, pl, int(n_substeps), int(flags), self._stream()), 'kb_step')
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.kb_step(self._h, pa, pl, int(n_substeps), int(flags), self._stream()), 'kb_step')

@@ -117,7 +117,22 @@ typedef struct kb_config {
      * Body.get_pose (body.py:63-65), ovx / ovy the velocity of the centre of mass like b2Body::GetLinearVelocity. */
     int32_t num_fixtures;                       /* 0, or num_objects..KB_MAX_OBJECTS (at most 8 fixtures per env in total) */
     int32_t obj_fixture_body[KB_MAX_OBJECTS];
+    int32_t damping_model;                      /* [KB_DAMPING_PADE] how b2Island::Solve applies linearDamping / angularDamping
+                                                   (body.py:15-16,35-36): Box2D >= 2.3.1 `v *= 1 / (1 + h c)`, Box2D <= 2.3.0
+                                                   `v *= clamp(1 - h c, 0, 1)`.  The reference does not pin box2d-py (setup.py:5);
+                                                   INTEGRATION.md says how to tell which one an installed wheel uses. */
+    float sense_radius;                         /* metres, centre to centre; 0 = off.  IR-range neighbour sensing (no counterpart in
+                                                   the reference; nearest: Body.collides_with, body.py:87-90): at the sensing point
+                                                   of every substep (kilobots_env.py:174-180, before the drive law) kilobot i counts
+                                                   the kilobots j != i of its env with |p_j - p_i|^2 <= (25 R)^2 in fp32 world units;
+                                                   kb_buffers.nbr_count holds the counts of the last substep */
+    int32_t contact_capacity;                   /* [0] contacts (and warm-start entries) per env; 0 = the default rule
+                                                   max(4 N + 64, min(N (N - 1) / 2 + 4 N, 2304)) + 40 objects.  A spawn that
+                                                   overlaps more kilobots than that sets status bit 0; raise it (<= 65528) then:
+                                                   the entries live in HBM (24 B each), not in LDS */
 } kb_config;
+
+enum kb_damping_model { KB_DAMPING_PADE = 0, KB_DAMPING_LINEAR = 1 };
 
 /* Device buffers of one handle.  NULL is allowed for buffers the configuration never touches
  * (noted per field).  Replaces the per-object state of the reference: b2Body position/angle
@@ -152,6 +167,7 @@ typedef struct kb_buffers {
                                            object-object (column = higher partner) and object-wall (column 8 + wall)
                                            contacts: b2ManifoldPoint id / normalImpulse / tangentImpulse; fill with -1
                                            to forget them */
+    uint32_t *nbr_count;                /* sense_radius > 0: [num_envs][num_bots] neighbours within IR range (output; required then) */
 } kb_buffers;
 
 typedef struct kb_sim kb_sim;
@@ -176,6 +192,34 @@ int kb_set_actions(kb_sim *sim, const float *d_actions, void *stream);
  * NULL = action None. */
 int kb_step(kb_sim *sim, const float *d_actions, const float *d_light_action, int n_substeps, int flags,
             void *stream);
+
+/* IR-range neighbour sensing on the CURRENT poses, without stepping (e.g. right after a reset): d_count
+ * [num_envs][num_bots] uint32 = number of kilobots j != i of the same env with |p_j - p_i|^2 <= (25 radius_m)^2.
+ * The same predicate kb_step evaluates at the sensing point of every substep when kb_config.sense_radius > 0.
+ * No reference counterpart (the reference has no neighbour sensing; nearest: Body.collides_with, body.py:87-90). */
+int kb_sense(kb_sim *sim, float radius_m, uint32_t *d_count, void *stream);
+
+/* KilobotsEnv.reset() for every env of the handle, on the device (kilobots_env.py:150-159 with the spawn rule of
+ * YamlKilobotsEnv._init_kilobots, yaml_kilobots_env.py:346-352): positions ~ N(mean, std) per coordinate, clipped to
+ * the world bounds -/+ 0.02 m, theta = 0 (body.py:28-29) or U(-pi, pi); commands and accelerations zeroed
+ * (random_velocity: the U([0, 0.01] x [-pi/2, pi/2]) initial command of kilobot.py:225-229); motors as after
+ * Kilobot._setup -> turn_left; phototaxis counters cleared; warm-start impulses forgotten; status cleared.  Object
+ * and light state is not touched.  resolve != 0 appends the "step to resolve" of kilobots_env.py:156-157 (one world.Step
+ * with the kilobots at rest).
+ * Random numbers: Philox4x32-10, key = seed (lo, hi), counter = (env_offset + env, bot, 0, 0); the four outputs give the
+ * two Box-Muller normals, the heading and the command.  A shard created with env_offset = its first global env index
+ * reproduces the corresponding rows of the unsharded reset bit for bit (the reference itself is not reproducible:
+ * seed() only stores the number, kilobots_env.py:145-148). */
+typedef struct kb_reset_params {
+    uint64_t seed;
+    int32_t env_offset;
+    float mean[2];          /* metres */
+    float std;              /* metres */
+    int32_t random_theta;
+    int32_t random_velocity;
+    int32_t resolve;
+} kb_reset_params;
+int kb_reset(kb_sim *sim, const kb_reset_params *rp, void *stream);
 
 /* KilobotsEnv.get_state()['kilobots'] (kilobots_env.py:115-118 -> body.py:63-72):
  * d_out [num_envs][num_bots][3] = (x [m], y [m], theta). */

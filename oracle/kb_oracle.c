@@ -186,6 +186,11 @@ static void polygon_mass(const shape_t *sh, float density, float *mass, v2 *cent
     *mass = m; *centroid = c; *inertia = Io;
 }
 
+static float damping_factor(int model, float h, float c) {
+    if (model == 1) return clampf(1.0f - h * c, 0.0f, 1.0f);
+    return 1.0f / (1.0f + h * c);
+}
+
 static void derive(const kbo_config *c, derived_t *d) {
     float W = c->world_width * WORLD_SCALE, H = c->world_height * WORLD_SCALE;
     d->xmin = -0.5f * W; d->xmax = 0.5f * W; d->ymin = -0.5f * H; d->ymax = 0.5f * H;
@@ -205,8 +210,9 @@ static void derive(const kbo_config *c, derived_t *d) {
     /* b2CircleShape::ComputeMass: mass = density * pi * r^2 */
     float m = c->bot_density * B2_PI * d->r_bot * d->r_bot;
     d->im_bot = m > 0.0f ? 1.0f / m : 0.0f;
-    d->kl_bot = 1.0f / (1.0f + d->h * c->bot_linear_damping);
-    d->ka_bot = 1.0f / (1.0f + d->h * c->bot_angular_damping);
+    /* b2Island::Solve: `v *= 1.0f / (1.0f + h * damping)` since Box2D 2.3.1; `v *= b2Clamp(1.0f - h * damping, 0, 1)` before */
+    d->kl_bot = damping_factor(c->damping_model, d->h, c->bot_linear_damping);
+    d->ka_bot = damping_factor(c->damping_model, d->h, c->bot_angular_damping);
     d->nfix = c->num_fixtures > 0 ? c->num_fixtures : c->num_objects;
     float bm[KBO_MAX_OBJECTS], bi[KBO_MAX_OBJECTS];
     v2 bc[KBO_MAX_OBJECTS];
@@ -264,8 +270,8 @@ static void derive(const kbo_config *c, derived_t *d) {
     }
     d->mu_oo = sqrtf(c->obj_friction * c->obj_friction);
     d->mu_ow = sqrtf(c->obj_friction * c->wall_friction);
-    d->kl_obj = 1.0f / (1.0f + d->h * c->obj_linear_damping);
-    d->ka_obj = 1.0f / (1.0f + d->h * c->obj_angular_damping);
+    d->kl_obj = damping_factor(c->damping_model, d->h, c->obj_linear_damping);
+    d->ka_obj = damping_factor(c->damping_model, d->h, c->obj_angular_damping);
 }
 
 /* ---- light sensing: CircularGradientLight.value_and_gradients, light.py:176-189 ------------- */
@@ -460,7 +466,7 @@ static void uf_union(int *p, int a, int b) {
  * ws_cnt[owner] entries each; entry (owner, slot) sits at woff[owner] + slot */
 static float ws_lookup(const kbo_state *st, const work_t *w, int e, int owner, unsigned key) {
     int cnt = st->ws_cnt[(size_t)e * w->N + owner];
-    for (int s = 0; s < cnt; ++s) {
+    for (int s = 0; s < cnt && w->woff[owner] + s < w->cap; ++s) {   /* (entries behind the capacity were never stored) */
         size_t idx = (size_t)e * w->cap + (size_t)(w->woff[owner] + s);
         if (st->ws_key[idx] == key) return st->ws_acc[idx];
     }
@@ -1525,6 +1531,110 @@ static void world_step_env(const kbo_config *cfg, const derived_t *d, kbo_state 
 }
 
 /* one substep of the kilobots_env.py:168-190 loop for env e */
+/* neighbour counts of one env: all pairs, fp32 world units */
+static void sense_env(const float *x, const float *y, int N, float radius_m, uint32_t *out) {
+    const float Rw = radius_m * WORLD_SCALE, R2 = Rw * Rw;
+    for (int a = 0; a < N; ++a) {
+        uint32_t cnt = 0;
+        for (int b = 0; b < N; ++b) {
+            if (b == a) continue;
+            const float dx = x[b] - x[a], dy = y[b] - y[a];
+            const float dd = dx * dx + dy * dy;
+            if (!(dd > R2)) cnt++;
+        }
+        out[a] = cnt;
+    }
+}
+
+int kbo_sense(const kbo_config *cfg, const kbo_state *st, float radius_m, uint32_t *out) {
+    if (!cfg || !st || !out || !(radius_m > 0.0f)) return -1;
+    for (int e = 0; e < cfg->num_envs; ++e) {
+        const size_t o = (size_t)e * cfg->num_bots;
+        sense_env(st->x + o, st->y + o, cfg->num_bots, radius_m, out + o);
+    }
+    return 0;
+}
+
+/* ---- kb_reset: Philox4x32-10, Cephes logf, Box-Muller ------------------------------------------------------------ */
+void kbo_philox4x32_10(const uint32_t cin[4], const uint32_t kin[2], uint32_t out[4]) {
+    uint32_t c0 = cin[0], c1 = cin[1], c2 = cin[2], c3 = cin[3], k0 = kin[0], k1 = kin[1];
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* natural logarithm of a positive normal float, Cephes single-precision algorithm */
+float kbo_logf(float xx) {
+    uint32_t bits; memcpy(&bits, &xx, 4);
+    int e = (int)((bits >> 23) & 255u) - 126;
+    uint32_t mb = (bits & 0x807FFFFFu) | 0x3F000000u;
+    float x; memcpy(&x, &mb, 4);                                        /* mantissa in [0.5, 1) */
+    if (x < 0.707106781186547524f) { e -= 1; x = x + x - 1.0f; }
+    else x = x - 1.0f;
+    float z = x * x;
+    float y = ((((((((7.0376836292E-2f * x - 1.1514610310E-1f) * x + 1.1676998740E-1f) * x - 1.2420140846E-1f) * x
+                  + 1.4249322787E-1f) * x - 1.6668057665E-1f) * x + 2.0000714765E-1f) * x - 2.4999993993E-1f) * x
+               + 3.3333331174E-1f) * x * z;
+    const float fe = (float)e;
+    if (e) y += -2.12194440e-4f * fe;
+    y += -0.5f * z;
+    z = x + y;
+    if (e) z += 0.693359375f * fe;
+    return z;
+}
+
+int kbo_reset(const kbo_config *cfg, kbo_state *st, const kbo_reset_params *rp) {
+    if (!cfg || !st || !rp) return -1;
+    const int E = cfg->num_envs, N = cfg->num_bots;
+    const uint32_t key[2] = {(uint32_t)(rp->seed & 0xFFFFFFFFull), (uint32_t)(rp->seed >> 32)};
+    /* world_bounds -/+ 0.02 (yaml_kilobots_env.py:350-351), metres */
+    const float lo_x = -0.5f * cfg->world_width + 0.02f, hi_x = 0.5f * cfg->world_width - 0.02f;
+    const float lo_y = -0.5f * cfg->world_height + 0.02f, hi_y = 0.5f * cfg->world_height - 0.02f;
+    for (int e = 0; e < E; ++e) {
+        for (int b = 0; b < N; ++b) {
+            const size_t i = (size_t)e * N + b;
+            const uint32_t ctr[4] = {(uint32_t)(rp->env_offset + e), (uint32_t)b, 0u, 0u};
+            uint32_t r[4];
+            kbo_philox4x32_10(ctr, key, r);
+            const float u1 = (float)((r[0] >> 8) + 1u) * (1.0f / 16777216.0f);      /* (0, 1] */
+            const float u2 = (float)(r[1] >> 8) * (1.0f / 16777216.0f);             /* [0, 1) */
+            const float rad = sqrtf(-2.0f * kbo_logf(u1));
+            float sn, cs;
+            kbo_sincosf(6.28318530717958647692f * u2, &sn, &cs);
+            float xm = rp->mean[0] + rp->std * (rad * cs), ym = rp->mean[1] + rp->std * (rad * sn);
+            xm = fminf(fmaxf(xm, lo_x), hi_x); ym = fminf(fmaxf(ym, lo_y), hi_y);
+            st->x[i] = xm * WORLD_SCALE; st->y[i] = ym * WORLD_SCALE;
+            float th = 0.0f;                                                          /* body.py:28-29 */
+            if (rp->random_theta) th = ((float)(r[2] >> 8) * (1.0f / 16777216.0f) * 2.0f - 1.0f) * 3.14159265358979323846f;
+            st->theta[i] = th;
+            st->ws_cnt[i] = 0;
+            if (cfg->drive_mode == KBO_DRIVE_VELOCITY || cfg->drive_mode == KBO_DRIVE_ACCEL) {
+                float v = 0.0f, w = 0.0f;
+                if (rp->random_velocity) {                                            /* kilobot.py:225-229 */
+                    v = (float)(r[3] & 0xFFFFu) * (1.0f / 65536.0f) * 0.01f;
+                    w = ((float)(r[3] >> 16) * (1.0f / 65536.0f) * 2.0f - 1.0f) * (0.5f * 3.14159265358979323846f);
+                }
+                st->v[i] = v; st->w[i] = w;
+            }
+            if (cfg->drive_mode == KBO_DRIVE_ACCEL) { st->acc_v[i] = 0.0f; st->acc_w[i] = 0.0f; }
+            if (cfg->drive_mode == KBO_DRIVE_MOTORS || cfg->drive_mode == KBO_DRIVE_PHOTOTAXIS) { st->motor_l[i] = 255; st->motor_r[i] = 0; }
+            if (cfg->drive_mode == KBO_DRIVE_PHOTOTAXIS) {
+                st->pt_threshold[i] = -INFINITY; st->pt_update[i] = 0; st->pt_nochange[i] = 0; st->pt_dir[i] = 0;
+            }
+        }
+        if (st->status) st->status[e] = 0;
+        if (cfg->num_objects > 0 && st->ows_acc)
+            for (int k = 0; k < KBO_MAX_OBJECTS * KBO_OWS_COLS * KBO_OWS_WORDS; ++k)
+                st->ows_acc[(size_t)e * (KBO_MAX_OBJECTS * KBO_OWS_COLS * KBO_OWS_WORDS) + k] = -1.0f;
+    }
+    return 0;
+}
+
 static void substep_env(const kbo_config *cfg, const derived_t *d, kbo_state *st, const float *light_action,
                         int flags, int e, work_t *w) {
     const int N = w->N;
@@ -1533,6 +1643,9 @@ static void substep_env(const kbo_config *cfg, const derived_t *d, kbo_state *st
     /* light.step, kilobots_env.py:171-172 */
     if (light_action && cfg->light_type != KBO_LIGHT_NONE && !(flags & KBO_STEP_NO_DRIVE))
         light_step_env(cfg, st, e, light_action, h);
+    /* IR-range neighbour sensing at the sensing point of the substep (with the light: kilobots_env.py:174-180) */
+    if (st->nbr_count && cfg->sense_radius > 0.0f && !(flags & KBO_STEP_NO_DRIVE))
+        sense_env(st->x + o, st->y + o, N, cfg->sense_radius, st->nbr_count + o);
     for (int b = 0; b < N; ++b) {
         float th = st->theta[o + b];
         float bvx = 0.0f, bvy = 0.0f, bw = 0.0f;
@@ -1624,6 +1737,7 @@ static void substep_env(const kbo_config *cfg, const derived_t *d, kbo_state *st
 int kbo_contact_capacity(const kbo_config *cfg) {
     /* contact capacity per env (must equal the HIP kernel's, kb_contact_capacity) */
     long N = cfg->num_bots;
+    if (cfg->contact_capacity > 0) return (int)((cfg->contact_capacity + 7) & ~7);
     long cap = N * (N - 1) / 2 + 4L * N;
     if (cap > 2304) cap = 2304;
     if (cap < 4L * N + 64) cap = 4L * N + 64;

@@ -49,7 +49,13 @@ class Config(C.Structure):
         ('obj_verts', ((C.c_float * 2) * MAX_POLY_VERTS) * MAX_OBJECTS),
         ('wall_friction', C.c_float),
         ('num_fixtures', C.c_int32), ('obj_fixture_body', C.c_int32 * MAX_OBJECTS),
+        ('damping_model', C.c_int32), ('sense_radius', C.c_float), ('contact_capacity', C.c_int32),
     ]
+
+
+class ResetParams(C.Structure):
+    _fields_ = [('seed', C.c_uint64), ('env_offset', C.c_int32), ('mean', C.c_float * 2), ('std', C.c_float),
+                ('random_theta', C.c_int32), ('random_velocity', C.c_int32), ('resolve', C.c_int32)]
 
 
 _PF = C.POINTER(C.c_float)
@@ -70,6 +76,7 @@ class State(C.Structure):
         ('cmd_vx', _PF), ('cmd_vy', _PF), ('cmd_w', _PF),
         ('status', _PI32),
         ('ows_acc', _PF),
+        ('nbr_count', _PU32),
     ]
 
 
@@ -100,6 +107,14 @@ def lib():
         _lib.kbo_contact_capacity.restype = C.c_int
         _lib.kbo_sincosf.argtypes = [C.c_float, _PF, _PF]
         _lib.kbo_sincosf.restype = None
+        _lib.kbo_logf.argtypes = [C.c_float]
+        _lib.kbo_logf.restype = C.c_float
+        _lib.kbo_sense.argtypes = [C.POINTER(Config), C.POINTER(State), C.c_float, _PU32]
+        _lib.kbo_sense.restype = C.c_int
+        _lib.kbo_philox4x32_10.argtypes = [_PU32, _PU32, _PU32]
+        _lib.kbo_philox4x32_10.restype = None
+        _lib.kbo_reset.argtypes = [C.POINTER(Config), C.POINTER(State), C.POINTER(ResetParams)]
+        _lib.kbo_reset.restype = C.c_int
     return _lib
 
 
@@ -121,11 +136,14 @@ def default_config(num_envs, num_bots, drive_mode=DRIVE_VELOCITY, light_type=LIG
     c.light_act_lo[0] = c.light_act_lo[1] = -0.01
     c.light_act_hi[0] = c.light_act_hi[1] = 0.01
     c.light_max_velocity = np.inf
-    c.ws_slots = 8
+    c.ws_slots = 32     # contacts per kilobot whose impulse is carried over (Box2D keeps every b2Contact; 32 covers a dense overlapping spawn)
     c.obj_density, c.obj_friction = 2.0, 0.01
     c.obj_linear_damping = c.obj_angular_damping = 0.8
     c.toi_walls = 1      # b2World continuousPhysics defaults to true
     c.wall_friction = 0.2  # b2FixtureDef default (the arena chain, kilobots_env.py:46-51)
+    c.damping_model = 0    # Pade (Box2D >= 2.3.1)
+    c.sense_radius = 0.0
+    c.contact_capacity = 0
     c.light_count = 1
     for i in range(MAX_LIGHTS):
         c.light_kind[i] = LIGHT_CIRCULAR
@@ -186,6 +204,7 @@ class OracleSim:
         self.ox, self.oy, self.otheta = f(E, M), f(E, M), f(E, M)
         self.ovx, self.ovy, self.ow = f(E, M), f(E, M), f(E, M)
         self.ows_acc = np.full((E, MAX_OBJECTS, OWS_COLS, OWS_WORDS), -1.0, np.float32)
+        self.nbr_count = np.zeros((E, N), np.uint32)
         self._st = State()
         for name, _t in State._fields_:
             arr = getattr(self, name, None)
@@ -217,6 +236,24 @@ class OracleSim:
                            None if la is None else la.ctypes.data_as(_PF), n_substeps, flags, threads)
         assert r == 0, r
 
+    def sense(self, radius_m):
+        """Neighbour counts [E, N] (uint32) on the current poses: brute force over all pairs (kbo_sense)."""
+        out = np.zeros((self.cfg.num_envs, self.cfg.num_bots), np.uint32)
+        r = lib().kbo_sense(C.byref(self.cfg), C.byref(self._st), C.c_float(radius_m), out.ctypes.data_as(_PU32))
+        assert r == 0, r
+        return out
+
+    def reset(self, seed=0, mean=(0.0, 0.0), std=0.1, random_theta=False, random_velocity=False, resolve=True, env_offset=0):
+        """The specification of kb_reset: Philox-keyed Gaussian spawn + (resolve) one world step at rest."""
+        rp = ResetParams()
+        rp.seed, rp.env_offset = int(seed) & 0xFFFFFFFFFFFFFFFF, int(env_offset)
+        rp.mean[0], rp.mean[1], rp.std = float(mean[0]), float(mean[1]), float(std)
+        rp.random_theta, rp.random_velocity, rp.resolve = int(bool(random_theta)), int(bool(random_velocity)), int(bool(resolve))
+        r = lib().kbo_reset(C.byref(self.cfg), C.byref(self._st), C.byref(rp))
+        assert r == 0, r
+        if resolve:
+            self.step(1, flags=STEP_NO_DRIVE)
+
     def count_contacts(self, env=0, with_objects=False):
         nb, nw, no = C.c_int32(0), C.c_int32(0), C.c_int32(0)
         lib().kbo_count_contacts(C.byref(self.cfg), C.byref(self._st), env, C.byref(nb), C.byref(nw), C.byref(no))
@@ -236,6 +273,18 @@ class OracleSim:
     def objects_m(self):
         return np.stack([self.ox.astype(np.float64) / WORLD_SCALE, self.oy.astype(np.float64) / WORLD_SCALE,
                          self.otheta.astype(np.float64)], -1)
+
+
+def logf(x):
+    return float(lib().kbo_logf(C.c_float(x)))
+
+
+def philox4x32_10(counter, key):
+    c = (C.c_uint32 * 4)(*counter)
+    k = (C.c_uint32 * 2)(*key)
+    o = (C.c_uint32 * 4)()
+    lib().kbo_philox4x32_10(c, k, o)
+    return tuple(int(v) for v in o)
 
 
 def sincosf(x):

@@ -17,11 +17,24 @@ class OracleBackend:
         for name in ('x', 'y', 'theta', 'v', 'w', 'acc_v', 'acc_w', 'motor_l', 'motor_r', 'pt_threshold',
                      'pt_update', 'pt_nochange', 'pt_dir', 'light_x', 'light_y', 'light_vx', 'light_vy', 'ws_cnt', 'status',
                      'light_value', 'light_gx', 'light_gy', 'cmd_vx', 'cmd_vy', 'cmd_w',
-                     'ox', 'oy', 'otheta', 'ovx', 'ovy', 'ow'):
-            setattr(self, name, torch.from_numpy(getattr(self.o, name)))     # shares memory
+                     'ox', 'oy', 'otheta', 'ovx', 'ovy', 'ow', 'nbr_count'):
+            arr = getattr(self.o, name)
+            setattr(self, name, torch.from_numpy(arr.view(np.int32) if arr.dtype == np.uint32 else arr))     # shares memory
         if drive_mode not in (O.DRIVE_MOTORS, O.DRIVE_PHOTOTAXIS):
             self.motor_l = self.motor_r = None
+        if not self.cfg.sense_radius > 0.0:
+            self.nbr_count = None
         self.lds_bytes, self.block_threads = 0, 0
+        self.device = torch.device('cpu')
+
+    def sense(self, radius_m, out=None):
+        return torch.from_numpy(self.o.sense(radius_m).view(np.int32))
+
+    def reset(self, **kw):
+        self.o.reset(**kw)
+
+    def status_bits(self):
+        return int(np.bitwise_or.reduce(self.o.status)) if self.o.status.size else 0
 
     def set_poses_m(self, xy, th):
         self.o.set_poses_m(xy, th)

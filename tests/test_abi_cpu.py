@@ -27,11 +27,49 @@ def test_exports_every_declared_symbol(lib):
     assert lib.kb_version().startswith(b'kilobots_hip')
 
 
-def test_struct_sizes_match_header():
-    # 3 ints, 2+1 floats, 2 ints, 2 ints, 4+1 floats, 8 floats, 1 float, 1 int, 8 floats, 4 floats, 1 int
-    # ... + solver_mode, light_count, light_kind[4], 2 x [4], 4 x [4][2]
-    assert C.sizeof(nat.KbConfig) == 4 * (3 + 3 + 2 + 2 + 5 + 8 + 1 + 1 + 8 + 4 + 1 + 1 + 1 + 4 + 8 + 32 + 8 + 8 + 64 + 1 + 1 + 8)
-    assert C.sizeof(nat.KbBuffers) == 8 * len(nat.BUFFER_FIELDS)
+def test_struct_layouts_match_header(tmp_path):
+    """The ctypes mirrors (product binding and oracle binding) have the size and field offsets that a C compiler gives
+    the structs of include/kilobots_hip.h and oracle/kb_oracle.h."""
+    import subprocess
+    from oracle import oracle as O
+    fields_cfg = [n for n, _ in nat.KbConfig._fields_]
+    fields_buf = list(nat.BUFFER_FIELDS)
+    fields_rp = [n for n, _ in nat.KbResetParams._fields_]
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "kilobots_hip.h"', '#include "kb_oracle.h"', 'int main(void) {',
+           'printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(kb_config), sizeof(kb_buffers), sizeof(kb_reset_params), sizeof(kbo_config), sizeof(kbo_state), sizeof(kbo_reset_params));']
+    for f in fields_cfg:
+        src.append('printf("%%zu %%zu\\n", offsetof(kb_config, %s), offsetof(kbo_config, %s));' % (f, f))
+    for f in fields_buf:
+        src.append('printf("%%zu\\n", offsetof(kb_buffers, %s));' % f)
+    for f in fields_rp:
+        src.append('printf("%%zu %%zu\\n", offsetof(kb_reset_params, %s), offsetof(kbo_reset_params, %s));' % (f, f))
+    for f, _ in O.State._fields_:
+        src.append('printf("%%zu\\n", offsetof(kbo_state, %s));' % f)
+    src.append('return 0; }')
+    c = tmp_path / 'layout.c'
+    c.write_text('\n'.join(src))
+    exe = str(tmp_path / 'layout')
+    subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), '-I', os.path.join(ROOT, 'oracle'), str(c), '-o', exe])
+    out = subprocess.check_output([exe]).decode().split('\n')
+    sizes = [int(v) for v in out[0].split()]
+    assert sizes == [C.sizeof(nat.KbConfig), C.sizeof(nat.KbBuffers), C.sizeof(nat.KbResetParams),
+                     C.sizeof(O.Config), C.sizeof(O.State), C.sizeof(O.ResetParams)]
+    assert [n for n, _ in O.Config._fields_] == fields_cfg          # the two configs share one layout
+    k = 1
+    for f in fields_cfg:
+        a, b = (int(v) for v in out[k].split())
+        assert a == getattr(nat.KbConfig, f).offset and b == getattr(O.Config, f).offset and a == b, f
+        k += 1
+    for f in fields_buf:
+        assert int(out[k]) == getattr(nat.KbBuffers, f).offset, f
+        k += 1
+    for f in fields_rp:
+        a, b = (int(v) for v in out[k].split())
+        assert a == getattr(nat.KbResetParams, f).offset and b == getattr(O.ResetParams, f).offset, f
+        k += 1
+    for f, _ in O.State._fields_:
+        assert int(out[k]) == getattr(O.State, f).offset, f
+        k += 1
 
 
 def test_create_validates_and_reports(lib):
