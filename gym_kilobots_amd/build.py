@@ -44,6 +44,12 @@ def _compile(args):
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd, stderr=subprocess.DEVNULL if not verbose else None)
+    # of the saved temporaries only the device assembly is wanted (the rest is hundreds of MB that would travel with
+    # every gpurun snapshot)
+    stem = obj[:-2]
+    for f in glob.glob(stem + '-*') + glob.glob(stem + '.hip-*'):
+        if not f.endswith('-hip-amdgcn-amd-amdhsa-gfx950.s'):
+            os.remove(f)
     return obj
 
 

@@ -1078,6 +1078,9 @@ __global__ void __launch_bounds__(WIDE ? 64 : 64 * KB_MAX_WAVES, WIDE ? 2 : KB_M
                 // (readfirstlane returns int: go through unsigned, or bit 31 smears into the upper half)
                 myMc = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(mm >> 32)) << 32) |
                        (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)mm);
+                // only candidates that exist: a stray bit (round 1 met one, a sign-extended bit 31) must never index a
+                // record behind the manifold-constraint area
+                myMc &= NMC >= 64 ? ~0ull : ((1ull << NMC) - 1ull);
             }
             // b2ContactSolver::WarmStart
             KB_REG_ROUNDS({
@@ -1323,6 +1326,7 @@ __global__ void __launch_bounds__(WIDE ? 64 : 64 * KB_MAX_WAVES, WIDE ? 2 : KB_M
                     const unsigned long long mm = mcMask[coop ? nw : wave];
                     myMc = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(mm >> 32)) << 32) |
                            (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)mm);
+                    myMc &= NMC >= 64 ? ~0ull : ((1ull << NMC) - 1ull);      // only candidates that exist
                 }
                 const bool leader = lid == 0;
 #define KB_ROUND_SYNC() do { if (coop) __syncthreads(); else wave_sync(); } while (0)
