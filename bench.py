@@ -55,6 +55,8 @@ def parse_args(argv=None):
     ap.add_argument('--boxes', action='store_true', help='with --objects: 0.15 m boxes (Quad) instead of discs')
     ap.add_argument('--sense', type=float, default=0.0, help='IR neighbour sensing radius in metres (0 = off; adds 4 B per kilobot-step)')
     ap.add_argument('--no-toi', action='store_true', help='disable the continuous step against the walls (A/B only)')
+    ap.add_argument('--vel-iters', type=int, default=10, help='solver velocity iterations (A/B only; the reference uses 10)')
+    ap.add_argument('--pos-iters', type=int, default=10, help='solver position iterations (A/B only; the reference uses 10)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fused', action='store_true', help='skip the extra fused 10-substep launches after the timed region')
     ap.add_argument('--cpu-envs', type=int, default=64)
@@ -198,6 +200,8 @@ def main():
         okw = dict(obj_shape=[1] * args.objects, obj_nverts=[4] * args.objects, obj_verts=[[[0.075 * 25.0, 0.075 * 25.0]]] * args.objects)
     if args.sense > 0.0:
         okw['sense_radius'] = args.sense
+    if args.vel_iters != 10 or args.pos_iters != 10:
+        okw.update(vel_iters=args.vel_iters, pos_iters=args.pos_iters)
     sim = KilobotSim(E, N, device=dev, num_objects=args.objects, toi_walls=0 if args.no_toi else 1, **okw)
     if args.threads:
         sim.block_threads = args.threads

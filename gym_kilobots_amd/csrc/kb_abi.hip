@@ -497,7 +497,7 @@ int kb_step(kb_sim *sim, const float *d_actions, const float *d_light_action, in
         const bool fixed = uses_fixed_1024(p, sim->threads) &&
                            p.NP == 1024 && p.NB == 1024 + KB_MAX_OBJECTS + 4 && (obj || p.capL == CAP_LDS) &&
                            (obj || p.cap == (int)((cap1024 + 7) & ~7L));
-        fn = kb_pick_velocity(fixed ? KB_PICK_FIXED_1024 : p.light_type, fixed ? (discs ? 5 : (int)obj) : objsel);
+        fn = kb_pick_velocity(fixed ? (p.sense_s > 0 ? KB_PICK_FIXED_1024_SENSE : KB_PICK_FIXED_1024) : p.light_type, fixed ? (discs ? 5 : (int)obj) : objsel);
     } break;
     case KB_DRIVE_ACCEL: fn = kb_pick_accel(p.light_type, objsel); break;
     case KB_DRIVE_MOTORS: fn = kb_pick_motors(p.light_type, objsel); break;

@@ -211,6 +211,38 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// ---- wave-wide reductions / scan over all 64 lanes with DPP (data-parallel primitives: row shifts inside the four rows of
+// 16 lanes, then the row_bcast steps across rows): six VALU instructions with no trip to the LDS crossbar, where a
+// __shfl_xor / __shfl_up ladder is six dependent ds_bpermute round trips.  All 64 lanes must be active.
+#define KB_DPP(v, ctrl, rows) __builtin_amdgcn_update_dpp(0, (int)(v), ctrl, rows, 0xf, true)
+__device__ __forceinline__ unsigned wave_or(unsigned v) {       // OR of v over the wave, the same value in every lane
+    v |= (unsigned)KB_DPP(v, 0x111, 0xf);      // row_shr:1
+    v |= (unsigned)KB_DPP(v, 0x112, 0xf);      // row_shr:2
+    v |= (unsigned)KB_DPP(v, 0x114, 0xf);      // row_shr:4
+    v |= (unsigned)KB_DPP(v, 0x118, 0xf);      // row_shr:8   -> lane 15 of each row holds its row
+    v |= (unsigned)KB_DPP(v, 0x142, 0xa);      // row_bcast:15 into rows 1 and 3
+    v |= (unsigned)KB_DPP(v, 0x143, 0xc);      // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned wave_umax(unsigned v) {
+    v = max(v, (unsigned)KB_DPP(v, 0x111, 0xf));
+    v = max(v, (unsigned)KB_DPP(v, 0x112, 0xf));
+    v = max(v, (unsigned)KB_DPP(v, 0x114, 0xf));
+    v = max(v, (unsigned)KB_DPP(v, 0x118, 0xf));
+    v = max(v, (unsigned)KB_DPP(v, 0x142, 0xa));
+    v = max(v, (unsigned)KB_DPP(v, 0x143, 0xc));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned wave_incl_scan(unsigned v) {   // inclusive prefix sum over the lanes
+    v += (unsigned)KB_DPP(v, 0x111, 0xf);
+    v += (unsigned)KB_DPP(v, 0x112, 0xf);
+    v += (unsigned)KB_DPP(v, 0x114, 0xf);
+    v += (unsigned)KB_DPP(v, 0x118, 0xf);
+    v += (unsigned)KB_DPP(v, 0x142, 0xa);
+    v += (unsigned)KB_DPP(v, 0x143, 0xc);
+    return v;
+}
+
 template <class AR>
 __device__ __forceinline__ void wall_geom(const AR &p, int wl, float x, float y, float &dist, float &nx, float &ny) {
     switch (wl) {
@@ -452,11 +484,7 @@ __device__ __forceinline__ unsigned block_scan_u8(const unsigned char *cnt, unsi
     const unsigned c4 = in ? *reinterpret_cast<const unsigned *>(cnt + 4 * tid) : 0u;
     const unsigned c0 = c4 & 255u, c1 = (c4 >> 8) & 255u, c2 = (c4 >> 16) & 255u, c3 = c4 >> 24;
     const unsigned sum = c0 + c1 + c2 + c3;
-    unsigned incl = sum;
-    for (int d = 1; d < 64; d <<= 1) {
-        const unsigned t = __shfl_up(incl, d);
-        if (lane >= d) incl += t;
-    }
+    const unsigned incl = wave_incl_scan(sum);
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
     unsigned base = 0, total = 0;
@@ -473,7 +501,7 @@ __device__ __forceinline__ unsigned block_scan_u8(const unsigned char *cnt, unsi
 
 
 typedef void (*kb_step_fn)(const Params);
-constexpr int KB_PICK_FIXED_1024 = -1024;   // kb_pick_velocity: the num_bots == 1024 specialisations (no light; without / with objects)
+constexpr int KB_PICK_FIXED_1024 = -1024, KB_PICK_FIXED_1024_SENSE = -1025;   // ... the same with the neighbour-sensing hook   // kb_pick_velocity: the num_bots == 1024 specialisations (no light; without / with objects)
 // one translation unit per drive law (kb_inst_d*.hip) instantiates its kernels and hands out the right one
 kb_step_fn kb_pick_velocity(int light_type, int objects);   // objects: 0 none, 1 yes, 2 yes + one-wave workgroup
 kb_step_fn kb_pick_velocity_discs(int light_type, int objects);   // objects: 5 discs, 6 discs + one-wave workgroup

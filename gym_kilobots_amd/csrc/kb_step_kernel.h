@@ -16,7 +16,10 @@ namespace kb {
 // instantiation.
 // POLY = false: instantiation for scenes whose objects are all discs (BASELINE config 4): the kilobot - polygon contact
 // code and its per-slot registers fold away (half the register spills, + 9 % at cfg4).
-template <int DRIVE_MODE, int LIGHT_TYPE, bool OBJ, int FN = 0, bool WIDE = false, bool POLY = true>
+// SENSE = false: instantiation without the IR-range neighbour sensing hook (the fixed-size kernels are at their register
+// budget: the hook costs them 2 more spilled VGPRs, 20 B/lane of scratch traffic per launch); kb_step picks it when
+// kb_config.sense_radius == 0.
+template <int DRIVE_MODE, int LIGHT_TYPE, bool OBJ, int FN = 0, bool WIDE = false, bool POLY = true, bool SENSE = true>
 __global__ void __launch_bounds__(WIDE ? 64 : 64 * KB_MAX_WAVES, WIDE ? 2 : KB_MIN_WAVES_PER_SIMD) kb_step_kernel(const Params p) {
     extern __shared__ __align__(16) unsigned char smem[];
     int e = blockIdx.x;
@@ -333,7 +336,7 @@ __global__ void __launch_bounds__(WIDE ? 64 : 64 * KB_MAX_WAVES, WIDE ? 2 : KB_M
             const int cell = cy * p.gw + cx;
             cellOf[b] = (unsigned short)cell;
             nextb[b] = (unsigned short)kb_exch16(head, cell, (unsigned)b);
-            if (p.sense_s > 0) newOff[b] = 0;       // (dead until the scan behind the label pass: the neighbour counters of the sensing pass)
+            if (SENSE && p.sense_s > 0) newOff[b] = 0;       // (dead until the scan behind the label pass: the neighbour counters of the sensing pass)
         }
         if (tid < M) { start[N + tid].x = pos[N + tid].x; start[N + tid].y = pos[N + tid].y; objA0[tid] = objA[tid]; }
         if (tid < M) {   // b2Island::Solve damping of the objects; they keep their velocity between substeps
@@ -348,7 +351,7 @@ __global__ void __launch_bounds__(WIDE ? 64 : 64 * KB_MAX_WAVES, WIDE ? 2 : KB_M
         KB_STAMP(0);
         // ---- IR-range neighbour sensing (kb_config.sense_radius): at the sensing point of the substep, like the light
         //      (kilobots_env.py:174-180), off the cell lists that the contact search uses ----
-        if (p.sense_s > 0 && drive)
+        if (SENSE && p.sense_s > 0 && drive)
             kb_sense_pass(pos, head, nextb, cellOf, reinterpret_cast<unsigned *>(newOff), N, nt, tid, p.gw, p.gh, p.sense_s, p.sense_r2);
         // object-object / object-wall manifolds (b2Contact::Update) + their velocity-constraint set-up: candidate t
         // is lane t of wave 0; the record lives in LDS, the previous substep's impulses come from g.ows_acc
@@ -378,23 +381,38 @@ __global__ void __launch_bounds__(WIDE ? 64 : 64 * KB_MAX_WAVES, WIDE ? 2 : KB_M
                     const bool in = ox >= 0 && ox < p.gw && oy < p.gh;
                     hd[k] = in ? (unsigned)head[in ? oy * p.gw + ox : cell] : (unsigned)EMPTY16;
                 }
+                // the five lists are walked in lockstep: one LDS round trip serves the next candidate of every list that
+                // still has one (lists that have ended re-read the kilobot itself), so the trips of this pass are the
+                // length of the longest list, not the sum of the five
+                unsigned ckk[5] = {0u, 0u, 0u, 0u, 0u};
+                while (hd[0] != (unsigned)EMPTY16 || hd[1] != (unsigned)EMPTY16 || hd[2] != (unsigned)EMPTY16 ||
+                       hd[3] != (unsigned)EMPTY16 || hd[4] != (unsigned)EMPTY16) {
+                    float2 pbk[5];
+                    unsigned nbk[5];
 #pragma unroll
-                for (int k = 0; k < 5; ++k) {
-                    unsigned ck = 0;
-                    for (unsigned b = hd[k]; b != (unsigned)EMPTY16;) {
-                        const float2 pb = pos[b];
-                        const unsigned nb = nextb[b];
+                    for (int k = 0; k < 5; ++k) {
+                        const unsigned bb = hd[k] != (unsigned)EMPTY16 ? hd[k] : (unsigned)a;
+                        pbk[k] = pos[bb]; nbk[k] = nextb[bb];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) {
+                        const unsigned b = hd[k];
+                        if (b == (unsigned)EMPTY16) continue;
                         if (!(k == 0 && (int)b <= a)) {
-                            const float dx = pb.x - ax, dy = pb.y - ay;
+                            const float dx = pbk[k].x - ax, dy = pbk[k].y - ay;
                             const float dd = dx * dx + dy * dy;
                             if (!(dd > rr2)) {  // b2CollideCircles
-                                ck++;
+                                ckk[k]++;
                                 const unsigned c = atomicAdd(&misc[M_NCON], 1u);
                                 if (c < (unsigned)stageCap_) { sPair[c] = (unsigned)a | (b << 16); sInfo[c] = (unsigned)k; }
                             }
                         }
-                        b = nb;
+                        hd[k] = nbk[k];
                     }
+                }
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    unsigned ck = ckk[k];
                     mine += ck;
                     if (ck > 63u) { ck = 63u; atomicOr(&misc[M_STATUS], 4u); }
                     cnt |= ck << (6 * k);
@@ -605,7 +623,7 @@ __global__ void __launch_bounds__(WIDE ? 64 : 64 * KB_MAX_WAVES, WIDE ? 2 : KB_M
             islWave[b] = (unsigned char)((unsigned)b % (unsigned)nw);
             head[cellOf[b]] = EMPTY16;
             active[b] = 1; active[NB + b] = 0;
-            if (p.sense_s > 0 && drive) g.nbr_count[o + b] = (unsigned)newOff[b];
+            if (SENSE && p.sense_s > 0 && drive) g.nbr_count[o + b] = (unsigned)newOff[b];
         }
         if (tid < 64) bkStart[tid] = 0;     // size-class counters of the island placement
         if (tid < 32) bkFill[tid] = 0;
@@ -660,8 +678,7 @@ __global__ void __launch_bounds__(WIDE ? 64 : 64 * KB_MAX_WAVES, WIDE ? 2 : KB_M
             __syncthreads();
             if (wave == 0) {
                 const unsigned v_ = lane < 32 ? szSum[lane] : 0u;
-                unsigned incl = v_;
-                for (int d = 1; d < 32; d <<= 1) { const unsigned t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+                const unsigned incl = wave_incl_scan(v_);
                 if (lane < 32) szPre[lane] = incl - v_;
                 if (lane < nw) misc[M_WCNT + lane] = 0;
             }
@@ -807,11 +824,7 @@ __global__ void __launch_bounds__(WIDE ? 64 : 64 * KB_MAX_WAVES, WIDE ? 2 : KB_M
                 const int s0 = lane * chunk, e0 = min(nb, s0 + chunk);
                 unsigned sum = 0;
                 for (int i = s0; i < e0; ++i) sum += bkStart[i];
-                unsigned incl = sum;
-                for (int d = 1; d < 64; d <<= 1) {
-                    unsigned t = __shfl_up(incl, d);
-                    if (lane >= d) incl += t;
-                }
+                const unsigned incl = wave_incl_scan(sum);
                 unsigned run = incl - sum;
                 for (int i = s0; i < e0; ++i) { unsigned v = bkStart[i]; bkStart[i] = run; run += v; }
                 if (lane == 63) bkStart[nb] = incl;
@@ -884,8 +897,7 @@ __global__ void __launch_bounds__(WIDE ? 64 : 64 * KB_MAX_WAVES, WIDE ? 2 : KB_M
                 }
             }
             // keys present in this wave (wave-uniform 52-bit mask)
-            for (int d = 32; d >= 1; d >>= 1) { mlo |= __shfl_xor(mlo, d); mhi |= __shfl_xor(mhi, d); }
-            mlo = __builtin_amdgcn_readfirstlane(mlo); mhi = __builtin_amdgcn_readfirstlane(mhi);
+            mlo = wave_or(mlo); mhi = wave_or(mhi);
             const unsigned long long keymask = ((unsigned long long)mhi << 32) | mlo;
             wave_sync();   // bkMaxRank of this wave
 #ifdef KB_PROFILE
@@ -953,8 +965,7 @@ __global__ void __launch_bounds__(WIDE ? 64 : 64 * KB_MAX_WAVES, WIDE ? 2 : KB_M
             int maxD = 0;
 #pragma unroll
             for (int j = 0; j < KREG; ++j) maxD = max(maxD, rdepth[j]);
-            for (int dd = 32; dd >= 1; dd >>= 1) maxD = max(maxD, __shfl_xor(maxD, dd));
-            maxD = __builtin_amdgcn_readfirstlane(maxD);
+            maxD = (int)wave_umax((unsigned)maxD);
             KB_STAMP_PRE(20);    // ... + depth pass
             // ---- deal the contacts to (lane, slot) in order of depth: the 64 shallowest go to slot 0, the rest to
             // slot 1, ...  A depth level then lives in one slot (two at a boundary), and a sweep round only pays for
@@ -985,10 +996,8 @@ __global__ void __launch_bounds__(WIDE ? 64 : 64 * KB_MAX_WAVES, WIDE ? 2 : KB_M
 #pragma unroll
             for (int j = 0; j < KREG; ++j) {
                 const unsigned long long mine = rvalid[j] ? 1ull << min(rdepth[j], 63) : 0ull;
-                unsigned lo = (unsigned)mine, hi = (unsigned)(mine >> 32);
-                for (int dd = 32; dd >= 1; dd >>= 1) { lo |= __shfl_xor(lo, dd); hi |= __shfl_xor(hi, dd); }
-                slotLevels[j] = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(hi) << 32) |
-                                (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(lo);
+                const unsigned lo = wave_or((unsigned)mine), hi = wave_or((unsigned)(mine >> 32));
+                slotLevels[j] = ((unsigned long long)hi << 32) | (unsigned long long)lo;
             }
             // ---- full load of the contacts ----
             // Kernels with objects (except the spill-free WIDE ones): lanes without a contact in slot j load a copy of the

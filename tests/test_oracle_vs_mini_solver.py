@@ -1,0 +1,76 @@
+"""Row a10 / f1 (the Box2D solver): the oracle against an INDEPENDENT second derivation of Box2D's discrete step.
+
+oracle/kb_oracle.c and the HIP kernel are twins of one restatement, so their bit-exact agreement cannot reveal a shared
+transcription error of Box2D.  tools/box2d_mini.py is a separate float32 restatement written in Box2D's own structure
+(bodies, fixtures, persistent contacts in creation order, b2ContactSolver per contact); tests/golden/mini_solver.json holds
+its trajectories for small scenes (circle-circle, circle-wall, polygon-circle with lever arm, box-wall with the two-point
+block solver and friction, disc-disc with friction, box-box).  The oracle must follow them within a float32 tolerance
+(stated per scene in the fixture: 2e-5 .. 2e-4 world units = 1 .. 8 micrometres for single-contact scenes, where the
+sweep order cannot matter; 2e-3 for scenes with several contacts, where Box2D's creation order and the oracle's canonical
+order legitimately differ).  box2d-py itself cannot be installed here: row a10 stays "parity unpinned" (DESIGN.md)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FIX = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'mini_solver.json')))['scenes']
+
+
+def _oracle_for(sc):
+    objs = sc['objects']
+    kw = dict(toi_walls=0, damping_model=1 if sc['damping'] == 'linear' else 0)
+    if objs:
+        pad = O.MAX_OBJECTS - len(objs)
+        kw.update(num_objects=len(objs),
+                  obj_shape=[O.SHAPE_CIRCLE if o['shape'] == 'circle' else O.SHAPE_BOX for o in objs] + [0] * pad,
+                  obj_nverts=[0 if o['shape'] == 'circle' else 4 for o in objs] + [0] * pad,
+                  obj_radius=[(o['r'] / 25.0) if o['shape'] == 'circle' else 0.0 for o in objs] + [0.075] * pad,
+                  obj_verts=[[[0.0, 0.0]] if o['shape'] == 'circle' else [[o['hx'], o['hy']]] for o in objs] + [[[0.0, 0.0]]] * pad)
+    N = len(sc['kilobots'])
+    o = O.OracleSim(O.default_config(1, N, **kw))
+    kb = np.array(sc['kilobots'], np.float64)
+    o.x[0], o.y[0], o.theta[0] = kb[:, 0].astype(np.float32), kb[:, 1].astype(np.float32), kb[:, 2].astype(np.float32)
+    o.set_actions(kb[None, :, 3:5].astype(np.float32))
+    for m, ob in enumerate(objs):
+        o.ox[0, m], o.oy[0, m], o.otheta[0, m] = ob['x'], ob['y'], ob['theta']
+        o.ovx[0, m], o.ovy[0, m], o.ow[0, m] = ob['vx'], ob['vy'], ob['w']
+    return o
+
+
+@pytest.mark.parametrize('name', sorted(FIX))
+def test_oracle_follows_the_independent_solver(name):
+    sc = FIX[name]
+    o = _oracle_for(sc)
+    tol = sc['tol']
+    touched = False
+    for k, ref in enumerate(sc['trajectory']):
+        o.step(1)
+        got = np.stack([o.x[0], o.y[0], o.theta[0]], -1).astype(np.float64)
+        want = np.array(ref['kilobots'])
+        assert np.abs(got[:, :2] - want[:, :2]).max() <= tol, (name, k, 'kilobot position', got, want)
+        assert np.abs(got[:, 2] - want[:, 2]).max() <= 10 * tol, (name, k, 'kilobot angle')
+        if sc['objects']:
+            g = np.stack([o.ox[0], o.oy[0], o.otheta[0], o.ovx[0], o.ovy[0], o.ow[0]], -1).astype(np.float64)
+            w = np.array(ref['objects'])
+            assert np.abs(g[:, :2] - w[:, :2]).max() <= tol, (name, k, 'object position', g, w)
+            assert np.abs(g[:, 2] - w[:, 2]).max() <= 10 * tol, (name, k, 'object angle', g, w)
+            assert np.abs(g[:, 3:] - w[:, 3:]).max() <= 200 * tol, (name, k, 'object velocity', g, w)
+        nb, nw, no = o.count_contacts(0, True)
+        touched |= (nb + nw + no) > 0
+    assert touched, 'the scene never made a contact'
+    assert int(o.status.max()) == 0
+
+
+def test_fixture_is_what_the_mini_solver_produces():
+    """The committed fixture equals a fresh run of tools/box2d_mini.py (two scenes, bit for bit through JSON)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import gen_mini_solver_golden as G
+    for name in ('head_on', 'box_hits_wall'):
+        traj, touched = G.run(G.SCENES[name])
+        assert touched
+        assert traj == FIX[name]['trajectory']
