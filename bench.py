@@ -57,6 +57,7 @@ def parse_args(argv=None):
     ap.add_argument('--no-toi', action='store_true', help='disable the continuous step against the walls (A/B only)')
     ap.add_argument('--vel-iters', type=int, default=10, help='solver velocity iterations (A/B only; the reference uses 10)')
     ap.add_argument('--pos-iters', type=int, default=10, help='solver position iterations (A/B only; the reference uses 10)')
+    ap.add_argument('--arena', type=float, nargs=2, default=None, metavar=('W', 'H'), help='arena size in metres (A/B only; default 2.0 x 1.5)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fused', action='store_true', help='skip the extra fused 10-substep launches after the timed region')
     ap.add_argument('--cpu-envs', type=int, default=64)
@@ -200,6 +201,8 @@ def main():
         okw = dict(obj_shape=[1] * args.objects, obj_nverts=[4] * args.objects, obj_verts=[[[0.075 * 25.0, 0.075 * 25.0]]] * args.objects)
     if args.sense > 0.0:
         okw['sense_radius'] = args.sense
+    if args.arena:
+        okw.update(world_width=args.arena[0], world_height=args.arena[1])
     if args.vel_iters != 10 or args.pos_iters != 10:
         okw.update(vel_iters=args.vel_iters, pos_iters=args.pos_iters)
     sim = KilobotSim(E, N, device=dev, num_objects=args.objects, toi_walls=0 if args.no_toi else 1, **okw)
@@ -323,7 +326,7 @@ def main():
                                '1 step = 1 world substep (dt 0.1 s) in 1 launch' % (E, N),
                    'envs_per_gpu': E, 'bots': N, 'total_envs': total_envs, 'substeps_per_launch': 1,
                    'parallelism': 'env-shard x%d' % world, 'workgroup_threads': sim.block_threads,
-                   'lds_bytes_per_env': sim.lds_bytes, 'seed': args.seed,
+                   'lds_bytes_per_env': sim.lds_bytes, 'resident_envs_per_cu': sim.resident_envs_per_cu, 'seed': args.seed,
                    'settle_substeps': settled, 'settle_stationary': bool(stationary),
                    'sense_radius_m': args.sense},
         'contacts_per_env': c_before, 'contacts_per_env_after': c_after,

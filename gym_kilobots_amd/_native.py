@@ -73,7 +73,7 @@ class KbBuffers(C.Structure):
 
 
 EXPORTS = ['kb_create', 'kb_destroy', 'kb_bind', 'kb_set_actions', 'kb_step', 'kb_get_poses', 'kb_sense', 'kb_reset',
-           'kb_lds_bytes', 'kb_contact_capacity', 'kb_scratch_bytes', 'kb_light_action_dim', 'kb_light_count', 'kb_block_threads', 'kb_set_block_threads',
+           'kb_lds_bytes', 'kb_resident_envs_per_cu', 'kb_contact_capacity', 'kb_scratch_bytes', 'kb_light_action_dim', 'kb_light_count', 'kb_block_threads', 'kb_set_block_threads',
            'kb_last_error', 'kb_version']
 
 _lib = None
@@ -125,7 +125,7 @@ def load():
     lib.kb_sense.restype = C.c_int
     lib.kb_reset.argtypes = [_P, C.POINTER(KbResetParams), _P]
     lib.kb_reset.restype = C.c_int
-    for name in ('kb_lds_bytes', 'kb_contact_capacity', 'kb_block_threads', 'kb_light_action_dim', 'kb_light_count'):
+    for name in ('kb_lds_bytes', 'kb_resident_envs_per_cu', 'kb_contact_capacity', 'kb_block_threads', 'kb_light_action_dim', 'kb_light_count'):
         getattr(lib, name).argtypes = [_P]
         getattr(lib, name).restype = C.c_int
     lib.kb_scratch_bytes.argtypes = [_P]

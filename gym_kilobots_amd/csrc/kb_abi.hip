@@ -159,15 +159,19 @@ struct kb_sim {
     bool bound;
     const void *attr_fn;   // kernel whose dynamic-LDS limit has been raised
     int threads;
+    int capL_regular;      // LDS staging entries of the regular image (the compact fixed-size image has its own: ldsc::CAPL)
 };
 
 // dynamic LDS of one env: the bucket tables scale with the waves of the workgroup, the object tables exist only in
 // scenes with objects (namespace lds, kb_common.h)
-static bool uses_fixed_1024(const kb::Params &p, int threads) {   // the instantiation kb_step picks (see there)
+static bool uses_fixed_1024(const kb::Params &p, int threads) {   // the instantiation kb_step picks: the ONE place that decides
+    const long cap1024 = (4L * 1024 + 64 + 7) & ~7L;
     return p.drive_mode == KB_DRIVE_VELOCITY && p.N == 1024 && p.light_type == KB_LIGHT_NONE && threads == 64 * kb::MAX_WAVES &&
-           kb::BPT * 64 * kb::MAX_WAVES == 1024;
+           kb::BPT * 64 * kb::MAX_WAVES == 1024 && p.NP == 1024 && p.NB == 1024 + KB_MAX_OBJECTS + 4 &&
+           (p.M > 0 || p.cap == (int)cap1024);      // (without objects the contact capacity is a compile-time constant of the kernel)
 }
 static int lds_bytes_for(const kb::Params &p, int threads, int capL) {
+    if (p.M == 0 && uses_fixed_1024(p, threads)) return kb::ldsc::total(p.NB, p.NP, p.ncell);     // the compact image (capL = ldsc::CAPL)
     const bool objarea = p.M > 0 || uses_fixed_1024(p, threads);
     return kb::lds::total(kb::lds::fixed(objarea, threads / 64), p.NB, capL, p.NP, p.ncell, p.nmc);
 }
@@ -414,6 +418,8 @@ int kb_create(const kb_config *cfg, kb_sim **out) {
         while (c - 8 >= lo && lds_bytes_for(p, s->threads, c) > LDS_CU / (fit + 1)) c -= 8;
         if (fit >= 1 && lds_bytes_for(p, s->threads, c) <= LDS_CU / (fit + 1)) p.capL = c;
     }
+    s->capL_regular = p.capL;
+    if (p.M == 0 && uses_fixed_1024(p, s->threads)) p.capL = ldsc::CAPL;
     p.lds_total = lds_bytes_for(p, s->threads, p.capL);
     if (p.lds_total > LDS_CU) {
         delete s;
@@ -471,6 +477,43 @@ int kb_set_actions(kb_sim *sim, const float *d_actions, void *stream) {
     return KB_OK;
 }
 
+// the kernel instantiation of a handle (drive law, light model, objects, workgroup size)
+static kb_step_fn select_kernel(const kb_sim *sim, const kb::Params &p) {
+    const bool obj = p.M > 0;
+    int objsel = obj ? (sim->threads <= 64 ? 2 : 1) : 0;     // one-wave workgroups with objects: the 256-VGPR instantiation
+    // scenes whose objects are all discs: instantiations without the kilobot - polygon contact code (5 / 6)
+    bool discs = obj;
+    for (int f = 0; f < p.F; ++f) discs = discs && ot_kind(p.otab[f]) == KB_SHAPE_CIRCLE;
+    if (discs) objsel += 4;
+    switch (p.drive_mode) {
+    case KB_DRIVE_VELOCITY: {
+        // the flagship size has its own instantiation with a compile-time LDS layout
+        const bool fixed = uses_fixed_1024(p, sim->threads);
+        if (fixed && !obj && p.capL != ldsc::CAPL) return nullptr;      // (cannot happen: kb_create / kb_set_block_threads keep them in step)
+        return kb_pick_velocity(fixed ? (p.sense_s > 0 ? KB_PICK_FIXED_1024_SENSE : KB_PICK_FIXED_1024) : p.light_type, fixed ? (discs ? 5 : (int)obj) : objsel);
+    }
+    case KB_DRIVE_ACCEL: return kb_pick_accel(p.light_type, objsel);
+    case KB_DRIVE_MOTORS: return kb_pick_motors(p.light_type, objsel);
+    case KB_DRIVE_SIMPLE_PHOTOTAXIS: return kb_pick_simple_phototaxis(p.light_type, objsel);
+    case KB_DRIVE_PHOTOTAXIS: return kb_pick_phototaxis(p.light_type, objsel);
+    default: return nullptr;
+    }
+}
+
+int kb_resident_envs_per_cu(kb_sim *sim) {
+    if (!sim) return fail(KB_EINVAL, "kb_resident_envs_per_cu: NULL handle");
+    kb_step_fn fn = select_kernel(sim, sim->p);
+    if (!fn) return fail(KB_EINVAL, "kb_resident_envs_per_cu: no kernel for this configuration");
+    if (sim->p.lds_total > 64 * 1024) {
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e2 != hipSuccess) return fail(KB_EHIP, "kb_resident_envs_per_cu: hipFuncSetAttribute: %s", hipGetErrorString(e2));
+    }
+    int n = 0;
+    hipError_t err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void *>(fn), sim->threads, (size_t)sim->p.lds_total);
+    if (err != hipSuccess) return fail(KB_EHIP, "kb_resident_envs_per_cu: %s", hipGetErrorString(err));
+    return n;
+}
+
 int kb_step(kb_sim *sim, const float *d_actions, const float *d_light_action, int n_substeps, int flags, void *stream) {
     if (!sim) return fail(KB_EINVAL, "kb_step: NULL handle");
     if (!sim->bound) return fail(KB_ENOTBOUND, "kb_step: kb_bind() first");
@@ -483,28 +526,7 @@ int kb_step(kb_sim *sim, const float *d_actions, const float *d_light_action, in
     p.light_action = d_light_action;
     p.n_substeps = n_substeps;
     p.flags = flags;
-    const bool obj = p.M > 0;
-    int objsel = obj ? (sim->threads <= 64 ? 2 : 1) : 0;     // one-wave workgroups with objects: the 256-VGPR instantiation
-    // scenes whose objects are all discs: instantiations without the kilobot - polygon contact code (5 / 6)
-    bool discs = obj;
-    for (int f = 0; f < p.F; ++f) discs = discs && ot_kind(p.otab[f]) == KB_SHAPE_CIRCLE;
-    if (discs) objsel += 4;
-    kb_step_fn fn = nullptr;
-    switch (p.drive_mode) {
-    case KB_DRIVE_VELOCITY: {
-        // the flagship size has its own instantiation with a compile-time LDS layout
-        const long cap1024 = 4L * 1024 + 64;
-        const bool fixed = uses_fixed_1024(p, sim->threads) &&
-                           p.NP == 1024 && p.NB == 1024 + KB_MAX_OBJECTS + 4 && (obj || p.capL == CAP_LDS) &&
-                           (obj || p.cap == (int)((cap1024 + 7) & ~7L));
-        fn = kb_pick_velocity(fixed ? (p.sense_s > 0 ? KB_PICK_FIXED_1024_SENSE : KB_PICK_FIXED_1024) : p.light_type, fixed ? (discs ? 5 : (int)obj) : objsel);
-    } break;
-    case KB_DRIVE_ACCEL: fn = kb_pick_accel(p.light_type, objsel); break;
-    case KB_DRIVE_MOTORS: fn = kb_pick_motors(p.light_type, objsel); break;
-    case KB_DRIVE_SIMPLE_PHOTOTAXIS: fn = kb_pick_simple_phototaxis(p.light_type, objsel); break;
-    case KB_DRIVE_PHOTOTAXIS: fn = kb_pick_phototaxis(p.light_type, objsel); break;
-    default: break;
-    }
+    kb_step_fn fn = select_kernel(sim, p);
     if (!fn) return fail(KB_EINVAL, "kb_step: no kernel for this drive mode / light type");
     if (p.lds_total > 64 * 1024 && sim->attr_fn != reinterpret_cast<const void *>(fn)) {
         // the attribute belongs to the kernel, not to this sim: raise it to the hardware limit, so that sims of
@@ -574,9 +596,11 @@ int kb_block_threads(const kb_sim *sim) { return sim ? sim->threads : KB_EINVAL;
 int kb_set_block_threads(kb_sim *sim, int threads) {
     if (!sim || threads < 64 || threads > 64 * MAX_WAVES || (threads & 63)) return fail(KB_EINVAL, "kb_set_block_threads: multiple of 64 up to the build maximum");
     if (sim->p.N > BPT * threads) return fail(KB_EINVAL, "kb_set_block_threads: need num_bots <= bots-per-thread x threads");
-    const int need = lds_bytes_for(sim->p, threads, sim->p.capL);
+    const int capL = (sim->p.M == 0 && uses_fixed_1024(sim->p, threads)) ? ldsc::CAPL : sim->capL_regular;
+    const int need = lds_bytes_for(sim->p, threads, capL);
     if (need > 160 * 1024) return fail(KB_ELDS, "kb_set_block_threads: more than 160 KiB of LDS per env at this workgroup size");
     sim->threads = threads;
+    sim->p.capL = capL;
     sim->p.lds_total = need;
     return KB_OK;
 }

@@ -53,6 +53,9 @@ constexpr int RK = 4;                 // rank buckets per class; the last one ho
 #ifndef KB_MIN_WAVES_PER_SIMD
 #define KB_MIN_WAVES_PER_SIMD 4
 #endif
+#ifndef KB_COMPACT_WAVES_PER_SIMD
+#define KB_COMPACT_WAVES_PER_SIMD 6     // the compact fixed-size kernel: 80 VGPRs, three 8-wave workgroups per CU
+#endif
 constexpr int MAX_WAVES = KB_MAX_WAVES;   // waves per workgroup
 constexpr int BK_PER_WAVE = NUM_CLS * RK;
 constexpr int MAX_BUCKETS = MAX_WAVES * BK_PER_WAVE;
@@ -113,6 +116,40 @@ __host__ __device__ inline int mcarea(int fx, int NB, int capL, int NP, int ncel
 // manifold-constraint records (objects only): MC_FIELDS words x nmc candidates, field-major
 __host__ __device__ inline int total(int fx, int NB, int capL, int NP, int ncell, int nmc) { return (mcarea(fx, NB, capL, NP, ncell) + 4 * MC_FIELDS_C * nmc + 15) & ~15; }
 }  // namespace lds
+
+// ---- compact LDS image: three envs of 1024 kilobots per CU --------------------------------------------------------------
+// What decides the throughput of the latency-bound step is how many envs a CU holds (profiles/: waves wait 60 % of their
+// cycles, no pipe is more than a third busy; 3 resident envs instead of 2 gave + 37 % at 480 kilobots).  The fixed-size
+// kernel without objects therefore runs at 80 VGPRs (6 waves per SIMD = three 8-wave workgroups) with an LDS image of
+// <= 54 608 B (a third of 160 KiB) instead of 80 416 B:
+//   - no image of the previous substep's warm-start list (6 B per entry): the label pass reads the packed list in HBM / L2;
+//   - the poses at the start of the substep (continuous step) are saved at integration time -- they do not change earlier --
+//     into arrays that are dead by then: x over [nextb | cellOf], y over dirCnt;
+//   - the per-contact scratch of the contact sort / slot dealing (lCbk) lies over nextb (dead once the label pass is done
+//     and needed only before the integration);
+//   - the bucket tables of the contact sort / island placement live in the cell-head area, which is dead once the label
+//     pass is done; the heads are cleared as a whole at the end of the substep;
+//   - 688 staged contacts (the settled benchmark scene has 550 +- 20 per env, at most 630 in 4096 envs; envs beyond take
+//     the global staging slice as before); no object tables.
+namespace ldsc {
+constexpr int CAPL = 688;
+constexpr int TABLES = lds::nlist(KB_MAX_WAVES) + 16 - lds::BKSTART;      // bucket tables, relative to the head area
+__host__ __device__ constexpr int pos(int) { return 320; }                 // (MISC 256 + WSUM 64 in front)
+__host__ __device__ constexpr int vel(int NB) { return pos(NB) + 8 * NB; }
+__host__ __device__ constexpr int dircnt(int NB) { return vel(NB) + 8 * NB; }
+__host__ __device__ constexpr int parent(int NB) { return dircnt(NB) + 4 * NB; }
+__host__ __device__ constexpr int con32(int NB, int k) { return parent(NB) + 4 * NB + 4 * CAPL * k; }      // lPair lInfo lAcc
+__host__ __device__ constexpr int con16(int NB, int k) { return con32(NB, 3) + 2 * CAPL * k; }             // lOrder (lCbk: over nextb)
+__host__ __device__ constexpr int bot16(int NB, int NP, int k) { return con16(NB, 1) + 2 * NP * k; }       // wsOff newOff nextb cellOf
+__host__ __device__ constexpr int bot8(int NB, int NP, int k) { return bot16(NB, NP, 4) + NP * k; }        // wsCnt wsCntNew
+__host__ __device__ constexpr int active(int NB, int NP) { return bot8(NB, NP, 2); }
+__host__ __device__ constexpr int islwave(int NB, int NP) { return active(NB, NP) + 2 * NB; }
+__host__ __device__ constexpr int head(int NB, int NP) { return (islwave(NB, NP) + NB + 15) & ~15; }
+__host__ __device__ inline int total(int NB, int NP, int ncell) {
+    const int h = (2 * ncell + 4 + 15) & ~15;
+    return head(NB, NP) + (h > TABLES ? h : TABLES);
+}
+}  // namespace ldsc
 
 struct Params {
     kb_buffers buf;

@@ -19,8 +19,11 @@ namespace kb {
 // SENSE = false: instantiation without the IR-range neighbour sensing hook (the fixed-size kernels are at their register
 // budget: the hook costs them 2 more spilled VGPRs, 20 B/lane of scratch traffic per launch); kb_step picks it when
 // kb_config.sense_radius == 0.
+// The fixed-size kernel without objects uses the compact LDS image (namespace ldsc) and a budget of 80 VGPRs (launch bounds of
+// six waves per SIMD): three envs of 1024 kilobots per CU.
 template <int DRIVE_MODE, int LIGHT_TYPE, bool OBJ, int FN = 0, bool WIDE = false, bool POLY = true, bool SENSE = true>
-__global__ void __launch_bounds__(WIDE ? 64 : 64 * KB_MAX_WAVES, WIDE ? 2 : KB_MIN_WAVES_PER_SIMD) kb_step_kernel(const Params p) {
+__global__ void __launch_bounds__(WIDE ? 64 : 64 * KB_MAX_WAVES, WIDE ? 2 : ((FN != 0 && !OBJ) ? KB_COMPACT_WAVES_PER_SIMD : KB_MIN_WAVES_PER_SIMD)) kb_step_kernel(const Params p) {
+    constexpr bool COMPACT = FN != 0 && !OBJ;
     extern __shared__ __align__(16) unsigned char smem[];
     int e = blockIdx.x;
     int tid = threadIdx.x;
@@ -33,31 +36,35 @@ __global__ void __launch_bounds__(WIDE ? 64 : 64 * KB_MAX_WAVES, WIDE ? 2 : KB_M
     const float h = p.h;
 
     const int NB = FN ? ((FN + 3) & ~3) + KB_MAX_OBJECTS + 4 : p.NB;
-    const int capL_ = (FN && !OBJ) ? (4 * FN + 64 < CAP_LDS ? 4 * FN + 64 : CAP_LDS) : p.capL;   // (FN >= 32: cap = 4 FN + 64, see kb_create)
+    const int capL_ = COMPACT ? ldsc::CAPL : p.capL;
     // LDS arrays (offsets: namespace lds in kb_common.h)
     // (the fixed-size instantiations keep room for the object tables even without objects: all their offsets are
     //  compile-time constants either way, two envs per CU fit both ways, and this image measured 1 % faster)
     const int fx = lds::fixed(OBJ || FN != 0, nw), ot_ = lds::objtab(nw);
     // positions, velocities and start-of-substep positions as (x, y) pairs: one 8-byte LDS access per body
-    float2 *pos = (float2 *)(smem + lds::body32(fx, NB, 0)), *vel = (float2 *)(smem + lds::body32(fx, NB, 2));
-    float2 *start = (float2 *)(smem + lds::body32(fx, NB, 4));
-    unsigned *dirCnt = (unsigned *)(smem + lds::body32(fx, NB, 6)), *parent = (unsigned *)(smem + lds::body32(fx, NB, 7));
+    float2 *pos = (float2 *)(smem + (COMPACT ? ldsc::pos(NB) : lds::body32(fx, NB, 0))), *vel = (float2 *)(smem + (COMPACT ? ldsc::vel(NB) : lds::body32(fx, NB, 2)));
+    float2 *start = (float2 *)(smem + lds::body32(fx, NB, 4));      // (not in the compact image: startX / startY below)
+    unsigned *dirCnt = (unsigned *)(smem + (COMPACT ? ldsc::dircnt(NB) : lds::body32(fx, NB, 6))), *parent = (unsigned *)(smem + (COMPACT ? ldsc::parent(NB) : lds::body32(fx, NB, 7)));
     unsigned *islCnt = dirCnt;  // alias: dirCnt is dead once the contacts are emitted
-    unsigned *lPair = (unsigned *)(smem + lds::con32(fx, NB, capL_, 0)), *lInfo = (unsigned *)(smem + lds::con32(fx, NB, capL_, 1));
-    float *lAcc = (float *)(smem + lds::con32(fx, NB, capL_, 2)), *oldAcc = (float *)(smem + lds::con32(fx, NB, capL_, 3));
-    unsigned short *lCbk = (unsigned short *)(smem + lds::con16(fx, NB, capL_, 0)), *lOrder = (unsigned short *)(smem + lds::con16(fx, NB, capL_, 1));
-    unsigned short *oldKey = (unsigned short *)(smem + lds::con16(fx, NB, capL_, 2));
-    unsigned short *wsOff = (unsigned short *)(smem + lds::bot16(fx, NB, capL_, NP, 0)), *newOff = (unsigned short *)(smem + lds::bot16(fx, NB, capL_, NP, 1));
-    unsigned short *nextb = (unsigned short *)(smem + lds::bot16(fx, NB, capL_, NP, 2)), *cellOf = (unsigned short *)(smem + lds::bot16(fx, NB, capL_, NP, 3));
-    unsigned char *wsCnt = smem + lds::bot8(fx, NB, capL_, NP, 0), *wsCntNew = smem + lds::bot8(fx, NB, capL_, NP, 1);
-    unsigned char *active = smem + lds::active(fx, NB, capL_, NP);
-    unsigned char *islWave = smem + lds::islwave(fx, NB, capL_, NP);   // wave that sweeps the island rooted at body b
-    unsigned short *head = (unsigned short *)(smem + lds::head(fx, NB, capL_, NP));   // per-cell list heads (EMPTY16 = empty)
+    unsigned *lPair = (unsigned *)(smem + (COMPACT ? ldsc::con32(NB, 0) : lds::con32(fx, NB, capL_, 0))), *lInfo = (unsigned *)(smem + (COMPACT ? ldsc::con32(NB, 1) : lds::con32(fx, NB, capL_, 1)));
+    float *lAcc = (float *)(smem + (COMPACT ? ldsc::con32(NB, 2) : lds::con32(fx, NB, capL_, 2))), *oldAcc = (float *)(smem + lds::con32(fx, NB, capL_, 3));
+    unsigned short *lCbk = (unsigned short *)(smem + (COMPACT ? ldsc::bot16(NB, NP, 2) : lds::con16(fx, NB, capL_, 0))), *lOrder = (unsigned short *)(smem + (COMPACT ? ldsc::con16(NB, 0) : lds::con16(fx, NB, capL_, 1)));
+    unsigned short *oldKey = (unsigned short *)(smem + lds::con16(fx, NB, capL_, 2));      // (oldAcc / oldKey: not in the compact image, never touched there)
+    unsigned short *wsOff = (unsigned short *)(smem + (COMPACT ? ldsc::bot16(NB, NP, 0) : lds::bot16(fx, NB, capL_, NP, 0))), *newOff = (unsigned short *)(smem + (COMPACT ? ldsc::bot16(NB, NP, 1) : lds::bot16(fx, NB, capL_, NP, 1)));
+    unsigned short *nextb = (unsigned short *)(smem + (COMPACT ? ldsc::bot16(NB, NP, 2) : lds::bot16(fx, NB, capL_, NP, 2))), *cellOf = (unsigned short *)(smem + (COMPACT ? ldsc::bot16(NB, NP, 3) : lds::bot16(fx, NB, capL_, NP, 3)));
+    unsigned char *wsCnt = smem + (COMPACT ? ldsc::bot8(NB, NP, 0) : lds::bot8(fx, NB, capL_, NP, 0)), *wsCntNew = smem + (COMPACT ? ldsc::bot8(NB, NP, 1) : lds::bot8(fx, NB, capL_, NP, 1));
+    unsigned char *active = smem + (COMPACT ? ldsc::active(NB, NP) : lds::active(fx, NB, capL_, NP));
+    unsigned char *islWave = smem + (COMPACT ? ldsc::islwave(NB, NP) : lds::islwave(fx, NB, capL_, NP));   // wave that sweeps the island rooted at body b
+    unsigned short *head = (unsigned short *)(smem + (COMPACT ? ldsc::head(NB, NP) : lds::head(fx, NB, capL_, NP)));   // per-cell list heads (EMPTY16 = empty)
+    // compact image: start-of-substep positions over arrays that are dead from the integration on
+    float *startX = reinterpret_cast<float *>(nextb), *startY = reinterpret_cast<float *>(dirCnt);
     unsigned *misc = (unsigned *)(smem + lds::MISC), *wsum = (unsigned *)(smem + lds::WSUM);
-    unsigned *bkStart = (unsigned *)(smem + lds::BKSTART), *bkFill = (unsigned *)(smem + lds::bkfill(nw));
-    unsigned *bkMaxRank = (unsigned *)(smem + lds::bkmaxrank(nw));
-    unsigned short *bkList = (unsigned short *)(smem + lds::bklist(nw));
-    unsigned char *nList = smem + lds::nlist(nw);
+    // (compact image: the bucket tables lie over the cell heads, which are dead between the label pass and the next substep)
+    const int tb_ = COMPACT ? ldsc::head(NB, NP) - lds::BKSTART : 0;
+    unsigned *bkStart = (unsigned *)(smem + tb_ + lds::BKSTART), *bkFill = (unsigned *)(smem + tb_ + lds::bkfill(nw));
+    unsigned *bkMaxRank = (unsigned *)(smem + tb_ + lds::bkmaxrank(nw));
+    unsigned short *bkList = (unsigned short *)(smem + tb_ + lds::bklist(nw));
+    unsigned char *nList = smem + tb_ + lds::nlist(nw);
     float *objTab = (float *)(smem + ot_);                       // fixture table (kb_objects.h: OT_*)
     float *objBody = (float *)(smem + ot_ + lds::OBJBODY);                     // body table (kb_objects.h: BT_*)
     unsigned *objCnt = (unsigned *)(smem + ot_ + lds::OBJCNT);                 // kilobots touching object m
@@ -199,7 +206,7 @@ __global__ void __launch_bounds__(WIDE ? 64 : 64 * KB_MAX_WAVES, WIDE ? 2 : KB_M
     __syncthreads();
     // warm-start list of the previous substep: offsets, and an LDS image of the packed entries if it fits
     unsigned oldTotal = block_scan_u8(wsCnt, wsOff, NP, wsum);
-    bool oldInLds = oldTotal <= (unsigned)capL_;
+    bool oldInLds = !COMPACT && oldTotal <= (unsigned)capL_;     // (compact image: the list is read where it lies, in HBM / L2)
     if (oldInLds) {
         for (unsigned i = tid; i < oldTotal; i += nt) {
             const unsigned k = g.ws_key[wo + i];
@@ -263,7 +270,8 @@ __global__ void __launch_bounds__(WIDE ? 64 : 64 * KB_MAX_WAVES, WIDE ? 2 : KB_M
             if (b >= N) continue;
             float bvx = 0.0f, bvy = 0.0f, bww = 0.0f;
             const float bx = pos[b].x, by = pos[b].y;
-            start[b].x = bx; start[b].y = by; sth0[q] = th[q];
+            if (!COMPACT) { start[b].x = bx; start[b].y = by; }
+            sth0[q] = th[q];
             if (drive) {
                 const float t = th[q];
                 float lval = 0.0f, lgx = 0.0f, lgy = 0.0f;
@@ -621,7 +629,7 @@ __global__ void __launch_bounds__(WIDE ? 64 : 64 * KB_MAX_WAVES, WIDE ? 2 : KB_M
             parent[b] = r;   // only ever replaces an ancestor by an older ancestor: concurrent walks stay valid
             islCnt[b] = 0;
             islWave[b] = (unsigned char)((unsigned)b % (unsigned)nw);
-            head[cellOf[b]] = EMPTY16;
+            if (!COMPACT) head[cellOf[b]] = EMPTY16;     // (compact image: the area becomes the bucket tables; cleared at the end)
             active[b] = 1; active[NB + b] = 0;
             if (SENSE && p.sense_s > 0 && drive) g.nbr_count[o + b] = (unsigned)newOff[b];
         }
@@ -637,7 +645,7 @@ __global__ void __launch_bounds__(WIDE ? 64 : 64 * KB_MAX_WAVES, WIDE ? 2 : KB_M
             active[b] = 1; active[NB + b] = 0;
         }
         const unsigned newTotal = block_scan_u8(wsCntNew, newOff, NP, wsum);   // (barriers inside)
-        const bool newInLds = newTotal <= (unsigned)capL_;
+        const bool newInLds = !COMPACT && newTotal <= (unsigned)capL_;
         if (OBJ && wave == 0) {   // island of every manifold constraint
             unsigned root = 0;
             const bool on = lane < NMC && mcTouch;
@@ -1204,6 +1212,7 @@ __global__ void __launch_bounds__(WIDE ? 64 : 64 * KB_MAX_WAVES, WIDE ? 2 : KB_M
                 const int b = tid + q * nt;
                 if (b >= N) continue;
                 float vxx = vel[b].x, vyy = vel[b].y, ww = bw[q];
+                if (COMPACT) { startX[b] = pos[b].x; startY[b] = pos[b].y; }     // pose at the start of the substep (continuous step)
                 const float tx = h * vxx, ty = h * vyy;
                 if (tx * tx + ty * ty > B2_MAX_TRANSLATION_SQ) {
                     const float ratio = B2_MAX_TRANSLATION / sqrtf(tx * tx + ty * ty);
@@ -1472,6 +1481,7 @@ __global__ void __launch_bounds__(WIDE ? 64 : 64 * KB_MAX_WAVES, WIDE ? 2 : KB_M
                     const int b = tid + q * nt;
                     if (b >= N) continue;
                     float vxx = vel[b].x, vyy = vel[b].y, ww = bw[q];
+                    if (COMPACT) { startX[b] = pos[b].x; startY[b] = pos[b].y; }
                     const float tx = h * vxx, ty = h * vyy;
                     if (tx * tx + ty * ty > B2_MAX_TRANSLATION_SQ) {
                         const float ratio = B2_MAX_TRANSLATION / sqrtf(tx * tx + ty * ty);
@@ -1593,7 +1603,8 @@ __global__ void __launch_bounds__(WIDE ? 64 : 64 * KB_MAX_WAVES, WIDE ? 2 : KB_M
         // a candidate list (in the staging area, idle after the solve) and processed one per thread, so that
         // the event logic exists once in the kernel instead of once per unrolled bot slot.
         if (p.toi_walls) {
-            float *cTh0 = reinterpret_cast<float *>(lInfo), *cTh = lAcc, *cW = reinterpret_cast<float *>(lCbk);
+            // (compact image: lCbk lies over nextb, where the start positions are by now; the order list is idle as well)
+            float *cTh0 = reinterpret_cast<float *>(lInfo), *cTh = lAcc, *cW = reinterpret_cast<float *>(COMPACT ? lOrder : lCbk);
             int cand[BPT];
             if (tid == 0) misc[M_NCON] = 0;
             __syncthreads();
@@ -1603,7 +1614,7 @@ __global__ void __launch_bounds__(WIDE ? 64 : 64 * KB_MAX_WAVES, WIDE ? 2 : KB_M
                 cand[q] = -1;
                 if (b >= N) continue;
                 const float total = p.r_bot + B2_POLYGON_RADIUS;
-                const float xa = start[b].x, ya = start[b].y, xb = pos[b].x, yb = pos[b].y;
+                const float xa = COMPACT ? startX[b] : start[b].x, ya = COMPACT ? startY[b] : start[b].y, xb = pos[b].x, yb = pos[b].y;
                 const float m0 = fminf(fminf(xa - p.xmin, p.xmax - xa), fminf(ya - p.ymin, p.ymax - ya));
                 const float m1 = fminf(fminf(xb - p.xmin, p.xmax - xb), fminf(yb - p.ymin, p.ymax - yb));
                 if (m0 > total && m1 > total) continue;          // stays clear of every wall: no event possible
@@ -1619,7 +1630,7 @@ __global__ void __launch_bounds__(WIDE ? 64 : 64 * KB_MAX_WAVES, WIDE ? 2 : KB_M
                 float R = p.r_bot, im = p.im_bot;
                 asm volatile("" : "+v"(R), "+v"(im));   // per-lane copies: keeps the two constants out of the scalar file over the event loop
                 float x_ = pos[b].x, y_ = pos[b].y, a_ = cTh[i], vx_ = vel[b].x, vy_ = vel[b].y, w_ = cW[i];
-                kb_toi_walls_body(p, R, im, start[b].x, start[b].y, cTh0[i], x_, y_, a_, vx_, vy_, w_);
+                kb_toi_walls_body(p, R, im, COMPACT ? startX[b] : start[b].x, COMPACT ? startY[b] : start[b].y, cTh0[i], x_, y_, a_, vx_, vy_, w_);
                 pos[b].x = x_; pos[b].y = y_; vel[b].x = vx_; vel[b].y = vy_; cTh[i] = a_; cW[i] = w_;
             }
             if (OBJ && tid < M) {   // objects: the TOI sub-solve runs on the manifold-constraint records of their wall contacts
@@ -1645,6 +1656,7 @@ __global__ void __launch_bounds__(WIDE ? 64 : 64 * KB_MAX_WAVES, WIDE ? 2 : KB_M
         }
         // the new warm-start list becomes the old one
         for (int b = tid; b < NP; b += nt) { wsCnt[b] = wsCntNew[b]; wsOff[b] = newOff[b]; }
+        if (COMPACT) for (int c = tid; c < p.ncell; c += nt) head[c] = EMPTY16;     // the bucket tables lay over the cell heads
         oldInLds = newInLds;
         oldTotal = newTotal;
         __syncthreads();

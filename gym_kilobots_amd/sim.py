@@ -112,6 +112,15 @@ class KilobotSim:
         return self._lib.kb_lds_bytes(self._h)
 
     @property
+    def resident_envs_per_cu(self):
+        """Workgroups (= envs) of this sim's kernel that one CU holds at a time (HIP occupancy query)."""
+        with torch.cuda.device(self.device):
+            n = self._lib.kb_resident_envs_per_cu(self._h)
+        if n < 0:
+            nat.check(n, 'kb_resident_envs_per_cu')
+        return n
+
+    @property
     def contact_capacity(self):
         return self._lib.kb_contact_capacity(self._h)
 
