@@ -169,9 +169,14 @@ class KilobotsEnv(object):
             elif isinstance(self._light, GradientLight):
                 light = self._sim.light_x.double().cpu().numpy()[:, None]
             else:
-                parts = [self._sim.light_x, self._sim.light_y]
-                l = torch.stack([p_.reshape(self.num_envs, -1) for p_ in parts], -1).double().cpu().numpy()
-                light = l.reshape(self.num_envs, -1)
+                # per env the concatenation of every component's get_state(): (x, y), or (x, y, vx, vy) for a MomentumLight
+                # (light.py:256-257, 318-319) -- the same layout as the single-env path
+                comps = self._light.lights if isinstance(self._light, CompositeLight) else (self._light,)
+                cols = []
+                for i, c in enumerate(comps):
+                    names = ('light_x', 'light_y') + (('light_vx', 'light_vy') if isinstance(c, MomentumLight) else ())
+                    cols += [getattr(self._sim, n).reshape(self.num_envs, -1)[:, i] for n in names]
+                light = torch.stack(cols, -1).double().cpu().numpy()
         objs = np.array([])
         if self._objects:
             op = self._sim.object_poses().cpu().numpy().astype(np.float64)

@@ -191,3 +191,36 @@ def test_user_programmed_kilobots_are_refused():
     env = make(Plain)
     env.reset()
     assert env.kilobots[0].get_motors() == (0, 200)
+
+
+def test_multi_env_light_state_has_the_single_env_layout():
+    """with num_envs > 1 the state of a MomentumLight must keep its velocity, (x, y, vx, vy) per component,
+    exactly like the single-env path (reference light.py:318-319, 256-257)."""
+    from gym_kilobots_amd.envs import KilobotsEnv
+    from gym_kilobots_amd.lib import SimplePhototaxisKilobot, MomentumLight, CircularGradientLight, CompositeLight
+    from tests.oracle_backend import OracleBackend
+
+    def make(num_envs, composite):
+        class Env(KilobotsEnv):
+            def _configure_environment(self):
+                m = MomentumLight(position=np.array([0.1, -0.05]), radius=0.3)
+                self._light = CompositeLight([CircularGradientLight(position=np.array([-0.2, 0.0]), radius=0.25), m]) if composite else m
+                for x in (-0.1, 0.0, 0.1):
+                    self._add_kilobot(SimplePhototaxisKilobot(self.world, position=(x, 0.2), light=self._light))
+
+            def get_reward(self, *a):
+                return 0.0
+        return Env(num_envs=num_envs, sim_factory=OracleBackend)
+    for composite in (False, True):
+        one, many = make(1, composite), make(3, composite)
+        one.reset()
+        many.reset()
+        adim = one.action_space.shape[0]
+        a = np.linspace(0.004, 0.01, adim)
+        for _ in range(3):
+            s1, *_ = one.step(a)
+            s3, *_ = many.step(a)
+        assert s1['light'].shape == ((6,) if composite else (4,))
+        assert s3['light'].shape == (3, 6 if composite else 4)
+        assert np.allclose(s3['light'], s1['light'][None], atol=1e-7)
+        assert np.abs(s1['light'][-2:]).max() > 0          # the momentum light moves
