@@ -445,6 +445,7 @@ __device__ __forceinline__ unsigned kb_exch16(unsigned short *base, int idx, uns
 __device__ __noinline__ void kb_sense_pass(const float2 *pos, const unsigned short *head, const unsigned short *nextb,
                                            const unsigned short *cellOf, unsigned *cnt16, int N, int nt, int tid,
                                            int gw, int gh, int s, float R2) {
+    constexpr int W = 8;      // list heads fetched together (one LDS round trip); most cells are empty
     for (int a = tid; a < N; a += nt) {
         const int cell = cellOf[a];
         const int cx = cell % gw, cy = cell / gw;
@@ -453,22 +454,27 @@ __device__ __noinline__ void kb_sense_pass(const float2 *pos, const unsigned sho
         for (int dy = 0; dy <= s; ++dy) {
             const int oy = cy + dy;
             if (oy >= gh) break;
-            for (int dx = (dy == 0 ? 0 : -s); dx <= s; ++dx) {
-                const int ox = cx + dx;
-                if (ox < 0 || ox >= gw) continue;
-                const bool own = dy == 0 && dx == 0;
-                for (unsigned b = head[oy * gw + ox]; b != (unsigned)EMPTY16;) {
-                    const float2 pb = pos[b];
-                    const unsigned nb = nextb[b];
-                    if (!(own && (int)b <= a)) {
-                        const float ex = pb.x - pa.x, ey = pb.y - pa.y;
-                        const float dd = ex * ex + ey * ey;
-                        if (!(dd > R2)) {
-                            mine++;
-                            atomicAdd(&cnt16[b >> 1], 1u << (16 * (b & 1u)));
+            const int x0 = dy == 0 ? cx : max(cx - s, 0), x1 = min(cx + s, gw - 1);
+            for (int xb = x0; xb <= x1; xb += W) {
+                unsigned cur[W];
+#pragma unroll
+                for (int i = 0; i < W; ++i) cur[i] = xb + i <= x1 ? (unsigned)head[oy * gw + xb + i] : (unsigned)EMPTY16;
+#pragma unroll
+                for (int i = 0; i < W; ++i) {
+                    const bool own = dy == 0 && xb + i == cx;
+                    for (unsigned b = cur[i]; b != (unsigned)EMPTY16;) {
+                        const float2 pb = pos[b];
+                        const unsigned nb = nextb[b];
+                        if (!(own && (int)b <= a)) {
+                            const float ex = pb.x - pa.x, ey = pb.y - pa.y;
+                            const float dd = ex * ex + ey * ey;
+                            if (!(dd > R2)) {
+                                mine++;
+                                atomicAdd(&cnt16[b >> 1], 1u << (16 * (b & 1u)));
+                            }
                         }
+                        b = nb;
                     }
-                    b = nb;
                 }
             }
         }
