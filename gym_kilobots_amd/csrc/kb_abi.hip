@@ -160,6 +160,7 @@ struct kb_sim {
     const void *attr_fn;   // kernel whose dynamic-LDS limit has been raised
     int threads;
     int capL_regular;      // LDS staging entries of the regular image (the compact fixed-size image has its own: ldsc::CAPL)
+    int tier;              // register budget of the kernels without objects: 0 = 128 VGPRs, 2 = 80 VGPRs (6 waves per SIMD)
 };
 
 // dynamic LDS of one env: the bucket tables scale with the waves of the workgroup, the object tables exist only in
@@ -171,9 +172,28 @@ static bool uses_fixed_1024(const kb::Params &p, int threads) {   // the instant
            (p.M > 0 || p.cap == (int)cap1024);      // (without objects the contact capacity is a compile-time constant of the kernel)
 }
 static int lds_bytes_for(const kb::Params &p, int threads, int capL) {
-    if (p.M == 0 && uses_fixed_1024(p, threads)) return kb::ldsc::total(p.NB, p.NP, p.ncell);     // the compact image (capL = ldsc::CAPL)
+    if (p.M == 0) {      // kernels without objects: the compact image (namespace ldsc)
+        const bool fold = uses_fixed_1024(p, threads);
+        return kb::ldsc::total(p.NB, fold ? kb::ldsc::CAPL : capL, p.NP, fold, p.ncell, threads / 64);
+    }
     const bool objarea = p.M > 0 || uses_fixed_1024(p, threads);
     return kb::lds::total(kb::lds::fixed(objarea, threads / 64), p.NB, capL, p.NP, p.ncell, p.nmc);
+}
+
+// workgroups of `threads` threads and `lds` bytes that one CU holds at a register budget of `wps` waves per SIMD
+// (LDS is handed out in granules: an image of 54 544 B got two workgroups per CU, one of 53 168 B three)
+static int resident_envs(int lds, int threads, int wps) {
+    const int LDS_CU = 160 * 1024, GRANULE = 1280;
+    const int byLds = LDS_CU / (((lds + GRANULE - 1) / GRANULE) * GRANULE);
+    const int byWaves = (4 * wps) / (threads / 64);
+    const int n = byLds < byWaves ? byLds : byWaves;
+    return n < 1 ? (byLds >= 1 ? 1 : 0) : n;
+}
+// register budget of a kernel without objects: 80 VGPRs (tier 2) where that holds more envs than 128 VGPRs, and only for
+// workgroups of four waves or more (one- and two-wave envs are LDS-bound before they are register-bound)
+static int pick_tier(const kb::Params &p, int threads, int lds) {
+    if (p.M > 0 || threads < 256) return 0;
+    return resident_envs(lds, threads, KB_COMPACT_WAVES_PER_SIMD) > resident_envs(lds, threads, KB_MIN_WAVES_PER_SIMD) ? 2 : 0;
 }
 
 extern "C" {
@@ -403,8 +423,10 @@ int kb_create(const kb_config *cfg, kb_sim **out) {
         // a resident env (LDS fit vs 16 waves per CU) while many lanes would idle.  kb_set_block_threads overrides.
         int T = 64;
         while (T < p.N && T < 64 * MAX_WAVES) T <<= 1;
-        const int fit = LDS_CU / lds_bytes_for(p, T, p.capL);
-        const int resident = fit < 16 / (T / 64) ? fit : 16 / (T / 64);
+        const int ldsT = lds_bytes_for(p, T, p.capL);
+        const int fit = LDS_CU / ldsT;
+        int resident = resident_envs(ldsT, T, KB_MIN_WAVES_PER_SIMD);
+        if (p.M == 0 && T >= 256 && resident_envs(ldsT, T, KB_COMPACT_WAVES_PER_SIMD) > resident) resident = resident_envs(ldsT, T, KB_COMPACT_WAVES_PER_SIMD);
         if (T > 64 && resident < fit && p.N * 100 < T * 85) T >>= 1;
         // with objects, up to 128 kilobots run as one wave: that selects the spill-free 256-VGPR instantiation
         // (kb_step), measured + 6 ... 9 % at 100 kilobots and - 3 % at 128 against two-wave workgroups
@@ -421,6 +443,7 @@ int kb_create(const kb_config *cfg, kb_sim **out) {
     s->capL_regular = p.capL;
     if (p.M == 0 && uses_fixed_1024(p, s->threads)) p.capL = ldsc::CAPL;
     p.lds_total = lds_bytes_for(p, s->threads, p.capL);
+    s->tier = pick_tier(p, s->threads, p.lds_total);
     if (p.lds_total > LDS_CU) {
         delete s;
         return fail(KB_ELDS, "kb_create: configuration needs more than 160 KiB of LDS per env");
@@ -480,7 +503,7 @@ int kb_set_actions(kb_sim *sim, const float *d_actions, void *stream) {
 // the kernel instantiation of a handle (drive law, light model, objects, workgroup size)
 static kb_step_fn select_kernel(const kb_sim *sim, const kb::Params &p) {
     const bool obj = p.M > 0;
-    int objsel = obj ? (sim->threads <= 64 ? 2 : 1) : 0;     // one-wave workgroups with objects: the 256-VGPR instantiation
+    int objsel = obj ? (sim->threads <= 64 ? 2 : 1) : (sim->tier == 2 ? 3 : 0);     // one-wave workgroups with objects: the 256-VGPR instantiation; no objects: 128 or 80 VGPRs
     // scenes whose objects are all discs: instantiations without the kilobot - polygon contact code (5 / 6)
     bool discs = obj;
     for (int f = 0; f < p.F; ++f) discs = discs && ot_kind(p.otab[f]) == KB_SHAPE_CIRCLE;
@@ -602,6 +625,7 @@ int kb_set_block_threads(kb_sim *sim, int threads) {
     sim->threads = threads;
     sim->p.capL = capL;
     sim->p.lds_total = need;
+    sim->tier = pick_tier(sim->p, threads, need);
     return KB_OK;
 }
 

@@ -119,35 +119,36 @@ __host__ __device__ inline int total(int fx, int NB, int capL, int NP, int ncell
 
 // ---- compact LDS image: three envs of 1024 kilobots per CU --------------------------------------------------------------
 // What decides the throughput of the latency-bound step is how many envs a CU holds (profiles/: waves wait 60 % of their
-// cycles, no pipe is more than a third busy; 3 resident envs instead of 2 gave + 37 % at 480 kilobots).  The fixed-size
-// kernel without objects therefore runs at 80 VGPRs (6 waves per SIMD = three 8-wave workgroups) with an LDS image of
-// <= 54 608 B (a third of 160 KiB) instead of 80 416 B:
+// cycles, no pipe is more than a third busy; 3 resident envs instead of 2 gave + 37 % at 480 kilobots).  Every kernel
+// without objects uses this image; the fixed-size one runs at 80 VGPRs (6 waves per SIMD = three 8-wave workgroups) with
+// 53 168 B instead of 80 416 B, the others pick the register budget that holds more envs (kb_create):
 //   - no image of the previous substep's warm-start list (6 B per entry): the label pass reads the packed list in HBM / L2;
 //   - the poses at the start of the substep (continuous step) are saved at integration time -- they do not change earlier --
 //     into arrays that are dead by then: x over [nextb | cellOf], y over dirCnt;
-//   - the per-contact scratch of the contact sort / slot dealing (lCbk) lies over nextb (dead once the label pass is done
-//     and needed only before the integration);
+//   - fixed-size kernel: the per-contact scratch of the contact sort / slot dealing (lCbk) lies over nextb (dead once the
+//     label pass is done and needed only before the integration; needs capL <= NP);
 //   - the bucket tables of the contact sort / island placement live in the cell-head area, which is dead once the label
 //     pass is done; the heads are cleared as a whole at the end of the substep;
 //   - 688 staged contacts (the settled benchmark scene has 550 +- 20 per env, at most 630 in 4096 envs; envs beyond take
 //     the global staging slice as before); no object tables.
 namespace ldsc {
-constexpr int CAPL = 688;
-constexpr int TABLES = lds::nlist(KB_MAX_WAVES) + 16 - lds::BKSTART;      // bucket tables, relative to the head area
+constexpr int CAPL = 688;                                                   // staged contacts of the fixed-size kernel
+__host__ __device__ constexpr int tables(int nw) { return lds::nlist(nw) + 16 - lds::BKSTART; }   // bucket tables, relative to the head area
 __host__ __device__ constexpr int pos(int) { return 320; }                 // (MISC 256 + WSUM 64 in front)
 __host__ __device__ constexpr int vel(int NB) { return pos(NB) + 8 * NB; }
 __host__ __device__ constexpr int dircnt(int NB) { return vel(NB) + 8 * NB; }
 __host__ __device__ constexpr int parent(int NB) { return dircnt(NB) + 4 * NB; }
-__host__ __device__ constexpr int con32(int NB, int k) { return parent(NB) + 4 * NB + 4 * CAPL * k; }      // lPair lInfo lAcc
-__host__ __device__ constexpr int con16(int NB, int k) { return con32(NB, 3) + 2 * CAPL * k; }             // lOrder (lCbk: over nextb)
-__host__ __device__ constexpr int bot16(int NB, int NP, int k) { return con16(NB, 1) + 2 * NP * k; }       // wsOff newOff nextb cellOf
-__host__ __device__ constexpr int bot8(int NB, int NP, int k) { return bot16(NB, NP, 4) + NP * k; }        // wsCnt wsCntNew
-__host__ __device__ constexpr int active(int NB, int NP) { return bot8(NB, NP, 2); }
-__host__ __device__ constexpr int islwave(int NB, int NP) { return active(NB, NP) + 2 * NB; }
-__host__ __device__ constexpr int head(int NB, int NP) { return (islwave(NB, NP) + NB + 15) & ~15; }
-__host__ __device__ inline int total(int NB, int NP, int ncell) {
+__host__ __device__ constexpr int con32(int NB, int capL, int k) { return parent(NB) + 4 * NB + 4 * capL * k; }      // lPair lInfo lAcc
+// 16-bit per-contact arrays: lOrder, and lCbk unless it lies over nextb (`fold`: only where capL <= NP, the fixed-size kernel)
+__host__ __device__ constexpr int con16(int NB, int capL, int k) { return con32(NB, capL, 3) + ((2 * capL + 3) & ~3) * k; }
+__host__ __device__ constexpr int bot16(int NB, int capL, int NP, bool fold, int k) { return con16(NB, capL, fold ? 1 : 2) + 2 * NP * k; }   // wsOff newOff nextb cellOf
+__host__ __device__ constexpr int bot8(int NB, int capL, int NP, bool fold, int k) { return bot16(NB, capL, NP, fold, 4) + NP * k; }        // wsCnt wsCntNew
+__host__ __device__ constexpr int active(int NB, int capL, int NP, bool fold) { return bot8(NB, capL, NP, fold, 2); }
+__host__ __device__ constexpr int islwave(int NB, int capL, int NP, bool fold) { return active(NB, capL, NP, fold) + 2 * NB; }
+__host__ __device__ constexpr int head(int NB, int capL, int NP, bool fold) { return (islwave(NB, capL, NP, fold) + NB + 15) & ~15; }
+__host__ __device__ inline int total(int NB, int capL, int NP, bool fold, int ncell, int nw) {
     const int h = (2 * ncell + 4 + 15) & ~15;
-    return head(NB, NP) + (h > TABLES ? h : TABLES);
+    return head(NB, capL, NP, fold) + (h > tables(nw) ? h : tables(nw));
 }
 }  // namespace ldsc
 

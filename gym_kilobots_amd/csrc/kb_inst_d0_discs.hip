@@ -5,12 +5,12 @@
 namespace kb {
 template <int LIGHT_TYPE>
 static kb_step_fn pick(int objects) {    // 5: objects, 6: objects + one-wave workgroup
-    return objects == 6 ? kb_step_kernel<KB_DRIVE_VELOCITY, LIGHT_TYPE, true, 0, true, false>
-                        : kb_step_kernel<KB_DRIVE_VELOCITY, LIGHT_TYPE, true, 0, false, false>;
+    return objects == 6 ? kb_step_kernel<KB_DRIVE_VELOCITY, LIGHT_TYPE, true, 0, 1, false>
+                        : kb_step_kernel<KB_DRIVE_VELOCITY, LIGHT_TYPE, true, 0, 0, false>;
 }
 kb_step_fn kb_pick_velocity_discs(int light_type, int objects) {
-    if (light_type == KB_PICK_FIXED_1024) return kb_step_kernel<KB_DRIVE_VELOCITY, KB_LIGHT_NONE, true, 1024, false, false, false>;
-    if (light_type == KB_PICK_FIXED_1024_SENSE) return kb_step_kernel<KB_DRIVE_VELOCITY, KB_LIGHT_NONE, true, 1024, false, false>;
+    if (light_type == KB_PICK_FIXED_1024) return kb_step_kernel<KB_DRIVE_VELOCITY, KB_LIGHT_NONE, true, 1024, 0, false, false>;
+    if (light_type == KB_PICK_FIXED_1024_SENSE) return kb_step_kernel<KB_DRIVE_VELOCITY, KB_LIGHT_NONE, true, 1024, 0, false>;
     if (light_type == KB_LIGHT_CIRCULAR) return pick<KB_LIGHT_CIRCULAR>(objects);
     if (light_type == KB_LIGHT_NONE) return pick<KB_LIGHT_NONE>(objects);
     return pick<KB_LIGHT_GENERAL>(objects);

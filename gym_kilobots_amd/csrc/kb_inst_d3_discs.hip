@@ -5,8 +5,8 @@
 namespace kb {
 template <int LIGHT_TYPE>
 static kb_step_fn pick(int objects) {    // 5: objects, 6: objects + one-wave workgroup
-    return objects == 6 ? kb_step_kernel<KB_DRIVE_SIMPLE_PHOTOTAXIS, LIGHT_TYPE, true, 0, true, false>
-                        : kb_step_kernel<KB_DRIVE_SIMPLE_PHOTOTAXIS, LIGHT_TYPE, true, 0, false, false>;
+    return objects == 6 ? kb_step_kernel<KB_DRIVE_SIMPLE_PHOTOTAXIS, LIGHT_TYPE, true, 0, 1, false>
+                        : kb_step_kernel<KB_DRIVE_SIMPLE_PHOTOTAXIS, LIGHT_TYPE, true, 0, 0, false>;
 }
 kb_step_fn kb_pick_simple_phototaxis_discs(int light_type, int objects) {
     if (light_type == KB_LIGHT_CIRCULAR) return pick<KB_LIGHT_CIRCULAR>(objects);

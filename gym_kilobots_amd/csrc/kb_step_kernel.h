@@ -19,11 +19,16 @@ namespace kb {
 // SENSE = false: instantiation without the IR-range neighbour sensing hook (the fixed-size kernels are at their register
 // budget: the hook costs them 2 more spilled VGPRs, 20 B/lane of scratch traffic per launch); kb_step picks it when
 // kb_config.sense_radius == 0.
-// The fixed-size kernel without objects uses the compact LDS image (namespace ldsc) and a budget of 80 VGPRs (launch bounds of
-// six waves per SIMD): three envs of 1024 kilobots per CU.
-template <int DRIVE_MODE, int LIGHT_TYPE, bool OBJ, int FN = 0, bool WIDE = false, bool POLY = true, bool SENSE = true>
-__global__ void __launch_bounds__(WIDE ? 64 : 64 * KB_MAX_WAVES, WIDE ? 2 : ((FN != 0 && !OBJ) ? KB_COMPACT_WAVES_PER_SIMD : KB_MIN_WAVES_PER_SIMD)) kb_step_kernel(const Params p) {
-    constexpr bool COMPACT = FN != 0 && !OBJ;
+// Kernels without objects use the compact LDS image (namespace ldsc).  TIER picks the register budget:
+//   0: 128 VGPRs (launch bounds of 4 waves per SIMD);
+//   1: "WIDE", one-wave workgroups in scenes with objects: 256 VGPRs (2 waves per SIMD), no spills;
+//   2: 80 VGPRs (6 waves per SIMD): three 8-wave / six 4-wave workgroups per CU where the LDS image admits them.
+// The fixed-size kernel without objects is always tier 2.
+template <int DRIVE_MODE, int LIGHT_TYPE, bool OBJ, int FN = 0, int TIER = 0, bool POLY = true, bool SENSE = true>
+__global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 ? 2 : ((TIER == 2 || (FN != 0 && !OBJ)) ? KB_COMPACT_WAVES_PER_SIMD : KB_MIN_WAVES_PER_SIMD)) kb_step_kernel(const Params p) {
+    constexpr bool WIDE = TIER == 1;
+    constexpr bool COMPACT = !OBJ;
+    constexpr bool FOLD = FN != 0 && !OBJ;       // lCbk over nextb (needs capL <= NP)
     extern __shared__ __align__(16) unsigned char smem[];
     int e = blockIdx.x;
     int tid = threadIdx.x;
@@ -36,7 +41,7 @@ __global__ void __launch_bounds__(WIDE ? 64 : 64 * KB_MAX_WAVES, WIDE ? 2 : ((FN
     const float h = p.h;
 
     const int NB = FN ? ((FN + 3) & ~3) + KB_MAX_OBJECTS + 4 : p.NB;
-    const int capL_ = COMPACT ? ldsc::CAPL : p.capL;
+    const int capL_ = FOLD ? ldsc::CAPL : p.capL;
     // LDS arrays (offsets: namespace lds in kb_common.h)
     // (the fixed-size instantiations keep room for the object tables even without objects: all their offsets are
     //  compile-time constants either way, two envs per CU fit both ways, and this image measured 1 % faster)
@@ -46,21 +51,22 @@ __global__ void __launch_bounds__(WIDE ? 64 : 64 * KB_MAX_WAVES, WIDE ? 2 : ((FN
     float2 *start = (float2 *)(smem + lds::body32(fx, NB, 4));      // (not in the compact image: startX / startY below)
     unsigned *dirCnt = (unsigned *)(smem + (COMPACT ? ldsc::dircnt(NB) : lds::body32(fx, NB, 6))), *parent = (unsigned *)(smem + (COMPACT ? ldsc::parent(NB) : lds::body32(fx, NB, 7)));
     unsigned *islCnt = dirCnt;  // alias: dirCnt is dead once the contacts are emitted
-    unsigned *lPair = (unsigned *)(smem + (COMPACT ? ldsc::con32(NB, 0) : lds::con32(fx, NB, capL_, 0))), *lInfo = (unsigned *)(smem + (COMPACT ? ldsc::con32(NB, 1) : lds::con32(fx, NB, capL_, 1)));
-    float *lAcc = (float *)(smem + (COMPACT ? ldsc::con32(NB, 2) : lds::con32(fx, NB, capL_, 2))), *oldAcc = (float *)(smem + lds::con32(fx, NB, capL_, 3));
-    unsigned short *lCbk = (unsigned short *)(smem + (COMPACT ? ldsc::bot16(NB, NP, 2) : lds::con16(fx, NB, capL_, 0))), *lOrder = (unsigned short *)(smem + (COMPACT ? ldsc::con16(NB, 0) : lds::con16(fx, NB, capL_, 1)));
+    unsigned *lPair = (unsigned *)(smem + (COMPACT ? ldsc::con32(NB, capL_, 0) : lds::con32(fx, NB, capL_, 0))), *lInfo = (unsigned *)(smem + (COMPACT ? ldsc::con32(NB, capL_, 1) : lds::con32(fx, NB, capL_, 1)));
+    float *lAcc = (float *)(smem + (COMPACT ? ldsc::con32(NB, capL_, 2) : lds::con32(fx, NB, capL_, 2))), *oldAcc = (float *)(smem + lds::con32(fx, NB, capL_, 3));
+    unsigned short *lCbk = (unsigned short *)(smem + (COMPACT ? (FOLD ? ldsc::bot16(NB, capL_, NP, FOLD, 2) : ldsc::con16(NB, capL_, 0)) : lds::con16(fx, NB, capL_, 0)));
+    unsigned short *lOrder = (unsigned short *)(smem + (COMPACT ? ldsc::con16(NB, capL_, FOLD ? 0 : 1) : lds::con16(fx, NB, capL_, 1)));
     unsigned short *oldKey = (unsigned short *)(smem + lds::con16(fx, NB, capL_, 2));      // (oldAcc / oldKey: not in the compact image, never touched there)
-    unsigned short *wsOff = (unsigned short *)(smem + (COMPACT ? ldsc::bot16(NB, NP, 0) : lds::bot16(fx, NB, capL_, NP, 0))), *newOff = (unsigned short *)(smem + (COMPACT ? ldsc::bot16(NB, NP, 1) : lds::bot16(fx, NB, capL_, NP, 1)));
-    unsigned short *nextb = (unsigned short *)(smem + (COMPACT ? ldsc::bot16(NB, NP, 2) : lds::bot16(fx, NB, capL_, NP, 2))), *cellOf = (unsigned short *)(smem + (COMPACT ? ldsc::bot16(NB, NP, 3) : lds::bot16(fx, NB, capL_, NP, 3)));
-    unsigned char *wsCnt = smem + (COMPACT ? ldsc::bot8(NB, NP, 0) : lds::bot8(fx, NB, capL_, NP, 0)), *wsCntNew = smem + (COMPACT ? ldsc::bot8(NB, NP, 1) : lds::bot8(fx, NB, capL_, NP, 1));
-    unsigned char *active = smem + (COMPACT ? ldsc::active(NB, NP) : lds::active(fx, NB, capL_, NP));
-    unsigned char *islWave = smem + (COMPACT ? ldsc::islwave(NB, NP) : lds::islwave(fx, NB, capL_, NP));   // wave that sweeps the island rooted at body b
-    unsigned short *head = (unsigned short *)(smem + (COMPACT ? ldsc::head(NB, NP) : lds::head(fx, NB, capL_, NP)));   // per-cell list heads (EMPTY16 = empty)
+    unsigned short *wsOff = (unsigned short *)(smem + (COMPACT ? ldsc::bot16(NB, capL_, NP, FOLD, 0) : lds::bot16(fx, NB, capL_, NP, 0))), *newOff = (unsigned short *)(smem + (COMPACT ? ldsc::bot16(NB, capL_, NP, FOLD, 1) : lds::bot16(fx, NB, capL_, NP, 1)));
+    unsigned short *nextb = (unsigned short *)(smem + (COMPACT ? ldsc::bot16(NB, capL_, NP, FOLD, 2) : lds::bot16(fx, NB, capL_, NP, 2))), *cellOf = (unsigned short *)(smem + (COMPACT ? ldsc::bot16(NB, capL_, NP, FOLD, 3) : lds::bot16(fx, NB, capL_, NP, 3)));
+    unsigned char *wsCnt = smem + (COMPACT ? ldsc::bot8(NB, capL_, NP, FOLD, 0) : lds::bot8(fx, NB, capL_, NP, 0)), *wsCntNew = smem + (COMPACT ? ldsc::bot8(NB, capL_, NP, FOLD, 1) : lds::bot8(fx, NB, capL_, NP, 1));
+    unsigned char *active = smem + (COMPACT ? ldsc::active(NB, capL_, NP, FOLD) : lds::active(fx, NB, capL_, NP));
+    unsigned char *islWave = smem + (COMPACT ? ldsc::islwave(NB, capL_, NP, FOLD) : lds::islwave(fx, NB, capL_, NP));   // wave that sweeps the island rooted at body b
+    unsigned short *head = (unsigned short *)(smem + (COMPACT ? ldsc::head(NB, capL_, NP, FOLD) : lds::head(fx, NB, capL_, NP)));   // per-cell list heads (EMPTY16 = empty)
     // compact image: start-of-substep positions over arrays that are dead from the integration on
     float *startX = reinterpret_cast<float *>(nextb), *startY = reinterpret_cast<float *>(dirCnt);
     unsigned *misc = (unsigned *)(smem + lds::MISC), *wsum = (unsigned *)(smem + lds::WSUM);
     // (compact image: the bucket tables lie over the cell heads, which are dead between the label pass and the next substep)
-    const int tb_ = COMPACT ? ldsc::head(NB, NP) - lds::BKSTART : 0;
+    const int tb_ = COMPACT ? ldsc::head(NB, capL_, NP, FOLD) - lds::BKSTART : 0;
     unsigned *bkStart = (unsigned *)(smem + tb_ + lds::BKSTART), *bkFill = (unsigned *)(smem + tb_ + lds::bkfill(nw));
     unsigned *bkMaxRank = (unsigned *)(smem + tb_ + lds::bkmaxrank(nw));
     unsigned short *bkList = (unsigned short *)(smem + tb_ + lds::bklist(nw));
@@ -1603,8 +1609,8 @@ __global__ void __launch_bounds__(WIDE ? 64 : 64 * KB_MAX_WAVES, WIDE ? 2 : ((FN
         // a candidate list (in the staging area, idle after the solve) and processed one per thread, so that
         // the event logic exists once in the kernel instead of once per unrolled bot slot.
         if (p.toi_walls) {
-            // (compact image: lCbk lies over nextb, where the start positions are by now; the order list is idle as well)
-            float *cTh0 = reinterpret_cast<float *>(lInfo), *cTh = lAcc, *cW = reinterpret_cast<float *>(COMPACT ? lOrder : lCbk);
+            // (fixed-size compact image: lCbk lies over nextb, where the start positions are by now; the order list is idle as well)
+            float *cTh0 = reinterpret_cast<float *>(lInfo), *cTh = lAcc, *cW = reinterpret_cast<float *>(FOLD ? lOrder : lCbk);
             int cand[BPT];
             if (tid == 0) misc[M_NCON] = 0;
             __syncthreads();
@@ -1705,11 +1711,12 @@ __global__ void __launch_bounds__(WIDE ? 64 : 64 * KB_MAX_WAVES, WIDE ? 2 : ((FN
 }
 
 
-// instantiation chooser of the kb_inst_d*.hip units: objects = 0 none, 1 with objects, 2 with objects and a one-wave
-// workgroup (the WIDE instantiation)
+// instantiation chooser of the kb_inst_d*.hip units: objects = 0 none (128 VGPRs), 1 with objects, 2 with objects and a
+// one-wave workgroup (the WIDE instantiation), 3 none at 80 VGPRs (six waves per SIMD)
 template <int DRIVE_MODE, int LIGHT_TYPE>
 static kb_step_fn kb_pick_obj(int objects) {
-    if (objects == 2) return kb_step_kernel<DRIVE_MODE, LIGHT_TYPE, true, 0, true>;
+    if (objects == 2) return kb_step_kernel<DRIVE_MODE, LIGHT_TYPE, true, 0, 1>;
+    if (objects == 3) return kb_step_kernel<DRIVE_MODE, LIGHT_TYPE, false, 0, 2>;
     return objects ? kb_step_kernel<DRIVE_MODE, LIGHT_TYPE, true> : kb_step_kernel<DRIVE_MODE, LIGHT_TYPE, false>;
 }
 

@@ -240,3 +240,27 @@ def test_plotting_snapshot_of_a_real_sim(tmp_path):
     kb_plotting.save_env_png(g.sim, str(out), object_radii=[0.075, 0.05])
     assert out.stat().st_size > 2000
     g.close()
+
+
+def test_three_envs_of_1024_kilobots_resident_per_cu():
+    """The benchmark instantiation holds THREE envs per CU (compact LDS image <= 52 KiB, 80 VGPRs): the HIP occupancy query
+    through the C ABI says so; the other 1024-kilobot configurations keep the regular image and two."""
+    from gym_kilobots_amd.sim import KilobotSim
+    g = KilobotSim(8, 1024)
+    assert g.lds_bytes <= 52 * 1024 and g.resident_envs_per_cu == 3
+    assert KilobotSim(8, 1024, num_objects=4).resident_envs_per_cu == 2
+    assert KilobotSim(8, 1024, contact_capacity=12000).resident_envs_per_cu == 2
+    # and it computes what the regular image computes: the same scene on both, bit for bit, over fused and single substeps
+    xy, th = scenes.lattice_spawn(8, 1024, seed=21, pitch=0.04)
+    big = KilobotSim(8, 1024, contact_capacity=4168)          # one entry more than the default: the generic kernel, 1024 staged contacts
+    assert big.lds_bytes > g.lds_bytes and big.resident_envs_per_cu == 2
+    for s in (g, big):
+        s.set_poses_m(xy, th)
+    for k in range(6):
+        a = dev(scenes.random_actions(8, 1024, seed=70 + k))
+        n = (1, 3, 10)[k % 3]
+        g.step(n, actions=a)
+        big.step(n, actions=a)
+        for f in ('x', 'y', 'theta'):
+            assert torch.equal(getattr(g, f), getattr(big, f)), (k, f)
+    assert int(g.status.max().item()) == 0
