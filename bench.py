@@ -183,11 +183,20 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     dist = None
+    # Rehearsal on a ONE-GPU box (the multi-rank path end to end, ranks sharing cuda:0): KB_BENCH_REHEARSAL=1 maps every
+    # rank to device 0 and uses gloo for the collectives (RCCL refuses two ranks on one device).  Never set by the driver.
+    rehearsal = os.environ.get('KB_BENCH_REHEARSAL') == '1'
+    if rehearsal:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=torch.device('cuda:%d' % local_rank))
+        if rehearsal:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda:%d' % local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda:%d' % local_rank)
+    cdev = torch.device('cpu') if rehearsal else dev          # where the few collective payloads live
 
     from gym_kilobots_amd.sim import KilobotSim
     from gym_kilobots_amd.dist import env_shard, gather_returns
@@ -268,10 +277,10 @@ def main():
     c_after = contacts_per_env(sim)
     rates = [E * N * K / elapsed_local]
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        r = torch.tensor([rates[0]], device=dev, dtype=torch.float64)
+        r = torch.tensor([rates[0]], device=cdev, dtype=torch.float64)
         rl = [torch.zeros_like(r) for _ in range(world)]
         dist.all_gather(rl, r)
         rates = [float(v.item()) for v in rl]
@@ -279,7 +288,7 @@ def main():
 
     # episode returns (negative mean displacement from spawn, a stand-in reward): gathered over RCCL
     ret = -torch.sqrt((sim.x - x0) ** 2 + (sim.y - y0) ** 2).mean(dim=1) / 25.0
-    all_ret = gather_returns(ret, dist)
+    all_ret = gather_returns(ret.to(cdev), dist)
 
     # fused variant: one launch = one env.step = 10 substeps, state LDS-resident in between
     fused = None
@@ -325,7 +334,7 @@ def main():
                                'random velocity-control actions every substep, every env and action set an independent draw; '
                                '1 step = 1 world substep (dt 0.1 s) in 1 launch' % (E, N),
                    'envs_per_gpu': E, 'bots': N, 'total_envs': total_envs, 'substeps_per_launch': 1,
-                   'parallelism': 'env-shard x%d' % world, 'workgroup_threads': sim.block_threads,
+                   'parallelism': 'env-shard x%d' % world + (' (REHEARSAL: all ranks on one GPU, gloo)' if rehearsal else ''), 'workgroup_threads': sim.block_threads,
                    'lds_bytes_per_env': sim.lds_bytes, 'resident_envs_per_cu': sim.resident_envs_per_cu, 'seed': args.seed,
                    'settle_substeps': settled, 'settle_stationary': bool(stationary),
                    'sense_radius_m': args.sense},
