@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(256) kb_sense_kernel(const Params p, const int
         nextb[b] = (unsigned short)kb_exch16(head, cell, (unsigned)b);
     }
     __syncthreads();
-    kb_sense_pass(pos, head, nextb, cellOf, cnt16, N, nt, tid, p.gw, p.gh, s, R2);
+    kb_sense_pass(pos, head, nextb, cellOf, cnt16, N, nt, tid, p.gw, p.gh, s, R2, 0);
     __syncthreads();
     for (int b = tid; b < N; b += nt) out[o + b] = (unsigned)reinterpret_cast<unsigned short *>(cnt16)[b];
 }
@@ -174,10 +174,10 @@ static bool uses_fixed_1024(const kb::Params &p, int threads) {   // the instant
 static int lds_bytes_for(const kb::Params &p, int threads, int capL) {
     if (p.M == 0) {      // kernels without objects: the compact image (namespace ldsc)
         const bool fold = uses_fixed_1024(p, threads);
-        return kb::ldsc::total(p.NB, fold ? kb::ldsc::CAPL : capL, p.NP, fold, p.ncell, threads / 64);
+        return kb::ldsc::total(p.NB, fold ? kb::ldsc::CAPL : capL, p.NP, fold, p.nhead, threads / 64);
     }
     const bool objarea = p.M > 0 || uses_fixed_1024(p, threads);
-    return kb::lds::total(kb::lds::fixed(objarea, threads / 64), p.NB, capL, p.NP, p.ncell, p.nmc);
+    return kb::lds::total(kb::lds::fixed(objarea, threads / 64), p.NB, capL, p.NP, p.nhead, p.nmc);
 }
 
 // workgroups of `threads` threads and `lds` bytes that one CU holds at a register budget of `wps` waves per SIMD
@@ -189,10 +189,9 @@ static int resident_envs(int lds, int threads, int wps) {
     const int n = byLds < byWaves ? byLds : byWaves;
     return n < 1 ? (byLds >= 1 ? 1 : 0) : n;
 }
-// register budget of a kernel without objects: 80 VGPRs (tier 2) where that holds more envs than 128 VGPRs, and only for
-// workgroups of four waves or more (one- and two-wave envs are LDS-bound before they are register-bound)
+// register budget of a kernel without objects: 80 VGPRs (tier 2) where that holds more envs than 128 VGPRs
 static int pick_tier(const kb::Params &p, int threads, int lds) {
-    if (p.M > 0 || threads < 256) return 0;
+    if (p.M > 0) return 0;
     return resident_envs(lds, threads, KB_COMPACT_WAVES_PER_SIMD) > resident_envs(lds, threads, KB_MIN_WAVES_PER_SIMD) ? 2 : 0;
 }
 
@@ -287,6 +286,13 @@ int kb_create(const kb_config *cfg, kb_sim **out) {
         cell *= 2.0f;
     }
     p.ncell = p.gw * p.gh;
+    {   // sparse swarms: a hash table of the cells instead of one list head per cell (kb_step_kernel.h, `hashed`); only where
+        // it at least halves the table, and never for the fixed-size kernel
+        int H = 64;
+        while (H < 2 * cfg->num_bots) H <<= 1;
+        if (2 * H <= p.ncell && cfg->num_bots != 1024) { p.nhead = H; p.hmask = H - 1; }
+        else { p.nhead = p.ncell; p.hmask = 0; }
+    }
     p.h = cfg->dt;
     p.r_bot = cfg->bot_radius * WORLD_SCALE;
     const float m = cfg->bot_density * B2_PI * p.r_bot * p.r_bot;  // b2CircleShape::ComputeMass
@@ -426,7 +432,7 @@ int kb_create(const kb_config *cfg, kb_sim **out) {
         const int ldsT = lds_bytes_for(p, T, p.capL);
         const int fit = LDS_CU / ldsT;
         int resident = resident_envs(ldsT, T, KB_MIN_WAVES_PER_SIMD);
-        if (p.M == 0 && T >= 256 && resident_envs(ldsT, T, KB_COMPACT_WAVES_PER_SIMD) > resident) resident = resident_envs(ldsT, T, KB_COMPACT_WAVES_PER_SIMD);
+        if (p.M == 0 && resident_envs(ldsT, T, KB_COMPACT_WAVES_PER_SIMD) > resident) resident = resident_envs(ldsT, T, KB_COMPACT_WAVES_PER_SIMD);
         if (T > 64 && resident < fit && p.N * 100 < T * 85) T >>= 1;
         // with objects, up to 128 kilobots run as one wave: that selects the spill-free 256-VGPR instantiation
         // (kb_step), measured + 6 ... 9 % at 100 kilobots and - 3 % at 128 against two-wave workgroups

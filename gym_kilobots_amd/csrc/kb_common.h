@@ -171,6 +171,7 @@ struct Params {
     float mu_oo, mu_ow;                       // b2MixFriction: object-object, object-wall
     int nmc;                                  // manifold-constraint candidates: pairs + 4 walls per object
     int lds_total;
+    int nhead, hmask;                         // cell heads: nhead entries; hmask != 0: a hash table of the cells (slot = cell & hmask)
     int sense_s;                              // IR neighbour sensing: reach of the stencil in cells (0 = off)
     float sense_r2;                           // ... and the squared radius in world units
 };
@@ -445,7 +446,7 @@ __device__ __forceinline__ unsigned kb_exch16(unsigned short *base, int idx, uns
 // Out of line: the kernels that never sense do not pay registers for it.
 __device__ __noinline__ void kb_sense_pass(const float2 *pos, const unsigned short *head, const unsigned short *nextb,
                                            const unsigned short *cellOf, unsigned *cnt16, int N, int nt, int tid,
-                                           int gw, int gh, int s, float R2) {
+                                           int gw, int gh, int s, float R2, int hmask) {
     constexpr int W = 8;      // list heads fetched together (one LDS round trip); most cells are empty
     for (int a = tid; a < N; a += nt) {
         const int cell = cellOf[a];
@@ -459,14 +460,17 @@ __device__ __noinline__ void kb_sense_pass(const float2 *pos, const unsigned sho
             for (int xb = x0; xb <= x1; xb += W) {
                 unsigned cur[W];
 #pragma unroll
-                for (int i = 0; i < W; ++i) cur[i] = xb + i <= x1 ? (unsigned)head[oy * gw + xb + i] : (unsigned)EMPTY16;
+                for (int i = 0; i < W; ++i) {      // (hmask: the heads are a hash table of the cells, the walk checks the candidate's cell)
+                    const int c_ = oy * gw + xb + i;
+                    cur[i] = xb + i <= x1 ? (unsigned)head[hmask ? (c_ & hmask) : c_] : (unsigned)EMPTY16;
+                }
 #pragma unroll
                 for (int i = 0; i < W; ++i) {
                     const bool own = dy == 0 && xb + i == cx;
                     for (unsigned b = cur[i]; b != (unsigned)EMPTY16;) {
                         const float2 pb = pos[b];
                         const unsigned nb = nextb[b];
-                        if (!(own && (int)b <= a)) {
+                        if (!(own && (int)b <= a) && (!hmask || (int)cellOf[b] == oy * gw + xb + i)) {
                             const float ex = pb.x - pa.x, ey = pb.y - pa.y;
                             const float dd = ex * ex + ey * ey;
                             if (!(dd > R2)) {

@@ -91,12 +91,18 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
     };
     ObjCtx ox;
     ox.pos = pos; ox.vel = vel; ox.objW = objW; ox.objA = objA; ox.objTab = objTab; ox.objBody = objBody;
-    ox.mc = (float *)(smem + lds::mcarea(fx, NB, capL_, NP, p.ncell));
+    ox.mc = (float *)(smem + lds::mcarea(fx, NB, capL_, NP, p.nhead));
     ox.N = N; ox.MCN = p.nmc; ox.mu_oo = p.mu_oo; ox.mu_ow = p.mu_ow;
     const int NMC = OBJ ? p.nmc : 0;      // manifold-constraint candidates (fixture pairs, fixture-wall)
     const int F = OBJ ? p.F : 0;          // fixtures of the objects (>= M)
 
     const kb_buffers &g = p.buf;
+    // Sparse swarms: the cell heads are a hash table of the cells (slot = cell & hmask, kb_create: a power of two >= 2 N)
+    // instead of one head per cell of the arena -- 2 494 cells of the default arena are 5 KB, 40 % of a 64-kilobot env's
+    // LDS image.  A list may then hold kilobots of several cells: every walk checks the candidate's own cell.  The set of
+    // contacts and their canonical order (which use the cell coordinates) do not change.
+    const bool hashed = FN == 0 && p.hmask != 0;
+    auto hix = [&](int cell_) __attribute__((always_inline)) -> int { return hashed ? (cell_ & p.hmask) : cell_; };
     // contact staging in global scratch, used when an env has more contacts than fit the LDS staging area
     unsigned *gPair, *gInfo;
     float *gAcc;
@@ -185,7 +191,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
     // manifold-constraint candidate t (object pair / object-wall) is looked after by lane t of wave 0
     bool mcTouch = false;
     float *owsMine = nullptr;
-    for (int c = tid; c < p.ncell; c += nt) head[c] = EMPTY16;
+    for (int c = tid; c < p.nhead; c += nt) head[c] = EMPTY16;
     if (tid == 0) misc[M_STATUS] = 0;
     float lx = 0.0f, ly = 0.0f;
     if (LIGHT_TYPE == KB_LIGHT_CIRCULAR) { lx = g.light_x[e]; ly = g.light_y[e]; }
@@ -364,7 +370,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
             cy = cy < 0 ? 0 : (cy >= p.gh ? p.gh - 1 : cy);
             const int cell = cy * p.gw + cx;
             cellOf[b] = (unsigned short)cell;
-            nextb[b] = (unsigned short)kb_exch16(head, cell, (unsigned)b);
+            nextb[b] = (unsigned short)kb_exch16(head, hix(cell), (unsigned)b);
             if (SENSE && p.sense_s > 0) newOff[b] = 0;       // (dead until the scan behind the label pass: the neighbour counters of the sensing pass)
         }
         if (tid < M) { start[N + tid].x = pos[N + tid].x; start[N + tid].y = pos[N + tid].y; objA0[tid] = objA[tid]; }
@@ -381,7 +387,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
         // ---- IR-range neighbour sensing (kb_config.sense_radius): at the sensing point of the substep, like the light
         //      (kilobots_env.py:174-180), off the cell lists that the contact search uses ----
         if (SENSE && p.sense_s > 0 && drive)
-            kb_sense_pass(pos, head, nextb, cellOf, reinterpret_cast<unsigned *>(newOff), N, nt, tid, p.gw, p.gh, p.sense_s, p.sense_r2);
+            kb_sense_pass(pos, head, nextb, cellOf, reinterpret_cast<unsigned *>(newOff), N, nt, tid, p.gw, p.gh, p.sense_s, p.sense_r2, hashed ? p.hmask : 0);
         // object-object / object-wall manifolds (b2Contact::Update) + their velocity-constraint set-up: candidate t
         // is lane t of wave 0; the record lives in LDS, the previous substep's impulses come from g.ows_acc
         if (OBJ && wave == 0) {
@@ -404,11 +410,13 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
                 const float ax = pos[a].x, ay = pos[a].y;
                 unsigned cnt = 0, mine = 0;
                 unsigned hd[5];      // heads of the five cell lists, fetched together (one LDS round trip)
+                int tcell[5];        // (hashed heads: the cell a candidate must be in)
 #pragma unroll
                 for (int k = 0; k < 5; ++k) {
                     const int ox = cx + dir_dx(k), oy = cy + dir_dy(k);
                     const bool in = ox >= 0 && ox < p.gw && oy < p.gh;
-                    hd[k] = in ? (unsigned)head[in ? oy * p.gw + ox : cell] : (unsigned)EMPTY16;
+                    tcell[k] = in ? oy * p.gw + ox : cell;
+                    hd[k] = in ? (unsigned)head[hix(tcell[k])] : (unsigned)EMPTY16;
                 }
                 // the five lists are walked in lockstep: one LDS round trip serves the next candidate of every list that
                 // still has one (lists that have ended re-read the kilobot itself), so the trips of this pass are the
@@ -418,16 +426,18 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
                        hd[3] != (unsigned)EMPTY16 || hd[4] != (unsigned)EMPTY16) {
                     float2 pbk[5];
                     unsigned nbk[5];
+                    int cbk_[5];
 #pragma unroll
                     for (int k = 0; k < 5; ++k) {
                         const unsigned bb = hd[k] != (unsigned)EMPTY16 ? hd[k] : (unsigned)a;
                         pbk[k] = pos[bb]; nbk[k] = nextb[bb];
+                        cbk_[k] = hashed ? (int)cellOf[bb] : tcell[k];
                     }
 #pragma unroll
                     for (int k = 0; k < 5; ++k) {
                         const unsigned b = hd[k];
                         if (b == (unsigned)EMPTY16) continue;
-                        if (!(k == 0 && (int)b <= a)) {
+                        if (!(k == 0 && (int)b <= a) && cbk_[k] == tcell[k]) {
                             const float dx = pbk[k].x - ax, dy = pbk[k].y - ay;
                             const float dd = dx * dx + dy * dy;
                             if (!(dd > rr2)) {  // b2CollideCircles
@@ -603,14 +613,14 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
                     for (int k2 = 0; k2 < k; ++k2) sbase += (int)((dc >> (6 * k2)) & 63u);
                     // rank base: contacts of this (cell, direction) group owned by lower-id bots of the cell
                     int rbase = 0;
-                    for (unsigned a2 = head[cell]; a2 != (unsigned)EMPTY16; a2 = nextb[a2])
-                        if ((int)a2 < a) rbase += (int)((dirCnt[a2] >> (6 * k)) & 63u);
+                    for (unsigned a2 = head[hix(cell)]; a2 != (unsigned)EMPTY16; a2 = nextb[a2])
+                        if ((int)a2 < a && (!hashed || (int)cellOf[a2] == cell)) rbase += (int)((dirCnt[a2] >> (6 * k)) & 63u);
                     // position of b among a's touching partners of this direction, in ascending id order
                     int j = 0;
                     if (((dc >> (6 * k)) & 63u) > 1u) {
                         const int oc = (cy + dir_dy(k)) * p.gw + (cx + dir_dx(k));
-                        for (unsigned b2 = head[oc]; b2 != (unsigned)EMPTY16; b2 = nextb[b2]) {
-                            if (b2 >= b || (k == 0 && (int)b2 <= a)) continue;
+                        for (unsigned b2 = head[hix(oc)]; b2 != (unsigned)EMPTY16; b2 = nextb[b2]) {
+                            if (b2 >= b || (k == 0 && (int)b2 <= a) || (hashed && (int)cellOf[b2] != oc)) continue;
                             const float2 pb2 = pos[b2];
                             const float ex = pb2.x - ax, ey = pb2.y - ay;
                             if (!(ex * ex + ey * ey > rr2)) j++;
@@ -650,7 +660,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
             parent[b] = r;   // only ever replaces an ancestor by an older ancestor: concurrent walks stay valid
             islCnt[b] = 0;
             islWave[b] = (unsigned char)((unsigned)b % (unsigned)nw);
-            if (!COMPACT) head[cellOf[b]] = EMPTY16;     // (compact image: the area becomes the bucket tables; cleared at the end)
+            if (!COMPACT) head[hix(cellOf[b])] = EMPTY16;     // (compact image: the area becomes the bucket tables; cleared at the end)
             active[b] = 1; active[NB + b] = 0;
             if (SENSE && p.sense_s > 0 && drive) g.nbr_count[o + b] = (unsigned)newOff[b];
         }
@@ -1677,7 +1687,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
         }
         // the new warm-start list becomes the old one
         for (int b = tid; b < NP; b += nt) { wsCnt[b] = wsCntNew[b]; wsOff[b] = newOff[b]; }
-        if (COMPACT) for (int c = tid; c < p.ncell; c += nt) head[c] = EMPTY16;     // the bucket tables lay over the cell heads
+        if (COMPACT) for (int c = tid; c < p.nhead; c += nt) head[c] = EMPTY16;     // the bucket tables lay over the cell heads
         oldInLds = newInLds;
         oldTotal = newTotal;
         __syncthreads();
