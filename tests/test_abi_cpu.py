@@ -103,6 +103,26 @@ def test_largest_config_fits_lds(lib):
     lib.kb_destroy(h)
 
 
+def test_lds_images_of_the_round_two_layouts(lib):
+    """Residency is what decides throughput: the compact image of the kernels without objects, the
+    hashed cell heads of sparse swarms and the folded staging of the fixed-size kernel keep their sizes."""
+    h = C.c_void_p()
+
+    def lds(n, **kw):
+        cfg = nat.default_config(4096, n, **kw)
+        assert lib.kb_create(C.byref(cfg), C.byref(h)) == 0
+        v = lib.kb_lds_bytes(h)
+        lib.kb_destroy(h)
+        return v
+    assert lds(1024) <= 52 * 1024                      # three envs per CU (the hardware hands LDS out in granules: < 53 248)
+    assert lds(1024, num_objects=4) <= 80 * 1024       # two
+    assert lds(1024, contact_capacity=12000) <= 64 * 1024
+    assert lds(64) <= 8192 + 512 and lds(16) <= 5632   # hashed cell heads: 20 / 24+ one-wave envs per CU
+    assert lds(512) <= 40 * 1024 and lds(768) <= 52 * 1024
+    # a small arena has fewer cells than the hash table would have entries: plain heads, still the compact image
+    assert lds(100, world_width=0.6, world_height=0.6) <= lds(100)
+
+
 def test_sim_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():
