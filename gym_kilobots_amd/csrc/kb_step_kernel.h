@@ -246,12 +246,11 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
     KB_STAMP(13);    // kernel start: state loads, warm-start scan and list load
     for (int sub = 0; sub < p.n_substeps; ++sub) {
         KB_ENV_ADDRESSES();
-        {   // the thread index is re-read every substep: predicates derived from it are then evaluated where they are
-            // used (one compare) instead of being hoisted out of the substep loop and kept in spilled scalar registers
-            int t_ = threadIdx.x;
-            if (FN == 0 || OBJ) asm volatile("" : "+v"(t_));     // (the fixed-size instantiation without objects has registers to spare)
-            tid = t_; lane = t_ & 63; wave = t_ >> 6;
-        }
+        // The thread index is re-read (through an opaque copy) at the top of every substep and of every phase: addresses
+        // and predicates derived from it are then computed where they are used instead of being kept alive -- in spilled
+        // registers -- across the phases.  (In the 80-VGPR kernel this alone took the spills from 35 to 11 VGPRs.)
+#define KB_RETID() do { int t_ = threadIdx.x; asm volatile("" : "+v"(t_)); tid = t_; lane = t_ & 63; wave = t_ >> 6; } while (0)
+        KB_RETID();
         // ---- light.step: SinglePositionLight.step, light.py:59-75 (uniform per env) ----
         if (p.light_action && LGEN && drive) {
             // Light.step of every component: light.py:59-75 (positional), 300-316 (momentum), 237-253 (gradient)
@@ -384,6 +383,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
         KB_STAMP_PRE(16);
         __syncthreads();
         KB_STAMP(0);
+        KB_RETID();
         // ---- IR-range neighbour sensing (kb_config.sense_radius): at the sensing point of the substep, like the light
         //      (kilobots_env.py:174-180), off the cell lists that the contact search uses ----
         if (SENSE && p.sense_s > 0 && drive)
@@ -514,6 +514,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
             __syncthreads();
         }
         KB_STAMP(1);
+        KB_RETID();
         const int stageCap = big ? p.cap : capL_;
         if ((int)misc[M_NCON] > stageCap && tid == 0) atomicOr(&misc[M_STATUS], 1u);
         const int ncon = min((int)misc[M_NCON], stageCap);
@@ -652,6 +653,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
         KB_STAMP_PRE(18);
         __syncthreads();
         KB_STAMP(2);
+        KB_RETID();
 
         // ---- islands: flatten roots; empty the grid for the next substep; offsets of the new ws list ----
         for (int b = tid; b < N; b += nt) {
@@ -683,6 +685,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
             if (on) { root = parent[mci(ox, MC_B, lane)]; mci_set(ox, MC_ISL, lane, (int)root); }
         }
         KB_STAMP(14);    // flatten roots + warm-start offset scan
+        KB_RETID();
         // per contact: island size (giant islands force the cooperative sweep) and contacts per wave
         auto census = [&](const unsigned *sPair) __attribute__((always_inline)) {
             for (int c = tid; c < ncon; c += nt) {
@@ -896,6 +899,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
         } else if (big) bucket_sort(gPair, gInfo, gCbk, gOrder);
         else bucket_sort(lPair, lInfo, lCbk, lOrder);
         KB_STAMP(3);
+        KB_RETID();
 
         if (reg) {
             // =========================== register-resident solver ===========================
@@ -1216,6 +1220,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
             }
             __syncthreads();
             KB_STAMP(4);
+            KB_RETID();
             mc_store();
 #ifdef KB_PROFILE
             if (tid == 0) prof_acc[9] += misc[M_PROF];   // deepest wave of the env (replaces the contacts-per-wave slot)
@@ -1274,6 +1279,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
             }
             __syncthreads();
             KB_STAMP(5);
+            KB_RETID();
             // SolvePositionConstraints; an island stops once its minSeparation >= -3 slop.  The island flags are read
             // once per iteration; depth levels without an active contact in this wave are skipped altogether.
             for (int it = 0; it < p.pos_iters; ++it) {
@@ -1485,6 +1491,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
                 }
                 __syncthreads();
                 KB_STAMP(4);
+                KB_RETID();
                 mc_store();
                 // StoreImpulses -> packed warm-start list of the next substep
                 const bool last = sub == p.n_substeps - 1;
@@ -1543,6 +1550,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
                 }
                 __syncthreads();
                 KB_STAMP(5);
+                KB_RETID();
                 // SolvePositionConstraints; an island stops once its minSeparation >= -3 slop
                 for (int it = 0; it < p.pos_iters; ++it) {
                     unsigned char *act = active + (it & 1) * NB, *nxt = active + ((it + 1) & 1) * NB;
@@ -1629,6 +1637,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
             if (big) solve_list(gPair, gInfo, gAcc, gCbk, gOrder); else solve_list(lPair, lInfo, lAcc, lCbk, lOrder);
         }
         __syncthreads();
+        KB_RETID();
         // ---- b2World::SolveTOI: continuous step of every dynamic body against the static walls ----
         // Only bodies that come within their contact radius of a wall can have a TOI event.  They are collected in
         // a candidate list (in the staging area, idle after the solve) and processed one per thread, so that
