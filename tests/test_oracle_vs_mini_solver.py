@@ -4,7 +4,8 @@ oracle/kb_oracle.c and the HIP kernel are twins of one restatement, so their bit
 transcription error of Box2D.  tools/box2d_mini.py is a separate float32 restatement written in Box2D's own structure
 (bodies, fixtures, persistent contacts in creation order, b2ContactSolver per contact); tests/golden/mini_solver.json holds
 its trajectories for small scenes (circle-circle, circle-wall, polygon-circle with lever arm, box-wall with the two-point
-block solver and friction, disc-disc with friction, box-box).  The oracle must follow them within a float32 tolerance
+block solver and friction, disc-disc with friction, box-box, and -- scenes `*__toi` -- the continuous step of kilobots and
+discs against the walls: b2TimeOfImpact, Advance, the TOI sub-solve; without it the oracle is 150 .. 18 000 tolerances away).  The oracle must follow them within a float32 tolerance
 (stated per scene in the fixture: 2e-5 .. 2e-4 world units = 1 .. 8 micrometres for single-contact scenes, where the
 sweep order cannot matter; 2e-3 for scenes with several contacts, where Box2D's creation order and the oracle's canonical
 order legitimately differ).  box2d-py itself cannot be installed here: row a10 stays "parity unpinned" (DESIGN.md)."""
@@ -22,7 +23,7 @@ FIX = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'mini_solver.json')))
 
 def _oracle_for(sc):
     objs = sc['objects']
-    kw = dict(toi_walls=0, damping_model=1 if sc['damping'] == 'linear' else 0)
+    kw = dict(toi_walls=1 if sc.get('toi') else 0, damping_model=1 if sc['damping'] == 'linear' else 0)
     if objs:
         pad = O.MAX_OBJECTS - len(objs)
         kw.update(num_objects=len(objs),

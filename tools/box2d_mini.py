@@ -12,7 +12,11 @@ It is NOT Box2D: box2d-py cannot be installed here, so this is still a restateme
 What it buys is independence: two derivations agreeing on contact manifolds, effective masses, the friction / block
 solver, warm starting by feature id, position correction and the integrator.
 
-Scope: b2World::Step(dt, velIters, posIters) with continuousPhysics = False, allowSleep = False, no gravity, no joints:
+Scope: b2World::Step(dt, velIters, posIters) with allowSleep = False, no gravity, no joints; continuousPhysics optional
+(World(continuous=True)): b2World::SolveTOI for CIRCLES against the static edges (non-bullet bodies only meet static bodies
+there): b2TimeOfImpact with the closed-form circle-centre / edge separation, b2Body::Advance, the TOI mini-island with
+b2ContactSolver::SolveTOIPositionConstraints (Baumgarte 0.75, 20 iterations), a velocity solve without warm starting and the
+integration of the rest of the step; polygons take no part in the continuous step here.  Discrete step:
   b2CollideCircles, b2CollidePolygonAndCircle, b2CollidePolygons, b2CollideEdgeAndCircle, b2CollideEdgeAndPolygon for a
   lone edge (no ghost vertices), b2Contact::Update (impulses carried over by feature id), b2Island::Solve (damping model
   selectable: Pade of 2.3.1 or the clamped linear form of 2.3.0), b2ContactSolver (friction, restitution threshold,
@@ -36,6 +40,9 @@ MAX_LINEAR_CORRECTION = f32(0.2)
 MAX_TRANSLATION = f32(2.0)
 MAX_ROTATION = f32(0.5) * PI
 EPSILON = f32(1.192092896e-07)
+TOI_BAUMGARTE = f32(0.75)
+MAX_SUB_STEPS = 8
+MAX_TOI_CONTACTS = 32
 MAXFLOAT = f32(3.402823466e+38)
 
 
@@ -227,6 +234,16 @@ class Body:
         self.I = self.inv_I = f32(0.0)
         self.fixtures = []
         self.island_index = -1
+        self.alpha0 = f32(0.0)
+
+    def advance(self, alpha):
+        """b2Body::Advance -> b2Sweep::Advance + SynchronizeTransform"""
+        beta = (f32(alpha) - self.alpha0) / (f32(1.0) - self.alpha0)
+        self.c0 = self.c0 + beta * (self.c - self.c0)
+        self.a0 = self.a0 + beta * (self.a - self.a0)
+        self.alpha0 = f32(alpha)
+        self.c, self.a = self.c0.copy(), self.a0
+        self.synchronize_transform()
 
     def create_fixture(self, shape, density=0.0, friction=0.2, restitution=0.0):
         f = Fixture(self, shape, density, friction, restitution)
@@ -591,6 +608,7 @@ class Contact:
         self.fA, self.fB, self.fn = _evaluate(fA, fB)
         self.manifold = Manifold()
         self.touching = False
+        self.toi, self.toi_valid, self.toi_count = f32(1.0), False, 0
         self.friction = f32(np.sqrt(self.fA.friction * self.fB.friction))          # b2MixFriction
         self.restitution = max(self.fA.restitution, self.fB.restitution)           # b2MixRestitution
 
@@ -615,9 +633,10 @@ class World:
     """b2World with gravity (0, 0), allowSleep False, continuousPhysics False, warmStarting True.
     damping: 'pade' (Box2D >= 2.3.1) or 'linear' (Box2D <= 2.3.0)."""
 
-    def __init__(self, damping='pade'):
+    def __init__(self, damping='pade', continuous=False):
         self.bodies, self.contacts, self.fixtures = [], [], []
         self.damping = damping
+        self.continuous = continuous
         self.inv_dt0 = f32(0.0)
 
     def create_body(self, **kw):
@@ -640,7 +659,119 @@ class World:
             c.update()
         dt_ratio = self.inv_dt0 * dt
         self._solve(dt, dt_ratio, vel_iters, pos_iters)
+        if self.continuous:
+            self._solve_toi(dt, vel_iters)
         self.inv_dt0 = f32(1.0) / dt
+
+    # ------------------------------------------------------------------ b2World::SolveTOI (circles against static edges)
+    def _solve_toi(self, dt, vel_iters):
+        for b in self.bodies:
+            b.alpha0 = f32(0.0)
+        for c in self.contacts:
+            c.toi, c.toi_valid, c.toi_count = f32(1.0), False, 0
+        while True:
+            min_c, min_alpha = None, f32(1.0)
+            for c in self.contacts:
+                if c.toi_count > MAX_SUB_STEPS:
+                    continue
+                if c.toi_valid:
+                    alpha = c.toi
+                else:
+                    bA, bB = c.fA.body, c.fB.body
+                    # non-bullet dynamic bodies only have TOI events with non-dynamic bodies
+                    if (bA.dynamic and bB.dynamic) or not (bA.dynamic or bB.dynamic):
+                        continue
+                    if not (c.fA.shape.kind == 'edge' and c.fB.shape.kind == 'circle'):
+                        continue                                   # (polygons: not covered by this restatement)
+                    alpha0 = max(bA.alpha0, bB.alpha0)
+                    if bA.alpha0 < alpha0:
+                        bA.advance(alpha0)
+                    elif bB.alpha0 < alpha0:
+                        bB.advance(alpha0)
+                    state, beta = time_of_impact_edge_circle(c.fA.shape, bA, c.fB.shape, bB)
+                    alpha = min(alpha0 + (f32(1.0) - alpha0) * beta, f32(1.0)) if state == 'touching' else f32(1.0)
+                    c.toi, c.toi_valid = alpha, True
+                if alpha < min_alpha:
+                    min_c, min_alpha = c, alpha
+            if min_c is None or f32(1.0) - f32(10.0) * EPSILON < min_alpha:
+                break
+            bA, bB = min_c.fA.body, min_c.fB.body
+            backup = [(b, b.c0.copy(), b.a0, b.c.copy(), b.a, b.alpha0) for b in (bA, bB)]
+            bA.advance(min_alpha)
+            bB.advance(min_alpha)
+            min_c.update()
+            min_c.toi_valid = False
+            min_c.toi_count += 1
+            if not min_c.touching:
+                for b, c0, a0, c, a, al in backup:
+                    b.c0, b.a0, b.c, b.a, b.alpha0 = c0, a0, c, a, al
+                    b.synchronize_transform()
+                continue
+            island_bodies, island_contacts = [bA, bB], [min_c]
+            for body in (bA, bB):
+                if not body.dynamic:
+                    continue
+                for c in self.contacts:
+                    if c is min_c or (c.fA.body is not body and c.fB.body is not body):
+                        continue
+                    if len(island_contacts) == MAX_TOI_CONTACTS:
+                        break
+                    other = c.fB.body if c.fA.body is body else c.fA.body
+                    if other.dynamic:                                # non-bullets: only static partners join
+                        continue
+                    c.update()
+                    if not c.touching:
+                        continue
+                    island_contacts.append(c)
+                    if other not in island_bodies:
+                        island_bodies.append(other)
+            h = (f32(1.0) - min_alpha) * f32(dt)
+            self._solve_toi_island(island_bodies, island_contacts, h, vel_iters, bA, bB)
+            for body in island_bodies:
+                if not body.dynamic:
+                    continue
+                for c in self.contacts:
+                    if c.fA.body is body or c.fB.body is body:
+                        c.toi_valid = False
+
+    def _solve_toi_island(self, bodies, contacts, h, vel_iters, toiA, toiB):
+        """b2Island::SolveTOI"""
+        pos = {id(b): [b.c.copy(), b.a] for b in bodies}
+        vel = {id(b): [b.v.copy(), b.w] for b in bodies}
+
+        def P(b): return pos[id(b)]
+        def Vv(b): return vel[id(b)] if b.dynamic else [V(), f32(0.0)]
+        vcs = [VelocityConstraint(c, P, Vv, f32(0.0)) for c in contacts]
+        for _ in range(20):                               # subStep.positionIterations
+            min_sep = f32(0.0)
+            for vc in vcs:
+                min_sep = min(min_sep, vc.solve_position(P, baumgarte=TOI_BAUMGARTE, movers=(toiA, toiB)))
+            if min_sep >= f32(-1.5) * LINEAR_SLOP:
+                break
+        for b in (toiA, toiB):                             # leap of faith to the new safe state
+            b.c0, b.a0 = pos[id(b)][0].copy(), pos[id(b)][1]
+        for vc in vcs:                                     # no warm starting: impulses start at zero
+            vc.ni = [f32(0.0)] * len(vc.ni)
+            vc.ti = [f32(0.0)] * len(vc.ti)
+            vc.initialize(P, Vv)
+        for _ in range(vel_iters):
+            for vc in vcs:
+                vc.solve(Vv)
+        for b in bodies:
+            if not b.dynamic:
+                continue
+            c, a = pos[id(b)]
+            v, w = vel[id(b)]
+            t = h * v
+            if dot(t, t) > MAX_TRANSLATION * MAX_TRANSLATION:
+                v = (MAX_TRANSLATION / t.length()) * v
+            r = h * w
+            if r * r > MAX_ROTATION * MAX_ROTATION:
+                w = w * (MAX_ROTATION / abs(r))
+            c = c + h * v
+            a = a + h * w
+            b.c, b.a, b.v, b.w = c, a, v, w
+            b.synchronize_transform()
 
     def _solve(self, h, dt_ratio, vel_iters, pos_iters):
         # islands: connected components over touching contacts between dynamic bodies; static bodies do not connect
@@ -874,12 +1005,20 @@ class VelocityConstraint:
         for j, p in enumerate(self.c.manifold.points[:len(self.ni)]):
             p.normal_impulse, p.tangent_impulse = self.ni[j], self.ti[j]
 
-    def solve_position(self, P):
-        """b2ContactSolver::SolvePositionConstraints for this contact; returns its minimum separation."""
+    def solve_position(self, P, baumgarte=None, movers=None):
+        """b2ContactSolver::SolvePositionConstraints (or SolveTOIPositionConstraints with `movers`: only the two TOI bodies
+        have mass) for this contact; returns its minimum separation."""
         m = self.c.manifold
         sA, sB = P(self.bA), P(self.bB)
         cA, aA, cB, aB = sA[0], sA[1], sB[0], sB[1]
         min_sep = f32(0.0)
+        baum = BAUMGARTE if baumgarte is None else baumgarte
+        mA, iA, mB, iB = self.mA, self.iA, self.mB, self.iB
+        if movers is not None:
+            if not any(self.bA is x for x in movers):
+                mA = iA = f32(0.0)
+            if not any(self.bB is x for x in movers):
+                mB = iB = f32(0.0)
         for j in range(len(m.points)):
             qA, qB = Rot(aA), Rot(aB)
             xfA = XF(cA - rot_mul(qA, self.lcA), qA)
@@ -905,20 +1044,96 @@ class VelocityConstraint:
                 normal = -normal
             rA, rB = point - cA, point - cB
             min_sep = min(min_sep, sep)
-            C = clamp(BAUMGARTE * (sep + LINEAR_SLOP), -MAX_LINEAR_CORRECTION, 0.0)
+            C = clamp(baum * (sep + LINEAR_SLOP), -MAX_LINEAR_CORRECTION, 0.0)
             rnA, rnB = cross(rA, normal), cross(rB, normal)
-            K = self.mA + self.mB + self.iA * rnA * rnA + self.iB * rnB * rnB
+            K = mA + mB + iA * rnA * rnA + iB * rnB * rnB
             imp = -C / K if K > 0.0 else f32(0.0)
             Pv = imp * normal
-            cA = cA - self.mA * Pv
-            aA = aA - self.iA * cross(rA, Pv)
-            cB = cB + self.mB * Pv
-            aB = aB + self.iB * cross(rB, Pv)
+            cA = cA - mA * Pv
+            aA = aA - iA * cross(rA, Pv)
+            cB = cB + mB * Pv
+            aB = aB + iB * cross(rB, Pv)
         if self.bA.dynamic:
             sA[0], sA[1] = cA, aA
         if self.bB.dynamic:
             sB[0], sB[1] = cB, aB
         return min_sep
+
+
+def time_of_impact_edge_circle(E, bA, C, bB):
+    """b2TimeOfImpact for a static edge (proxy A, radius = polygon radius) and a circle (proxy B) whose body sweeps linearly
+    from (c0, a0) to (c, a) over t in [0, 1].  Between the core shapes (the segment and the circle's centre) b2Distance is
+    the point-segment distance; the separation function is the e_faceA one on the edge normal (two simplex vertices on the
+    edge, one on the circle), as long as the closest point lies inside the segment.  Returns (state, t)."""
+    total = E.radius + C.radius
+    target = max(LINEAR_SLOP, total - f32(3.0) * LINEAR_SLOP)
+    tol = f32(0.25) * LINEAR_SLOP
+    v1, v2 = xf_mul(bA.xf, E.v1), xf_mul(bA.xf, E.v2)
+    e = v2 - v1
+
+    def centre(t):
+        t = f32(t)
+        c = (f32(1.0) - t) * bB.c0 + t * bB.c
+        a = (f32(1.0) - t) * bB.a0 + t * bB.a
+        q = Rot(a)
+        xf = XF(c - rot_mul(q, bB.local_center), q)
+        return xf_mul(xf, C.p)
+
+    def dist_and_axis(t):
+        p = centre(t)
+        u = dot(e, p - v1) / dot(e, e)
+        u = clamp(u, 0.0, 1.0)
+        closest = v1 + u * e
+        d = p - closest
+        return d.length(), p
+    t1 = f32(0.0)
+    for _ in range(20):
+        dist, p = dist_and_axis(t1)
+        if dist <= 0.0:
+            return 'overlapped', f32(0.0)
+        if dist < target + tol:
+            return 'touching', t1
+        # separation function (e_faceA): normal of the edge pointing at the circle at t1
+        n = cross_vs(e, 1.0).normalized()
+        mid = f32(0.5) * (v1 + v2)
+        if dot(p - mid, n) < 0.0:
+            n = -n
+
+        def sep(t):
+            return dot(centre(t) - mid, n)
+        done = False
+        t2 = f32(1.0)
+        for _push in range(8):
+            s2 = sep(t2)
+            if s2 > target + tol:
+                return 'separated', f32(1.0)
+            if s2 > target - tol:
+                t1 = t2
+                break
+            s1 = sep(t1)
+            if s1 < target - tol:
+                return 'failed', t1
+            if s1 <= target + tol:
+                return 'touching', t1
+            a1, a2 = t1, t2
+            for it in range(50):
+                if it & 1:
+                    t = a1 + (target - s1) * (a2 - a1) / (s2 - s1)
+                else:
+                    t = f32(0.5) * (a1 + a2)
+                s = sep(t)
+                if abs(s - target) < tol:
+                    t2 = t
+                    break
+                if s > target:
+                    a1, s1 = t, s
+                else:
+                    a2, s2 = t, s
+        else:
+            done = True
+        if done:
+            break
+    return 'failed', t1
 
 
 def world_manifold(m, xfA, rA, xfB, rB):

@@ -44,6 +44,16 @@ SCENES = {
                                                                        dict(shape='circle', r=1.25, x=1.4, y=-0.5, theta=0.0, vx=-2.0, vy=0.5, w=1.0)], steps=40, tol=5e-5),
     'box_box': dict(kilobots=[[20.0, 15.0, 0.0, 0.0, 0.0]], objects=[dict(shape='box', hx=1.875, hy=1.875, x=-2.2, y=0.0, theta=0.0, vx=3.0, vy=0.0, w=0.0),
                                                                      dict(shape='box', hx=1.25, hy=1.25, x=1.3, y=0.6, theta=0.5, vx=-2.0, vy=0.0, w=0.0)], steps=40, tol=2e-4),
+    # the continuous step (b2World::SolveTOI) against the walls: the same wall scenes with continuousPhysics on, a fast disc,
+    # a kilobot that starts a hair outside the contact radius, a corner
+    'wall_left__toi': dict(kilobots=[[-25.0 + 0.6, 3.0, math.pi - 0.5, 0.01, 0.1]], objects=[], steps=40, tol=2e-5, toi=True),
+    'wall_top__toi': dict(kilobots=[[4.0, 18.75 - 0.55, 1.2, 0.01, -0.2]], objects=[], steps=40, tol=2e-5, toi=True),
+    'wall_graze__toi': dict(kilobots=[[-25.0 + 0.4335, -2.0, math.pi / 2 + 0.05, 0.01, 0.0]], objects=[], steps=40, tol=2e-5, toi=True),
+    'corner__toi': dict(kilobots=[[25.0 - 0.62, -18.75 + 0.6, -0.7, 0.01, 0.0]], objects=[], steps=60, tol=5e-5, toi=True),
+    'disc_hits_wall__toi': dict(kilobots=[[20.0, 15.0, 0.0, 0.0, 0.0]], objects=[dict(shape='circle', r=1.5, x=25.0 - 1.9, y=2.0, theta=0.0, vx=4.0, vy=2.0, w=0.0)],
+                                steps=40, tol=5e-5, toi=True),
+    'fast_disc__toi': dict(kilobots=[[20.0, 15.0, 0.0, 0.0, 0.0]], objects=[dict(shape='circle', r=1.25, x=-25.0 + 3.2, y=-4.0, theta=0.0, vx=-16.0, vy=3.0, w=2.0)],
+                           steps=30, tol=5e-5, toi=True),
     # several contacts: Box2D sweeps in contact-creation order, the oracle in its canonical key order -> looser tolerance
     'chain_of_three': dict(kilobots=[[-0.9, 0.0, 0.0, 0.01, 0.0], [-0.05, 0.03, 0.0, 0.0, 0.0], [0.8, -0.02, 0.0, 0.0, 0.0]], objects=[], steps=60, tol=2e-3),
     'two_bots_push_box': dict(kilobots=[[-2.9, 0.9, 0.0, 0.01, 0.0], [-2.9, -0.8, 0.0, 0.01, 0.0]],
@@ -52,7 +62,7 @@ SCENES = {
 
 
 def run(scene, damping='pade', dt=0.1, vel_iters=10, pos_iters=10):
-    w = B.World(damping=damping)
+    w = B.World(damping=damping, continuous=bool(scene.get('toi')))
     table = w.create_body(dynamic=False)
     x0, x1, y0, y1 = -W / 2, W / 2, -H / 2, H / 2
     for a, b in (((x0, y1), (x0, y0)), ((x0, y0), (x1, y0)), ((x1, y0), (x1, y1)), ((x1, y1), (x0, y1))):   # kilobots_env.py:48-51
