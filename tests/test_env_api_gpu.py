@@ -107,7 +107,7 @@ def test_yaml_scene_with_boxes_on_gpu_equals_oracle_env():
         assert np.array_equal(og['kilobots'], oo['kilobots']), k
         assert np.array_equal(og['objects'], oo['objects']), k
     assert type(g.sim).__name__ == 'KilobotSim'
-    assert int(g.sim.status.max().item()) == int(o.sim.status.max().item())     # (dense spawn: warm-start slots may overflow)
+    assert int(g.sim.status.max().item()) == 0 and int(o.sim.status.max().item()) == 0     # ws_slots = 32 holds the dense spawn (and the env would have raised)
     assert np.abs(og['objects'] - start).max() > 1e-3          # the swarm moved something
     g.close()
 
