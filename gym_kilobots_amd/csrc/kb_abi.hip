@@ -23,6 +23,7 @@
 //
 // Arithmetic: fp32, compiled with -ffp-contract=off; every expression is written in the operation order of the
 // specification so results do not depend on launch fusion, workgroup size or sharding.
+#include <cstdlib>
 #include <new>
 
 #include "kb_common.h"
@@ -192,6 +193,7 @@ static int resident_envs(int lds, int threads, int wps) {
 // register budget of a kernel without objects: 80 VGPRs (tier 2) where that holds more envs than 128 VGPRs
 static int pick_tier(const kb::Params &p, int threads, int lds) {
     if (p.M > 0) return 0;
+    if (const char *t = getenv("KB_TIER")) return atoi(t) == 2 ? 2 : 0;      // experiment knob (A/B of the register budgets)
     return resident_envs(lds, threads, KB_COMPACT_WAVES_PER_SIMD) > resident_envs(lds, threads, KB_MIN_WAVES_PER_SIMD) ? 2 : 0;
 }
 
