@@ -92,6 +92,62 @@ __global__ void __launch_bounds__(256) kb_sense_kernel(const Params p, const int
     for (int b = tid; b < N; b += nt) out[o + b] = (unsigned)reinterpret_cast<unsigned short *>(cnt16)[b];
 }
 
+// The sensing point of a substep on its own (kb_light_sense): light.step + value_and_gradients at every kilobot's sensor
+// (kilobots_env.py:171-180), with the arithmetic of the step kernel (shared functions of kb_common.h), for kilobots whose
+// _loop runs on the host between the sensing and the motor law.  One workgroup per env.
+__global__ void __launch_bounds__(256) kb_light_sense_kernel(const Params p, const float *light_action) {
+    const int e = blockIdx.x, tid = threadIdx.x, nt = blockDim.x, N = p.N;
+    const kb_buffers &g = p.buf;
+    const size_t o = (size_t)e * N;
+    const bool general = p.light_type != KB_LIGHT_CIRCULAR;
+    float lx = 0.0f, ly = 0.0f;
+    float glx[KB_MAX_LIGHTS], gly[KB_MAX_LIGHTS], glvx[KB_MAX_LIGHTS], glvy[KB_MAX_LIGHTS];
+#pragma unroll
+    for (int i = 0; i < KB_MAX_LIGHTS; ++i) { glx[i] = 0.0f; gly[i] = 0.0f; glvx[i] = 0.0f; glvy[i] = 0.0f; }
+    if (!general) { lx = g.light_x[e]; ly = g.light_y[e]; }
+    else {
+#pragma unroll
+        for (int i = 0; i < KB_MAX_LIGHTS; ++i) {
+            if (i >= p.lcount) break;
+            glx[i] = g.light_x[(size_t)e * p.lcount + i];
+            if (p.light_type != KB_LIGHT_GRADIENT) gly[i] = g.light_y[(size_t)e * p.lcount + i];
+            if (p.lkind[i] == KB_LIGHT_MOMENTUM) { glvx[i] = g.light_vx[(size_t)e * p.lcount + i]; glvy[i] = g.light_vy[(size_t)e * p.lcount + i]; }
+        }
+    }
+    __syncthreads();      // every thread holds the old light state before thread 0 stores the new one
+    if (light_action) {
+        if (general) kb_light_general_step(p, light_action + (size_t)e * p.ladim, p.h, glx, gly, glvx, glvy);
+        else kb_light_single_step(p, light_action + 2 * e, p.h, lx, ly);
+        if (tid == 0) {
+            if (!general) { g.light_x[e] = lx; g.light_y[e] = ly; }
+            else {
+#pragma unroll
+                for (int i = 0; i < KB_MAX_LIGHTS; ++i) {
+                    if (i >= p.lcount) break;
+                    g.light_x[(size_t)e * p.lcount + i] = glx[i];
+                    if (p.light_type != KB_LIGHT_GRADIENT) g.light_y[(size_t)e * p.lcount + i] = gly[i];
+                    if (p.lkind[i] == KB_LIGHT_MOMENTUM) { g.light_vx[(size_t)e * p.lcount + i] = glvx[i]; g.light_vy[(size_t)e * p.lcount + i] = glvy[i]; }
+                }
+            }
+        }
+    }
+    for (int b = tid; b < N; b += nt) {
+        const float bx = g.x[o + b], by = g.y[o + b];
+        float sx = bx, sy = by;
+        if (p.drive_mode != KB_DRIVE_SIMPLE_PHOTOTAXIS) {  // kilobot.py:54-55: world point of (0, -r)
+            float s, c;
+            kb_sincosf(g.theta[o + b], s, c);
+            const float lx0 = 0.0f, ly0 = -p.r_bot;
+            sx = (c * lx0 - s * ly0) + bx;
+            sy = (s * lx0 + c * ly0) + by;
+        }
+        float lval, lgx, lgy;
+        if (general) kb_light_general_sense(p, glx, gly, sx / WORLD_SCALE, sy / WORLD_SCALE, lval, lgx, lgy);
+        else kb_light_circular(sx / WORLD_SCALE, sy / WORLD_SCALE, lx, ly, p.light_radius, lval, lgx, lgy);
+        g.light_value[o + b] = lval; g.light_gx[o + b] = lgx; g.light_gy[o + b] = lgy;
+    }
+}
+
 // KilobotsEnv.reset spawn (kb_reset): one thread per kilobot, Philox4x32-10 keyed by the seed, counter (global env, bot)
 struct ResetArgs {
     unsigned k0, k1;
@@ -584,6 +640,18 @@ int kb_sense(kb_sim *sim, float radius_m, uint32_t *d_count, void *stream) {
     hipLaunchKernelGGL(kb_sense_kernel, dim3((unsigned)p.E), dim3(256), lds, (hipStream_t)stream, p, sense_reach(Rw, p.inv_cell), Rw * Rw, d_count);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return fail(KB_EHIP, "kb_sense: %s", hipGetErrorString(err));
+    return KB_OK;
+}
+
+int kb_light_sense(kb_sim *sim, const float *d_light_action, void *stream) {
+    if (!sim) return fail(KB_EINVAL, "kb_light_sense: NULL handle");
+    if (!sim->bound) return fail(KB_ENOTBOUND, "kb_light_sense: kb_bind() first");
+    if (sim->cfg.light_type == KB_LIGHT_NONE) return fail(KB_EINVAL, "kb_light_sense: the handle has no light");
+    const Params &p = sim->p;
+    if (!p.buf.light_value || !p.buf.light_gx || !p.buf.light_gy) return fail(KB_EINVAL, "kb_light_sense: kb_buffers.light_value / light_gx / light_gy are not bound");
+    hipLaunchKernelGGL(kb_light_sense_kernel, dim3((unsigned)p.E), dim3(256), 0, (hipStream_t)stream, p, d_light_action);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return fail(KB_EHIP, "kb_light_sense: %s", hipGetErrorString(err));
     return KB_OK;
 }
 

@@ -215,6 +215,68 @@ __device__ __forceinline__ void kb_light_circular(float sx, float sy, float lx, 
     gx = dx; gy = dy;
 }
 
+// ---- light models shared by the step kernel and kb_light_sense (same operations in the same order: same bits) ----
+// SinglePositionLight.step of the single circular light, light.py:59-75; la = this env's action (2 floats)
+__device__ __forceinline__ void kb_light_single_step(const Params &p, const float *la, float h, float &lx, float &ly) {
+    float ax = fminf(fmaxf(la[0], p.act_lo[0]), p.act_hi[0]);
+    float ay = fminf(fmaxf(la[1], p.act_lo[1]), p.act_hi[1]);
+    float nlx = lx + ax * h, nly = ly + ay * h;
+    lx = fminf(fmaxf(nlx, p.light_lo[0]), p.light_hi[0]);
+    ly = fminf(fmaxf(nly, p.light_lo[1]), p.light_hi[1]);
+}
+// Light.step of every component of the general model: light.py:59-75 (positional), 300-316 (momentum), 237-253 (gradient);
+// la = this env's action (ladim floats)
+__device__ __forceinline__ void kb_light_general_step(const Params &p, const float *la, float h, float (&glx)[KB_MAX_LIGHTS],
+                                                      float (&gly)[KB_MAX_LIGHTS], float (&glvx)[KB_MAX_LIGHTS], float (&glvy)[KB_MAX_LIGHTS]) {
+    if (p.light_type == KB_LIGHT_GRADIENT) {
+        const float pi = 3.14159265358979323846f;
+        float ang = fminf(fmaxf(la[0], -2.0f * pi), 2.0f * pi);
+        if (ang < -pi) ang += 2.0f * pi;
+        if (ang > pi) ang -= 2.0f * pi;
+        glx[0] = ang;
+    } else {
+#pragma unroll
+        for (int i = 0; i < KB_MAX_LIGHTS; ++i) {
+            if (i >= p.lcount) break;
+            const float ax = fminf(fmaxf(la[2 * i + 0], p.lalo[i][0]), p.lahi[i][0]);
+            const float ay = fminf(fmaxf(la[2 * i + 1], p.lalo[i][1]), p.lahi[i][1]);
+            float nlx, nly;
+            if (p.lkind[i] == KB_LIGHT_MOMENTUM) {
+                float mvx = glvx[i] + ax * h, mvy = glvy[i] + ay * h;
+                const float nv = sqrtf(mvx * mvx + mvy * mvy);
+                if (nv > p.lmaxv[i]) { const float sc = p.lmaxv[i] / nv; mvx *= sc; mvy *= sc; }
+                glvx[i] = mvx; glvy[i] = mvy;
+                nlx = glx[i] + mvx * h; nly = gly[i] + mvy * h;
+            } else {
+                nlx = glx[i] + ax * h; nly = gly[i] + ay * h;
+            }
+            glx[i] = fminf(fmaxf(nlx, p.llo[i][0]), p.lhi[i][0]);
+            gly[i] = fminf(fmaxf(nly, p.llo[i][1]), p.lhi[i][1]);
+        }
+    }
+}
+// value_and_gradients of the general model at one sensor position (metres): light.py:176-189, 137-141;
+// GradientLight: projection on the gradient direction (intent of light.py:255-260)
+__device__ __forceinline__ void kb_light_general_sense(const Params &p, const float (&glx)[KB_MAX_LIGHTS], const float (&gly)[KB_MAX_LIGHTS],
+                                                       float sx, float sy, float &val, float &gx, float &gy) {
+    if (p.light_type == KB_LIGHT_GRADIENT) {
+        float s_, c_;
+        kb_sincosf(glx[0], s_, c_);
+        val = c_ * sx + s_ * sy; gx = c_; gy = s_;
+        return;
+    }
+    float vsum = 0.0f, vbest = 0.0f, bgx = 0.0f, bgy = 0.0f;
+#pragma unroll
+    for (int i = 0; i < KB_MAX_LIGHTS; ++i) {
+        if (i >= p.lcount) break;
+        float v, x, y;
+        kb_light_circular(sx, sy, glx[i], gly[i], p.lradius[i], v, x, y);
+        vsum = i == 0 ? v : vsum + v;
+        if (i == 0 || v > vbest) { vbest = v; bgx = x; bgy = y; }   // np.argmax: first maximum
+    }
+    val = vsum; gx = bgx; gy = bgy;
+}
+
 // Kilobot.step motor law, kilobot.py:86-127; body velocity in world units
 __device__ __forceinline__ void kb_motor_law(int ml, int mr, float th, float h, float &vx, float &vy, float &w) {
     const float max_lin = 0.01f, max_ang = 0.5f * 3.14159265358979323846f;

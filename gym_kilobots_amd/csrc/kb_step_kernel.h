@@ -207,25 +207,9 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
             if (p.lkind[i] == KB_LIGHT_MOMENTUM) { glvx[i] = g.light_vx[(size_t)e * p.lcount + i]; glvy[i] = g.light_vy[(size_t)e * p.lcount + i]; }
         }
     }
-    // value_and_gradients of the general model at one sensor position (metres): light.py:176-189, 137-141;
-    // GradientLight: projection on the gradient direction (intent of light.py:255-260)
+    // value_and_gradients of the general model at one sensor position (metres): kb_common.h
     auto sense_general = [&](float sx, float sy, float &val, float &gx, float &gy) __attribute__((always_inline)) {
-        if (p.light_type == KB_LIGHT_GRADIENT) {
-            float s_, c_;
-            kb_sincosf(glx[0], s_, c_);
-            val = c_ * sx + s_ * sy; gx = c_; gy = s_;
-            return;
-        }
-        float vsum = 0.0f, vbest = 0.0f, bgx = 0.0f, bgy = 0.0f;
-#pragma unroll
-        for (int i = 0; i < KB_MAX_LIGHTS; ++i) {
-            if (i >= p.lcount) break;
-            float v, x, y;
-            kb_light_circular(sx, sy, glx[i], gly[i], p.lradius[i], v, x, y);
-            vsum = i == 0 ? v : vsum + v;
-            if (i == 0 || v > vbest) { vbest = v; bgx = x; bgy = y; }   // np.argmax: first maximum
-        }
-        val = vsum; gx = bgx; gy = bgy;
+        kb_light_general_sense(p, glx, gly, sx, sy, val, gx, gy);
     };
     const bool drive = !(p.flags & KB_STEP_NO_DRIVE);
     const float rr = p.r_bot + p.r_bot, rr2 = rr * rr;
@@ -252,43 +236,10 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
 #define KB_RETID() do { int t_ = threadIdx.x; asm volatile("" : "+v"(t_)); tid = t_; lane = t_ & 63; wave = t_ >> 6; } while (0)
         KB_RETID();
         // ---- light.step: SinglePositionLight.step, light.py:59-75 (uniform per env) ----
-        if (p.light_action && LGEN && drive) {
-            // Light.step of every component: light.py:59-75 (positional), 300-316 (momentum), 237-253 (gradient)
-            const float *la = p.light_action + (size_t)e * p.ladim;
-            if (p.light_type == KB_LIGHT_GRADIENT) {
-                const float pi = 3.14159265358979323846f;
-                float ang = fminf(fmaxf(la[0], -2.0f * pi), 2.0f * pi);
-                if (ang < -pi) ang += 2.0f * pi;
-                if (ang > pi) ang -= 2.0f * pi;
-                glx[0] = ang;
-            } else {
-#pragma unroll
-                for (int i = 0; i < KB_MAX_LIGHTS; ++i) {
-                    if (i >= p.lcount) break;
-                    const float ax = fminf(fmaxf(la[2 * i + 0], p.lalo[i][0]), p.lahi[i][0]);
-                    const float ay = fminf(fmaxf(la[2 * i + 1], p.lalo[i][1]), p.lahi[i][1]);
-                    float nlx, nly;
-                    if (p.lkind[i] == KB_LIGHT_MOMENTUM) {
-                        float mvx = glvx[i] + ax * h, mvy = glvy[i] + ay * h;
-                        const float nv = sqrtf(mvx * mvx + mvy * mvy);
-                        if (nv > p.lmaxv[i]) { const float sc = p.lmaxv[i] / nv; mvx *= sc; mvy *= sc; }
-                        glvx[i] = mvx; glvy[i] = mvy;
-                        nlx = glx[i] + mvx * h; nly = gly[i] + mvy * h;
-                    } else {
-                        nlx = glx[i] + ax * h; nly = gly[i] + ay * h;
-                    }
-                    glx[i] = fminf(fmaxf(nlx, p.llo[i][0]), p.lhi[i][0]);
-                    gly[i] = fminf(fmaxf(nly, p.llo[i][1]), p.lhi[i][1]);
-                }
-            }
-        }
-        if (p.light_action && LIGHT_TYPE == KB_LIGHT_CIRCULAR && drive) {
-            float ax = fminf(fmaxf(p.light_action[2 * e + 0], p.act_lo[0]), p.act_hi[0]);
-            float ay = fminf(fmaxf(p.light_action[2 * e + 1], p.act_lo[1]), p.act_hi[1]);
-            float nlx = lx + ax * h, nly = ly + ay * h;
-            lx = fminf(fmaxf(nlx, p.light_lo[0]), p.light_hi[0]);
-            ly = fminf(fmaxf(nly, p.light_lo[1]), p.light_hi[1]);
-        }
+        if (p.light_action && LGEN && drive)
+            kb_light_general_step(p, p.light_action + (size_t)e * p.ladim, h, glx, gly, glvx, glvy);
+        if (p.light_action && LIGHT_TYPE == KB_LIGHT_CIRCULAR && drive)
+            kb_light_single_step(p, p.light_action + 2 * e, h, lx, ly);
         // ---- sensing + drive law + damping; grid insertion; reset per-substep scratch ----
 #pragma unroll
         for (int q = 0; q < BPT; ++q) {

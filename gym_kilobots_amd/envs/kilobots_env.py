@@ -74,6 +74,7 @@ class KilobotsEnv(object):
         self._sim_factory = sim_factory or _default_sim_factory
         self._sim = None
         self._sim_signature = None
+        self._host_programmed = False
 
         # the "world": records bodies created by _configure_environment (kilobots_env.py:45-51)
         self.world = World()
@@ -233,13 +234,31 @@ class KilobotsEnv(object):
             fixture_body.extend([i] * len(fixtures))
         if len(specs) > nat.MAX_OBJECTS:
             raise UnknownObjectException('at most %d fixtures (convex parts of all objects) per env' % nat.MAX_OBJECTS)
-        kinds = {type(k).drive_mode for k in kbs}
-        if len(kinds) != 1:
-            raise ValueError('all kilobots of an env must share one drive law (got %s)' % sorted(kinds))
         for k in kbs:
             if not isinstance(k, Kilobot):
                 raise TypeError('kilobots must derive from gym_kilobots_amd.lib.Kilobot')
-            k._assert_device_law()
+            k._assert_steppable()
+        kinds = {type(k).drive_mode for k in kbs}
+        motor_family = kinds <= {nat.DRIVE_MOTORS, nat.DRIVE_PHOTOTAXIS}
+        # Kilobots with their own _loop (the reference's extension point, kilobot.py:86-88,164-168) and mixes of the classes
+        # that share Kilobot.step (the motor law) are "host-programmed": every substep the device senses the light, the
+        # host runs each kilobot's _loop, and the device applies the motor law and steps the world (_step_host_programmed).
+        self._host_programmed = any(type(k)._host_programmed() for k in kbs) or (motor_family and len(kinds) > 1)
+        if self._host_programmed:
+            if not motor_family:
+                raise ValueError('host-programmed kilobots (own _loop) only mix with classes that use the motor law of '
+                                 'Kilobot.step (got drive laws %s)' % sorted(kinds))
+            if self.num_envs != 1:
+                raise ValueError('kilobots with their own _loop are Python objects of ONE world: use num_envs=1 '
+                                 '(the batched device laws are the classes of gym_kilobots_amd.lib.kilobot)')
+            kinds = {nat.DRIVE_MOTORS}
+        if len(kinds) != 1:
+            raise ValueError('all kilobots of an env must share one drive law (got %s); only classes built on the motor law '
+                             '(Kilobot.step) can be mixed' % sorted(kinds))
+        props = {(float(type(k)._density), float(type(k)._radius), float(type(k)._linear_damping), float(type(k)._angular_damping))
+                 for k in kbs}
+        if len(props) != 1:
+            raise ValueError('all kilobots of an env must share density, radius and damping (got %s)' % sorted(props))
         mode = kinds.pop()
         light_type = nat.LIGHT_NONE
         overrides = dict(world_width=self.world_width, world_height=self.world_height, dt=self.sim_step,
@@ -388,8 +407,11 @@ class KilobotsEnv(object):
         la = None
         if action is not None and self._light:
             la = self._light_action_tensor(action)
-        # the whole `for i in range(steps_per_action)` loop (kilobots_env.py:168-190) is one launch
-        self._sim.step(self.__steps_per_action, light_action=la)
+        if self._host_programmed:
+            self._step_host_programmed(la)
+        else:
+            # the whole `for i in range(steps_per_action)` loop (kilobots_env.py:168-190) is one launch
+            self._sim.step(self.__steps_per_action, light_action=la)
         self.world.touch()
         self.__sim_steps += self.__steps_per_action
         next_state = self.get_state()
@@ -403,6 +425,34 @@ class KilobotsEnv(object):
     def _step_world(self):
         self._sim.step(1, flags=nat.STEP_NO_DRIVE)
         self.world.touch()
+
+    # ------------------------------------------------------------------ host-programmed kilobots
+    _HOST_ARRAYS = ('motor_l', 'motor_r', 'x', 'y', 'theta')
+
+    def _step_host_programmed(self, la):
+        """The substep loop of kilobots_env.py:168-190 for kilobots whose _loop is Python: per substep the device steps the
+        light and evaluates it at every sensor (kb_light_sense, :171-180), the host runs every kilobot's _loop on copies of
+        the state (get_ambientlight / set_motors / the body getters; kilobot.py:88), and the device applies the motor law
+        and world.Step (kb_step(1); :183-188).  Physics and sensing stay on the GPU; only the user's code runs here."""
+        sim, world = self._sim, self.world
+        names = self._HOST_ARRAYS + (('light_value', 'light_gx', 'light_gy') if self._light is not None else ())
+        for _ in range(self.__steps_per_action):
+            if self._light is not None:
+                sim.light_sense(la)
+            cache = {n: getattr(sim, n)[0].cpu().numpy().copy() for n in names}
+            world.host_cache, world.host_dirty = cache, set()
+            try:
+                for k in self._kilobots:
+                    k._host_loop()
+            finally:
+                world.host_cache = None
+            for n in sorted(world.host_dirty):
+                dst = getattr(sim, n)
+                dst[0].copy_(torch.from_numpy(cache[n]).to(dst.device))
+            if world.host_dirty & {'x', 'y'}:
+                sim.forget_contacts()
+            world.host_dirty = set()
+            sim.step(1)
 
     def render(self, mode=None):
         raise NotImplementedError('rendering (pygame viewer) is outside the accelerated hot path; '

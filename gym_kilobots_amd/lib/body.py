@@ -17,6 +17,10 @@ class World:
         self.backend = None
         self.env_index = 0
         self.version = 0        # bumped by every write to the device state that goes through the body / light views
+        # host-programmed kilobots (KilobotsEnv._step_host_programmed): per-substep host copies of env 0's arrays, name -> [N]
+        # numpy array; reads and writes of the body views go there while the kilobots' _loop runs
+        self.host_cache = None
+        self.host_dirty = set()
 
     def touch(self):
         self.version += 1
@@ -68,9 +72,17 @@ class Body:
         return self._world.backend is not None and self._index >= 0
 
     def _get(self, name):
+        hc = self._world.host_cache
+        if hc is not None and name in hc:
+            return float(hc[name][self._index])
         return float(getattr(self._world.backend, name)[self._world.env_index, self._index].item())
 
     def _set(self, name, value):
+        hc = self._world.host_cache
+        if hc is not None and name in hc:
+            hc[name][self._index] = value
+            self._world.host_dirty.add(name)
+            return
         getattr(self._world.backend, name)[self._world.env_index, self._index] = float(value)
         self._world.touch()
 

@@ -85,22 +85,42 @@ class Kilobot(Circle):
     def step(self, time_step):
         raise NotImplementedError('kilobots are stepped in bulk by the env (one HIP launch per substep batch)')
 
-    def _assert_device_law(self):
-        """The reference's extension point is a user subclass overriding _loop / _setup / step (kilobot.py:86-88,164-168):
-        Python run per kilobot per substep.  The device step only knows the five drive laws of the reference; a subclass
-        that programs its own behaviour would silently not run, so it is refused when the scene is uploaded."""
+    # ---- where does this kilobot's program run? ----------------------------------------------------------------------
+    @classmethod
+    def _user_code(cls, name):
+        """Is method `name` of this class user code (defined outside this module and not an empty body)?"""
+        impl = getattr(cls, name)
+        owner = next(c for c in cls.__mro__ if name in c.__dict__)
+        code = getattr(impl, '__code__', None)
+        noop = code is not None and code.co_code == MotorKilobot._loop.__code__.co_code and not code.co_names
+        return owner.__module__ != __name__ and not noop
+
+    @classmethod
+    def _host_programmed(cls):
+        """The reference's extension point is a Kilobot subclass with its own _loop / _setup (kilobot.py:86-88,164-168):
+        Python run per kilobot per substep, between the light sensing and the motor law.  Such a class is stepped with its
+        _loop on the HOST (KilobotsEnv._step_host_programmed: kb_light_sense -> _loop of every kilobot -> kb_step(1) with
+        the motor law and the world step on the device); the library's own classes run entirely on the device."""
+        return cls._user_code('_loop')
+
+    def _assert_steppable(self):
+        """A subclass that overrides step() itself writes a b2Body's velocities directly (kilobot.py:123-127): there is no
+        b2Body here.  Refused loudly when the scene is uploaded instead of being silently ignored."""
         cls = type(self)
-        for name in ('_loop', 'step'):
-            impl = getattr(cls, name)
-            owner = next(c for c in cls.__mro__ if name in c.__dict__)
-            noop = name == '_loop' and getattr(impl, '__code__', None) is not None and \
-                impl.__code__.co_code == MotorKilobot._loop.__code__.co_code and not impl.__code__.co_names
-            if owner.__module__ != __name__ and not noop:
-                raise NotImplementedError(
-                    '%s.%s is user code: per-kilobot Python (%s) does not run on the device. The HIP step implements the drive laws '
-                    'of Kilobot (motors), SimplePhototaxisKilobot, SimpleVelocityControlKilobot, SimpleAccelerationControlKilobot '
-                    'and PhototaxisKilobot; derive from one of them without overriding %s, or drive the swarm through '
-                    'set_motors / set_action between env.step calls.' % (cls.__name__, name, impl.__qualname__, name))
+        if cls._user_code('step'):
+            raise NotImplementedError(
+                '%s.step is user code that drives a Box2D body directly; the device step implements the drive laws of Kilobot '
+                '(motors), SimplePhototaxisKilobot, SimpleVelocityControlKilobot, SimpleAccelerationControlKilobot and '
+                'PhototaxisKilobot.  Program the kilobot through _loop / set_motors (runs on the host, the physics on the device) '
+                'or derive from one of those classes without overriding step.' % cls.__name__)
+        if cls._host_programmed() and cls.drive_mode not in (nat.DRIVE_MOTORS, nat.DRIVE_PHOTOTAXIS):
+            raise NotImplementedError(
+                '%s overrides _loop but derives from a class whose step() is not the motor law (%s): a host-side _loop can only '
+                'drive the motors (Kilobot.step, kilobot.py:86-127)' % (cls.__name__, cls.__mro__[1].__name__))
+
+    def _host_loop(self):
+        """What the host runs for this kilobot at each substep of a host-programmed env: the user's _loop."""
+        self._loop()
 
     @classmethod
     def get_radius(cls):
@@ -218,8 +238,32 @@ class SimpleAccelerationControlKilobot(SimpleVelocityControlKilobot):
 class PhototaxisKilobot(Kilobot):
     drive_mode = nat.DRIVE_PHOTOTAXIS
 
+    def __init__(self, world, position=None, orientation=None, light=None):
+        super().__init__(world=world, position=position, orientation=orientation, light=light)
+        # host twin of the device law's per-kilobot state (kilobot.py:307-313); only used in host-programmed envs
+        self._pt_threshold = np.float32(-np.inf)
+        self._pt_update_counter = 0
+        self._pt_no_change_counter = 0
+
     def _setup(self):
         self.turn_left()
 
     def _loop(self):
         pass
+
+    def _host_loop(self):
+        """kilobot.py:318-333 in the arithmetic of the device law (fp32 threshold), for envs that mix this class with
+        host-programmed kilobots: there every _loop runs on the host."""
+        if type(self)._host_programmed():
+            return self._loop()
+        if self._pt_update_counter % 6:
+            self._pt_update_counter += 1
+            return
+        self._pt_update_counter += 1
+        meas = np.float32(self.get_ambientlight())
+        if meas > self._pt_threshold or self._pt_no_change_counter >= 15:
+            self._pt_threshold = np.float32(meas + np.float32(0.01))
+            self.switch_directions()
+            self._pt_no_change_counter = 0
+        else:
+            self._pt_no_change_counter += 1

@@ -204,6 +204,16 @@ class KilobotSim:
             nat.check(self._lib.kb_sense(self._h, float(radius_m), C.c_void_p(out.data_ptr()), self._stream()), 'kb_sense')
         return out
 
+    def light_sense(self, light_action=None):
+        """The sensing point of one substep on its own (kb_light_sense): Light.step with `light_action` (None: the light
+        stays) + value_and_gradients at every kilobot's sensor into light_value / light_gx / light_gy -- for kilobots whose
+        _loop runs on the host between the sensing and the motor law (kilobots_env.py:171-184)."""
+        if self.light_value is None:
+            raise ValueError('light_sense needs the sensing outputs: create the sim with debug_outputs=True')
+        pl = self._ptr(light_action, (self.num_envs, self._lib.kb_light_action_dim(self._h)), 'light_action')
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.kb_light_sense(self._h, pl, self._stream()), 'kb_light_sense')
+
     def reset(self, seed=0, mean=(0.0, 0.0), std=0.1, random_theta=False, random_velocity=False, resolve=True, env_offset=0):
         """KilobotsEnv.reset of every env on the device (kb_reset): Gaussian spawn clipped to the bounds -/+ 0.02 m
         (yaml_kilobots_env.py:346-352), Philox4x32-10 keyed by (seed; env_offset + env, bot), then the step to resolve."""

@@ -199,6 +199,14 @@ int kb_step(kb_sim *sim, const float *d_actions, const float *d_light_action, in
  * No reference counterpart (the reference has no neighbour sensing; nearest: Body.collides_with, body.py:87-90). */
 int kb_sense(kb_sim *sim, float radius_m, uint32_t *d_count, void *stream);
 
+/* The sensing point of ONE substep on its own, for kilobots that are programmed on the host (a Kilobot subclass with its
+ * own _loop, kilobot.py:86-88,164-168): Light.step with d_light_action ([num_envs][kb_light_action_dim()], NULL = action None:
+ * the light stays) and value_and_gradients at every kilobot's light sensor (kilobots_env.py:171-180) into
+ * kb_buffers.light_value / light_gx / light_gy, exactly the arithmetic the fused step uses.  The host then runs the
+ * kilobots' _loop (get_ambientlight -> light_value, set_motors -> motor_l / motor_r) and calls
+ * kb_step(sim, NULL, NULL, 1, 0, stream): motor law + world.Step of that substep (the light is not stepped again). */
+int kb_light_sense(kb_sim *sim, const float *d_light_action, void *stream);
+
 /* KilobotsEnv.reset() for every env of the handle, on the device (kilobots_env.py:150-159 with the spawn rule of
  * YamlKilobotsEnv._init_kilobots, yaml_kilobots_env.py:346-352): positions ~ N(mean, std) per coordinate, clipped to
  * the world bounds -/+ 0.02 m, theta = 0 (body.py:28-29) or U(-pi, pi); commands and accelerations zeroed

@@ -1734,6 +1734,32 @@ static void substep_env(const kbo_config *cfg, const derived_t *d, kbo_state *st
     if (st->status) st->status[e] |= w->status;
 }
 
+/* The sensing point of one substep on its own (specification of kb_light_sense, include/kilobots_hip.h): light.step with
+ * the action (NULL = None: the light stays) and value_and_gradients at every kilobot's sensor, kilobots_env.py:171-180,
+ * exactly as substep_env does them -- for kilobots whose _loop runs on the host before the motor law. */
+int kbo_light_sense(const kbo_config *cfg, kbo_state *st, const float *light_action) {
+    if (!cfg || !st || cfg->light_type == KBO_LIGHT_NONE || !st->light_value || !st->light_gx || !st->light_gy) return -1;
+    derived_t d;
+    derive(cfg, &d);
+    const int N = cfg->num_bots;
+    for (int e = 0; e < cfg->num_envs; ++e) {
+        const size_t o = (size_t)e * N;
+        if (light_action) light_step_env(cfg, st, e, light_action, d.h);
+        for (int b = 0; b < N; ++b) {
+            const float th = st->theta[o + b], px = st->x[o + b], py = st->y[o + b];
+            float sx = px, sy = py;
+            if (cfg->drive_mode != KBO_DRIVE_SIMPLE_PHOTOTAXIS) {
+                float s, c; kbo_sincosf(th, &s, &c);
+                float lx0 = 0.0f, ly0 = -d.r_bot;
+                sx = (c * lx0 - s * ly0) + px;
+                sy = (s * lx0 + c * ly0) + py;
+            }
+            light_sense(cfg, st, e, sx / WORLD_SCALE, sy / WORLD_SCALE, &st->light_value[o + b], &st->light_gx[o + b], &st->light_gy[o + b]);
+        }
+    }
+    return 0;
+}
+
 int kbo_contact_capacity(const kbo_config *cfg) {
     /* contact capacity per env (must equal the HIP kernel's, kb_contact_capacity) */
     long N = cfg->num_bots;

@@ -111,6 +111,8 @@ def lib():
         _lib.kbo_logf.restype = C.c_float
         _lib.kbo_sense.argtypes = [C.POINTER(Config), C.POINTER(State), C.c_float, _PU32]
         _lib.kbo_sense.restype = C.c_int
+        _lib.kbo_light_sense.argtypes = [C.POINTER(Config), C.POINTER(State), _PF]
+        _lib.kbo_light_sense.restype = C.c_int
         _lib.kbo_philox4x32_10.argtypes = [_PU32, _PU32, _PU32]
         _lib.kbo_philox4x32_10.restype = None
         _lib.kbo_reset.argtypes = [C.POINTER(Config), C.POINTER(State), C.POINTER(ResetParams)]
@@ -234,6 +236,12 @@ class OracleSim:
         la = None if light_action is None else np.ascontiguousarray(light_action, np.float32)
         r = lib().kbo_step(C.byref(self.cfg), C.byref(self._st),
                            None if la is None else la.ctypes.data_as(_PF), n_substeps, flags, threads)
+        assert r == 0, r
+
+    def light_sense(self, light_action=None):
+        """The sensing point of one substep on its own (kbo_light_sense): light.step + sensing into light_value / gx / gy."""
+        la = None if light_action is None else np.ascontiguousarray(light_action, np.float32)
+        r = lib().kbo_light_sense(C.byref(self.cfg), C.byref(self._st), None if la is None else la.ctypes.data_as(_PF))
         assert r == 0, r
 
     def sense(self, radius_m):

@@ -30,6 +30,9 @@ class OracleBackend:
     def sense(self, radius_m, out=None):
         return torch.from_numpy(self.o.sense(radius_m).view(np.int32))
 
+    def light_sense(self, light_action=None):
+        self.o.light_sense(None if light_action is None else light_action.cpu().numpy())
+
     def reset(self, **kw):
         self.o.reset(**kw)
 

@@ -161,7 +161,9 @@ def test_batched_reset_is_seeded_and_on_device_rule():
     assert not np.array_equal(c.reset().numpy(), b.sim.poses().numpy())
 
 
-def test_user_programmed_kilobots_are_refused():
+def test_user_programmed_kilobots_run_their_loop_on_the_host():
+    """a user _loop used to be ignored, then refused; now it runs (tests/test_host_programmed.py has the
+    parity tests).  A subclass of a device-law class that overrides _loop replaces that law, as in the reference."""
     from gym_kilobots_amd.envs import KilobotsEnv
     from gym_kilobots_amd.lib import PhototaxisKilobot, CircularGradientLight, Kilobot
     from tests.oracle_backend import OracleBackend
@@ -170,7 +172,7 @@ def test_user_programmed_kilobots_are_refused():
         def _loop(self):                       # reference extension point (kilobot.py:164-168): runs per kilobot per substep
             self.set_motors(10, 20)
 
-    class Plain(Kilobot):                      # only _setup is user code: that runs on the host at construction, fine
+    class Plain(Kilobot):                      # only _setup is user code: that runs on the host at construction
         def _setup(self):
             self.set_motors(0, 200)
 
@@ -186,11 +188,14 @@ def test_user_programmed_kilobots_are_refused():
             def get_reward(self, *a):
                 return 0.0
         return Env(sim_factory=OracleBackend)
-    with pytest.raises(NotImplementedError, match='does not run on the device'):
-        make(MyBot).reset()
+    env = make(MyBot)
+    env.reset()
+    assert env._host_programmed and env.kilobots[0].get_motors() == (255, 0)        # _setup -> turn_left
+    env.step(None)
+    assert env.kilobots[0].get_motors() == (10, 20)
     env = make(Plain)
     env.reset()
-    assert env.kilobots[0].get_motors() == (0, 200)
+    assert not env._host_programmed and env.kilobots[0].get_motors() == (0, 200)
 
 
 def test_multi_env_light_state_has_the_single_env_layout():
