@@ -50,6 +50,7 @@ class KbConfig(C.Structure):
         ('wall_friction', C.c_float),
         ('num_fixtures', C.c_int32), ('obj_fixture_body', C.c_int32 * MAX_OBJECTS),
         ('damping_model', C.c_int32), ('sense_radius', C.c_float), ('contact_capacity', C.c_int32),
+        ('allow_sleep', C.c_int32),
     ]
 
 
@@ -65,7 +66,8 @@ BUFFER_FIELDS = ['x', 'y', 'theta', 'v', 'w', 'acc_v', 'acc_w', 'motor_l', 'moto
                  'light_x', 'light_y', 'light_vx', 'light_vy',
                  'ox', 'oy', 'otheta', 'ovx', 'ovy', 'ow',
                  'ws_key', 'ws_acc', 'ws_cnt',
-                 'light_value', 'light_gx', 'light_gy', 'cmd_vx', 'cmd_vy', 'cmd_w', 'status', 'scratch', 'ows_acc', 'nbr_count']
+                 'light_value', 'light_gx', 'light_gy', 'cmd_vx', 'cmd_vy', 'cmd_w', 'status', 'scratch', 'ows_acc', 'nbr_count',
+                 'sleep_time', 'osleep']
 
 
 class KbBuffers(C.Structure):
@@ -73,7 +75,7 @@ class KbBuffers(C.Structure):
 
 
 EXPORTS = ['kb_create', 'kb_destroy', 'kb_bind', 'kb_set_actions', 'kb_step', 'kb_get_poses', 'kb_sense', 'kb_light_sense', 'kb_reset',
-           'kb_lds_bytes', 'kb_resident_envs_per_cu', 'kb_contact_capacity', 'kb_scratch_bytes', 'kb_light_action_dim', 'kb_light_count', 'kb_block_threads', 'kb_set_block_threads',
+           'kb_lds_bytes', 'kb_resident_envs_per_cu', 'kb_contact_capacity', 'kb_lds_staging_entries', 'kb_scratch_bytes', 'kb_light_action_dim', 'kb_light_count', 'kb_block_threads', 'kb_set_block_threads',
            'kb_last_error', 'kb_version']
 
 _lib = None
@@ -127,7 +129,7 @@ def load():
     lib.kb_light_sense.restype = C.c_int
     lib.kb_reset.argtypes = [_P, C.POINTER(KbResetParams), _P]
     lib.kb_reset.restype = C.c_int
-    for name in ('kb_lds_bytes', 'kb_resident_envs_per_cu', 'kb_contact_capacity', 'kb_block_threads', 'kb_light_action_dim', 'kb_light_count'):
+    for name in ('kb_lds_bytes', 'kb_resident_envs_per_cu', 'kb_contact_capacity', 'kb_lds_staging_entries', 'kb_block_threads', 'kb_light_action_dim', 'kb_light_count'):
         getattr(lib, name).argtypes = [_P]
         getattr(lib, name).restype = C.c_int
     lib.kb_scratch_bytes.argtypes = [_P]
@@ -176,6 +178,7 @@ def default_config(num_envs, num_bots, drive_mode=DRIVE_VELOCITY, light_type=LIG
     c.damping_model = DAMPING_PADE
     c.sense_radius = 0.0
     c.contact_capacity = 0
+    c.allow_sleep = 0      # b2World(doSleep=...): KilobotsEnv switches it on like kilobots_env.py:45
     c.light_count = 1
     for i in range(MAX_LIGHTS):
         c.light_kind[i] = LIGHT_CIRCULAR

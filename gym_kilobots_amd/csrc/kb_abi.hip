@@ -189,6 +189,7 @@ __global__ void kb_reset_kernel(const Params p, const ResetArgs a) {
         p.buf.pt_threshold[i] = -INFINITY; p.buf.pt_update[i] = 0; p.buf.pt_nochange[i] = 0; p.buf.pt_dir[i] = 0;
     }
     if (b == 0) p.buf.status[e] = 0;
+    if (p.buf.sleep_time) p.buf.sleep_time[i] = 0.0f;      // new bodies are awake (b2BodyDef::awake)
     if (p.M > 0) {      // forget the objects' manifold impulses as well
         float *ows = p.buf.ows_acc + (size_t)e * (MAXOBJ * KB_OWS_COLS * KB_OWS_WORDS);
         for (int k = b; k < MAXOBJ * KB_OWS_COLS * KB_OWS_WORDS; k += p.N) ows[k] = -1.0f;
@@ -224,6 +225,7 @@ struct kb_sim {
 // scenes with objects (namespace lds, kb_common.h)
 static bool uses_fixed_1024(const kb::Params &p, int threads) {   // the instantiation kb_step picks: the ONE place that decides
     const long cap1024 = (4L * 1024 + 64 + 7) & ~7L;
+    if (p.allow_sleep) return false;            // (the fixed-size instantiations do not carry the sleep state)
     return p.drive_mode == KB_DRIVE_VELOCITY && p.N == 1024 && p.light_type == KB_LIGHT_NONE && threads == 64 * kb::MAX_WAVES &&
            kb::BPT * 64 * kb::MAX_WAVES == 1024 && p.NP == 1024 && p.NB == 1024 + KB_MAX_OBJECTS + 4 &&
            (p.M > 0 || p.cap == (int)cap1024);      // (without objects the contact capacity is a compile-time constant of the kernel)
@@ -248,7 +250,7 @@ static int resident_envs(int lds, int threads, int wps) {
 }
 // register budget of a kernel without objects: 80 VGPRs (tier 2) where that holds more envs than 128 VGPRs
 static int pick_tier(const kb::Params &p, int threads, int lds) {
-    if (p.M > 0) return 0;
+    if (p.M > 0 || p.allow_sleep) return 0;      // (the instantiations with the sleep state exist at 128 VGPRs only)
     if (const char *t = getenv("KB_TIER")) return atoi(t) == 2 ? 2 : 0;      // experiment knob (A/B of the register budgets)
     return resident_envs(lds, threads, KB_COMPACT_WAVES_PER_SIMD) > resident_envs(lds, threads, KB_MIN_WAVES_PER_SIMD) ? 2 : 0;
 }
@@ -329,6 +331,7 @@ int kb_create(const kb_config *cfg, kb_sim **out) {
     Params &p = s->p;
     memset(&p, 0, sizeof(p));
     p.N = cfg->num_bots; p.E = cfg->num_envs; p.S = cfg->ws_slots;
+    p.allow_sleep = cfg->allow_sleep != 0;
     p.drive_mode = cfg->drive_mode; p.light_type = cfg->light_type;
     p.vel_iters = cfg->vel_iters; p.pos_iters = cfg->pos_iters;
     const float W = cfg->world_width * WORLD_SCALE, H = cfg->world_height * WORLD_SCALE;
@@ -545,6 +548,8 @@ int kb_bind(kb_sim *sim, const kb_buffers *b) {
     if ((b->cmd_vx != nullptr) != (b->cmd_vy != nullptr) || (b->cmd_vx != nullptr) != (b->cmd_w != nullptr))
         return fail(KB_EINVAL, "kb_bind: cmd_vx, cmd_vy, cmd_w must be given together");
     if (sim->cfg.sense_radius > 0.0f && !b->nbr_count) return fail(KB_ENOTBOUND, "kb_bind: nbr_count is required when sense_radius > 0");
+    if (sim->cfg.allow_sleep && (!b->sleep_time || (sim->cfg.num_objects > 0 && !b->osleep)))
+        return fail(KB_ENOTBOUND, "kb_bind: sleep_time (and osleep with objects) are required when allow_sleep is set");
     sim->p.buf = *b;
     sim->bound = true;
     return KB_OK;
@@ -571,6 +576,7 @@ static kb_step_fn select_kernel(const kb_sim *sim, const kb::Params &p) {
     // scenes whose objects are all discs: instantiations without the kilobot - polygon contact code (5 / 6)
     bool discs = obj;
     for (int f = 0; f < p.F; ++f) discs = discs && ot_kind(p.otab[f]) == KB_SHAPE_CIRCLE;
+    if (p.allow_sleep) { discs = false; objsel = (obj ? (sim->threads <= 64 ? 2 : 1) : 0) | KB_PICK_SLEEP; }   // generic 128-VGPR instantiations with the sleep state
     if (discs) objsel += 4;
     switch (p.drive_mode) {
     case KB_DRIVE_VELOCITY: {
@@ -691,6 +697,7 @@ int kb_light_action_dim(const kb_sim *sim) { return sim ? sim->p.ladim : KB_EINV
 int kb_light_count(const kb_sim *sim) { return sim ? (sim->cfg.light_type == KB_LIGHT_NONE ? 0 : sim->p.lcount) : KB_EINVAL; }
 size_t kb_scratch_bytes(const kb_sim *sim) { return sim ? (size_t)sim->p.E * (size_t)sim->p.cap * 16u : 0; }
 int kb_contact_capacity(const kb_sim *sim) { return sim ? sim->p.cap : KB_EINVAL; }
+int kb_lds_staging_entries(const kb_sim *sim) { return sim ? sim->p.capL : KB_EINVAL; }
 int kb_block_threads(const kb_sim *sim) { return sim ? sim->threads : KB_EINVAL; }
 int kb_set_block_threads(kb_sim *sim, int threads) {
     if (!sim || threads < 64 || threads > 64 * MAX_WAVES || (threads & 63)) return fail(KB_EINVAL, "kb_set_block_threads: multiple of 64 up to the build maximum");

@@ -23,6 +23,9 @@ constexpr float B2_MAX_ROTATION_SQ = B2_MAX_ROTATION * B2_MAX_ROTATION;
 constexpr float B2_EPSILON = 1.19209290e-07f;
 constexpr float B2_TOI_BAUMGARTE = 0.75f;
 constexpr int B2_MAX_SUBSTEPS = 8;     // b2World::SolveTOI k_maxSubSteps
+constexpr float B2_TIME_TO_SLEEP = 0.5f;                                  // b2_timeToSleep
+constexpr float B2_LINEAR_SLEEP_TOL = 0.01f;                              // b2_linearSleepTolerance
+constexpr float B2_ANGULAR_SLEEP_TOL = 2.0f / 180.0f * B2_PI;             // b2_angularSleepTolerance
 constexpr float WORLD_SCALE = 25.0f;  // body.py:7
 
 constexpr float CELL_SIZE = 0.875f;   // world units, >= 2 * bot radius
@@ -95,7 +98,8 @@ constexpr int OBJW = OBJLIST + A16(2 * KB_MAX_OBJECTS * OBJ_LIST);       // angu
 constexpr int OBJA = OBJW + A16(4 * KB_MAX_OBJECTS);
 constexpr int OBJA0 = OBJA + A16(4 * KB_MAX_OBJECTS);
 constexpr int MCMASK = OBJA0 + A16(4 * KB_MAX_OBJECTS);                  // per wave: which manifold constraints it owns (u64)
-constexpr int OBJ_AREA = MCMASK + A16(8 * (MAX_WAVES + 1));
+constexpr int OBJSLP = MCMASK + A16(8 * (MAX_WAVES + 1));                // sleeping: b2Body::m_sleepTime of the objects (< 0: asleep)
+constexpr int OBJ_AREA = OBJSLP + A16(4 * KB_MAX_OBJECTS);
 __host__ __device__ constexpr int fixed(bool obj, int nw) { return objtab(nw) + (obj ? OBJ_AREA : 0); }
 // per-body 32-bit arrays (stride 4 * NB): px py vx vy x0 y0 dirCnt parent
 constexpr int BODY32_COUNT = 8;
@@ -172,6 +176,7 @@ struct Params {
     int nmc;                                  // manifold-constraint candidates: pairs + 4 walls per object
     int lds_total;
     int nhead, hmask;                         // cell heads: nhead entries; hmask != 0: a hash table of the cells (slot = cell & hmask)
+    int allow_sleep;                          // kb_config.allow_sleep: the SLEEP instantiations are launched
     int sense_s;                              // IR neighbour sensing: reach of the stencil in cells (0 = off)
     float sense_r2;                           // ... and the squared radius in world units
 };
@@ -611,6 +616,7 @@ __device__ __forceinline__ unsigned block_scan_u8(const unsigned char *cnt, unsi
 
 
 typedef void (*kb_step_fn)(const Params);
+constexpr int KB_PICK_SLEEP = 16;      // kb_pick_*(..., objects | KB_PICK_SLEEP): the instantiation with the sleep state
 constexpr int KB_PICK_FIXED_1024 = -1024, KB_PICK_FIXED_1024_SENSE = -1025;   // ... the same with the neighbour-sensing hook   // kb_pick_velocity: the num_bots == 1024 specialisations (no light; without / with objects)
 // one translation unit per drive law (kb_inst_d*.hip) instantiates its kernels and hands out the right one
 kb_step_fn kb_pick_velocity(int light_type, int objects);   // objects: 0 none, 1 yes, 2 yes + one-wave workgroup

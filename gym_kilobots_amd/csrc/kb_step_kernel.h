@@ -24,10 +24,14 @@ namespace kb {
 //   1: "WIDE", one-wave workgroups in scenes with objects: 256 VGPRs (2 waves per SIMD), no spills;
 //   2: 80 VGPRs (6 waves per SIMD): three 8-wave / six 4-wave workgroups per CU where the LDS image admits them.
 // The fixed-size kernel without objects is always tier 2.
-template <int DRIVE_MODE, int LIGHT_TYPE, bool OBJ, int FN = 0, int TIER = 0, bool POLY = true, bool SENSE = true>
+// SLEEP = true: b2World(doSleep=True) of kilobots_env.py:45 -- bodies carry b2Body::m_sleepTime, islands without an awake
+// body are not solved (b2World::Solve), islands at rest for b2_timeToSleep whose position constraints converged fall asleep
+// (b2Island::Solve).  Generic kernels only; kb_step picks it when kb_config.allow_sleep != 0.
+template <int DRIVE_MODE, int LIGHT_TYPE, bool OBJ, int FN = 0, int TIER = 0, bool POLY = true, bool SENSE = true, bool SLEEP = false>
 __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 ? 2 : ((TIER == 2 || (FN != 0 && !OBJ)) ? KB_COMPACT_WAVES_PER_SIMD : KB_MIN_WAVES_PER_SIMD)) kb_step_kernel(const Params p) {
     constexpr bool WIDE = TIER == 1;
     constexpr bool COMPACT = !OBJ;
+    static_assert(!SLEEP || FN == 0, "the fixed-size instantiations do not carry the sleep state");
     constexpr bool FOLD = FN != 0 && !OBJ;       // lCbk over nextb (needs capL <= NP)
     extern __shared__ __align__(16) unsigned char smem[];
     int e = blockIdx.x;
@@ -77,6 +81,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
     unsigned short *objList = (unsigned short *)(smem + ot_ + lds::OBJLIST);   // ... and who they are
     float *objW = (float *)(smem + ot_ + lds::OBJW), *objA = (float *)(smem + ot_ + lds::OBJA), *objA0 = (float *)(smem + ot_ + lds::OBJA0);
     unsigned long long *mcMask = (unsigned long long *)(smem + ot_ + lds::MCMASK);   // manifold constraints owned by wave w
+    float *objSlp = (float *)(smem + ot_ + lds::OBJSLP);                              // sleep time of object m (< 0: asleep)
     const int M = OBJ ? p.M : 0;   // OBJ = false: every object loop below folds away
     // inverse mass / radius of a body id: kilobot < N, object N + m, wall >= WALL_CODE (static, edge skin radius)
     auto bim = [&](int id) __attribute__((always_inline)) -> float {
@@ -131,13 +136,15 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
     // ---- load state; optional fused set_action (kilobot.py:235-241, 283-289) ----
     float th[BPT], bw[BPT], cv[BPT], cw[BPT], av[BPT], aw[BPT];
     float sth0[BPT];     // angle at the start of the substep (continuous step against the walls)
+    float slp[BPT];      // SLEEP: b2Body::m_sleepTime; < 0: the kilobot is asleep
     const bool velmode = DRIVE_MODE == KB_DRIVE_VELOCITY || DRIVE_MODE == KB_DRIVE_ACCEL;
 #pragma unroll
     for (int q = 0; q < BPT; ++q) {
         const int b = tid + q * nt;
-        th[q] = 0.0f; bw[q] = 0.0f; cv[q] = 0.0f; cw[q] = 0.0f; av[q] = 0.0f; aw[q] = 0.0f;
+        th[q] = 0.0f; bw[q] = 0.0f; cv[q] = 0.0f; cw[q] = 0.0f; av[q] = 0.0f; aw[q] = 0.0f; slp[q] = 0.0f;
         if (b < N) {
             pos[b].x = g.x[o + b]; pos[b].y = g.y[o + b]; th[q] = g.theta[o + b];
+            if (SLEEP) slp[q] = g.sleep_time[o + b];
             wsCnt[b] = g.ws_cnt[o + b];
             // (a velocity action replaces the stored command: nothing to load then)
             if (velmode && !(DRIVE_MODE == KB_DRIVE_VELOCITY && p.actions)) { cv[q] = g.v[o + b]; cw[q] = g.w[o + b]; }
@@ -179,6 +186,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
         const size_t oi = (size_t)e * M + tid;
         pos[N + tid].x = g.ox[oi]; pos[N + tid].y = g.oy[oi]; vel[N + tid].x = g.ovx[oi]; vel[N + tid].y = g.ovy[oi];
         objA[tid] = g.otheta[oi]; objW[tid] = g.ow[oi];
+        if (SLEEP) objSlp[tid] = g.osleep[oi];
         const float lx = p.obody[tid][BT_LCX], ly = p.obody[tid][BT_LCY];
         if (lx != 0.0f || ly != 0.0f) {    // the state holds the body origin, the solver works on the centre of mass
             const XF t = xf_make(g.ox[oi], g.oy[oi], g.otheta[oi]);
@@ -309,6 +317,14 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
                 }
             }
             if (g.cmd_vx) { g.cmd_vx[o + b] = bvx; g.cmd_vy[o + b] = bvy; g.cmd_w[o + b] = bww; }
+            if (SLEEP) {
+                // kilobot.py:123-127 assigns angularVelocity / linearVelocity: b2Body::SetAngularVelocity / SetLinearVelocity
+                // wake a sleeping body iff the value is non-zero (w * w > 0, b2Dot(v, v) > 0); one that stays asleep has
+                // zero velocity
+                if (drive && slp[q] < 0.0f && (bww * bww > 0.0f || bvx * bvx + bvy * bvy > 0.0f)) slp[q] = 0.0f;
+                if (slp[q] < 0.0f) { bvx = 0.0f; bvy = 0.0f; bww = 0.0f; }
+                active[b] = 0;       // "the island rooted here has an awake body": set in the flatten phase
+            }
             // b2Island::Solve: v *= 1/(1 + h c)  (SimplePhototaxisKilobot sets linearDamping = 0, kilobot.py:203)
             const float kl = (DRIVE_MODE == KB_DRIVE_SIMPLE_PHOTOTAXIS) ? 1.0f / (1.0f + h * 0.0f) : p.kl_bot;
             vel[b].x = bvx * kl; vel[b].y = bvy * kl; bw[q] = bww * p.ka_bot;
@@ -328,6 +344,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
             vel[N + tid].x *= p.kl_obj; vel[N + tid].y *= p.kl_obj; objW[tid] *= p.ka_obj;
             parent[N + tid] = N + tid;
             objCnt[tid] = 0;
+            if (SLEEP) active[N + tid] = 0;
         }
         if (OBJ && tid >= M && tid < F) objCnt[tid] = 0;
         if (tid < M_COUNT && tid != M_STATUS) misc[tid] = 0;
@@ -614,7 +631,8 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
             islCnt[b] = 0;
             islWave[b] = (unsigned char)((unsigned)b % (unsigned)nw);
             if (!COMPACT) head[hix(cellOf[b])] = EMPTY16;     // (compact image: the area becomes the bucket tables; cleared at the end)
-            active[b] = 1; active[NB + b] = 0;
+            if (!SLEEP) active[b] = 1;
+            active[NB + b] = 0;
             if (SENSE && p.sense_s > 0 && drive) g.nbr_count[o + b] = (unsigned)newOff[b];
         }
         if (tid < 64) bkStart[tid] = 0;     // size-class counters of the island placement
@@ -626,7 +644,18 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
             parent[b] = r;
             islCnt[b] = 0;
             islWave[b] = (unsigned char)((unsigned)b % (unsigned)nw);
-            active[b] = 1; active[NB + b] = 0;
+            if (!SLEEP) active[b] = 1;
+            active[NB + b] = 0;
+        }
+        if (SLEEP) {
+            // b2World::Solve: islands grow from awake seeds.  active[root] = 1 iff the island has an awake body (every writer
+            // stores the same value; the flags were cleared in the drive phase); islands without one are not solved at all.
+#pragma unroll
+            for (int q = 0; q < BPT; ++q) {
+                const int b = tid + q * nt;
+                if (b < N && !(slp[q] < 0.0f)) active[parent[b]] = 1;
+            }
+            if (tid < M && !(objSlp[tid] < 0.0f)) active[parent[N + tid]] = 1;
         }
         const unsigned newTotal = block_scan_u8(wsCntNew, newOff, NP, wsum);   // (barriers inside)
         const bool newInLds = !COMPACT && newTotal <= (unsigned)capL_;
@@ -743,7 +772,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
             reg = maxw <= 64u * KREG;
         }
         if (OBJ && wave == 0) {   // which wave sweeps which manifold constraint (slot nw: all of them)
-            const bool on = lane < NMC && mcTouch;
+            const bool on = lane < NMC && mcTouch && (!SLEEP || active[mci(ox, MC_ISL, lane)] != 0);
             const unsigned w_ = on ? (unsigned)islWave[mci(ox, MC_ISL, lane)] : 0u;
             for (int w = 0; w < nw; ++w) {
                 const unsigned long long mk = __ballot(on && (int)w_ == w);
@@ -759,7 +788,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
         auto mc_velocity_pass = [&](unsigned long long mask, bool leader) __attribute__((always_inline)) {
             if (leader) for (unsigned long long m_ = mask; m_; m_ &= m_ - 1) mc_solve_velocity(ox, __builtin_ctzll(m_));
         };
-        auto mc_position_pass = [&](unsigned long long mask, bool leader, const unsigned char *act, unsigned char *nxt) __attribute__((always_inline)) -> bool {
+        auto mc_position_pass = [&](unsigned long long mask, bool leader, const unsigned char *act, unsigned char *nxt, bool lastIt) __attribute__((always_inline)) -> bool {
             bool viol = false;
             if (leader)
                 for (unsigned long long m_ = mask; m_; m_ &= m_ - 1) {
@@ -767,7 +796,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
                     const int isl = mci(ox, MC_ISL, t);
                     if (!act[isl]) continue;
                     const float minSep = mc_solve_position(ox, t, B2_BAUMGARTE);
-                    if (minSep < -3.0f * B2_LINEAR_SLOP) { nxt[isl] = 1; viol = true; }
+                    if (minSep < -3.0f * B2_LINEAR_SLOP) { nxt[isl] = 1; viol = true; if (SLEEP && lastIt) islWave[isl] = 3; }
                 }
             return viol;
         };
@@ -802,6 +831,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
             __syncthreads();
             for (int c = tid; c < ncon; c += nt) {
                 const unsigned root = parent[sPair[c] >> 16];
+                if (SLEEP && !active[root]) { cbk[c] = EMPTY16; continue; }      // sleeping island: never swept
                 const int w = coop ? 0 : (int)islWave[root];
                 const unsigned inf = sInfo[c];
                 const int cls = inf & 0x7F, r = (inf >> 8) & 0xFF;
@@ -825,6 +855,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
             __syncthreads();
             for (int c = tid; c < ncon; c += nt) {
                 const int bk = cbk[c];
+                if (SLEEP && bk == (int)EMPTY16) continue;
                 order[bkStart[bk] + atomicAdd(&bkFill[bk], 1u)] = (unsigned short)c;
             }
             if (wave < W) {   // every (virtual) wave compacts the list of its non-empty buckets, in key order
@@ -885,9 +916,13 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
                     const int cls = inf & 0x7F, r = (inf >> 8) & 0xFF;
                     rc[j] = c; ra[j] = pr & 0xFFFF; rb[j] = pr >> 16; rrank[j] = r;
                     const int key = cls * RK + (r < RK - 1 ? r : RK - 1);
-                    rkey[j] = key;
-                    if (key < 32) mlo |= 1u << key; else mhi |= 1u << (key - 32);
-                    if (r >= RK - 1) atomicMax(&bkMaxRank[wave * NUM_CLS + cls], (unsigned)r);
+                    if (SLEEP && !active[parent[rb[j]]]) {
+                        rkey[j] = -1;        // contact of a sleeping island: in no round (depth 0), its impulse is carried over
+                    } else {
+                        rkey[j] = key;
+                        if (key < 32) mlo |= 1u << key; else mhi |= 1u << (key - 32);
+                        if (r >= RK - 1) atomicMax(&bkMaxRank[wave * NUM_CLS + cls], (unsigned)r);
+                    }
                 }
             }
             // keys present in this wave (wave-uniform 52-bit mask)
@@ -966,7 +1001,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
             // the slots that hold contacts of its level. ----
             if (KREG > 1 && mycnt > 64u) {
                 unsigned base_ = 0;
-                for (int d_ = 1; d_ <= maxD; ++d_) {
+                for (int d_ = SLEEP ? 0 : 1; d_ <= maxD; ++d_) {      // (depth 0: contacts of sleeping islands)
 #pragma unroll
                     for (int j = 0; j < KREG; ++j) {
                         const bool is = rvalid[j] && rdepth[j] == d_;
@@ -1213,6 +1248,9 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
                 pos[b].x += h * vxx; pos[b].y += h * vyy;
                 th[q] += h * ww;
                 vel[b].x = vxx; vel[b].y = vyy; bw[q] = ww;
+                // (islWave is idle from here on) island state for the sleep bookkeeping: bit 1 = has an awake body,
+                // bit 0 = position constraints not solved (set by the last position sweep; always without sweeps)
+                if (SLEEP) islWave[b] = (unsigned char)((active[b] ? 2 : 0) | (p.pos_iters <= 0 ? 1 : 0));
             }
             if (tid < M) {   // objects: same integrator (b2Island writes the clamped velocity back to the body)
                 const int b = N + tid;
@@ -1227,6 +1265,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
                 vel[b].x = vxx; vel[b].y = vyy; objW[tid] = ww;
                 pos[b].x += h * vxx; pos[b].y += h * vyy;
                 objA[tid] += h * ww;
+                if (SLEEP) islWave[b] = (unsigned char)((active[b] ? 2 : 0) | (p.pos_iters <= 0 ? 1 : 0));
             }
             __syncthreads();
             KB_STAMP(5);
@@ -1258,7 +1297,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
                             const V2 clipPoint = mk2(pos[a].x, pos[a].y);
                             const float sep = v_dot(v_sub(clipPoint, planePoint), normal) - T[BT_RADIUS] - p.r_bot;
                             const V2 rA = v_sub(clipPoint, mk2(pos[b].x, pos[b].y));
-                            if (sep < -3.0f * B2_LINEAR_SLOP) { nxt[isl] = 1; viol = true; }
+                            if (sep < -3.0f * B2_LINEAR_SLOP) { nxt[isl] = 1; viol = true; if (SLEEP && it == p.pos_iters - 1) islWave[isl] = 3; }
                             const float C = kb_clampf(B2_BAUMGARTE * (sep + B2_LINEAR_SLOP), -B2_MAX_LINEAR_CORRECTION, 0.0f);
                             const float rnA = v_cross(rA, normal);
                             const float K = T[BT_IM] + p.im_bot + T[BT_II] * rnA * rnA;
@@ -1287,7 +1326,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
                             if (!(len < B2_EPSILON)) { const float inv = 1.0f / len; nx = dx * inv; ny = dy * inv; }
                             sep = (dx * nx + dy * ny) - R_RA(j) - R_RB(j);
                         }
-                        if (sep < -3.0f * B2_LINEAR_SLOP) { nxt[isl] = 1; viol = true; }
+                        if (sep < -3.0f * B2_LINEAR_SLOP) { nxt[isl] = 1; viol = true; if (SLEEP && it == p.pos_iters - 1) islWave[isl] = 3; }
                         const float C = kb_clampf(B2_BAUMGARTE * (sep + B2_LINEAR_SLOP), -B2_MAX_LINEAR_CORRECTION, 0.0f);
                         const float K = ima + imb;
                         const float imp = K > 0.0f ? -C / K : 0.0f;
@@ -1297,7 +1336,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
                     }
                     wave_sync();
                 }
-                if (OBJ && myMc) { viol |= mc_position_pass(myMc, lane == 0, act, nxt); wave_sync(); }
+                if (OBJ && myMc) { viol |= mc_position_pass(myMc, lane == 0, act, nxt, it == p.pos_iters - 1); wave_sync(); }
 #ifdef KB_PROFILE
                 if (tid == 0) prof_acc[10] += 1;
 #endif
@@ -1484,6 +1523,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
                     pos[b].x += h * vxx; pos[b].y += h * vyy;
                     th[q] += h * ww;
                     vel[b].x = vxx; vel[b].y = vyy; bw[q] = ww;
+                    if (SLEEP) islWave[b] = (unsigned char)((active[b] ? 2 : 0) | (p.pos_iters <= 0 ? 1 : 0));
                 }
                 if (tid < M) {   // objects
                     const int b = N + tid;
@@ -1498,6 +1538,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
                     vel[b].x = vxx; vel[b].y = vyy; objW[tid] = ww;
                     pos[b].x += h * vxx; pos[b].y += h * vyy;
                     objA[tid] += h * ww;
+                    if (SLEEP) islWave[b] = (unsigned char)((active[b] ? 2 : 0) | (p.pos_iters <= 0 ? 1 : 0));
                 }
                 __syncthreads();
                 KB_STAMP(5);
@@ -1523,7 +1564,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
                             const V2 clipPoint = mk2(pos[a].x, pos[a].y);
                             const float sep = v_dot(v_sub(clipPoint, planePoint), normal) - T[OT_RADIUS] - p.r_bot;
                             const V2 rA = v_sub(clipPoint, mk2(pos[b].x, pos[b].y));
-                            if (sep < -3.0f * B2_LINEAR_SLOP) { nxt[isl] = 1; viol = true; }
+                            if (sep < -3.0f * B2_LINEAR_SLOP) { nxt[isl] = 1; viol = true; if (SLEEP && it == p.pos_iters - 1) islWave[isl] = 3; }
                             const float C = kb_clampf(B2_BAUMGARTE * (sep + B2_LINEAR_SLOP), -B2_MAX_LINEAR_CORRECTION, 0.0f);
                             const float rnA = v_cross(rA, normal);
                             const float K = T[OT_IM] + p.im_bot + T[OT_II] * rnA * rnA;
@@ -1552,7 +1593,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
                                 if (!(len < B2_EPSILON)) { const float inv = 1.0f / len; nx = dx * inv; ny = dy * inv; }
                                 sep = (dx * nx + dy * ny) - rda - rdb;
                             }
-                            if (sep < -3.0f * B2_LINEAR_SLOP) { nxt[isl] = 1; viol = true; }
+                            if (sep < -3.0f * B2_LINEAR_SLOP) { nxt[isl] = 1; viol = true; if (SLEEP && it == p.pos_iters - 1) islWave[isl] = 3; }
                             const float C = kb_clampf(B2_BAUMGARTE * (sep + B2_LINEAR_SLOP), -B2_MAX_LINEAR_CORRECTION, 0.0f);
                             const float K = ima + imb;
                             const float imp = K > 0.0f ? -C / K : 0.0f;
@@ -1561,7 +1602,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
                             pos[b].x = bx + imb * Px; pos[b].y = by + imb * Py;
                         }
                     })
-                    if (OBJ && myMc) { viol |= mc_position_pass(myMc, leader, act, nxt); KB_ROUND_SYNC(); }
+                    if (OBJ && myMc) { viol |= mc_position_pass(myMc, leader, act, nxt, it == p.pos_iters - 1); KB_ROUND_SYNC(); }
                     bool any;
                     if (coop) {
                         if (viol) misc[M_ANY] = 1u;
@@ -1589,6 +1630,62 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
         }
         __syncthreads();
         KB_RETID();
+        if (SLEEP) {
+            // ---- b2Island::Solve, the allowSleep block: a body slower than the sleep tolerances accumulates sleep time; an
+            // island (awake ones only: bit 1 of islWave[root]) whose bodies have all rested for b2_timeToSleep and whose
+            // position constraints converged (bit 0 clear) is put to sleep: b2Body::SetAwake(false) zeroes the sleep time and
+            // the velocities.  Bodies of an awake island that were asleep have been woken by it (b2World::Solve).
+            // Per island: minimum of the sleep times (non-negative floats order like their bit patterns) in the contact
+            // staging area, which is idle between the position sweeps and the continuous step (2 capL >= NB words).
+            unsigned *islMin = lPair;
+            const float linTolSqr = B2_LINEAR_SLEEP_TOL * B2_LINEAR_SLEEP_TOL, angTolSqr = B2_ANGULAR_SLEEP_TOL * B2_ANGULAR_SLEEP_TOL;
+            for (int b = tid; b < N + M; b += nt) islMin[b] = 0x7F7FFFFFu;      // b2_maxFloat
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < BPT; ++q) {
+                const int b = tid + q * nt;
+                if (b >= N) continue;
+                const unsigned r = parent[b];
+                if (!(islWave[r] & 2)) continue;
+                if (slp[q] < 0.0f) slp[q] = 0.0f;
+                const float2 v_ = vel[b];
+                if (bw[q] * bw[q] > angTolSqr || v_.x * v_.x + v_.y * v_.y > linTolSqr) { slp[q] = 0.0f; atomicMin(&islMin[r], 0u); }
+                else { slp[q] += h; atomicMin(&islMin[r], __float_as_uint(slp[q])); }
+            }
+            if (tid < M) {
+                const int b = N + tid;
+                const unsigned r = parent[b];
+                if (islWave[r] & 2) {
+                    float sl = objSlp[tid];
+                    if (sl < 0.0f) sl = 0.0f;
+                    const float2 v_ = vel[b];
+                    const float w_ = objW[tid];
+                    if (w_ * w_ > angTolSqr || v_.x * v_.x + v_.y * v_.y > linTolSqr) { sl = 0.0f; atomicMin(&islMin[r], 0u); }
+                    else { sl += h; atomicMin(&islMin[r], __float_as_uint(sl)); }
+                    objSlp[tid] = sl;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < BPT; ++q) {
+                const int b = tid + q * nt;
+                if (b >= N) continue;
+                const unsigned r = parent[b];
+                const unsigned st_ = islWave[r];
+                if ((st_ & 2) && !(st_ & 1) && __uint_as_float(islMin[r]) >= B2_TIME_TO_SLEEP) {
+                    slp[q] = -1.0f; vel[b].x = 0.0f; vel[b].y = 0.0f; bw[q] = 0.0f;
+                }
+            }
+            if (tid < M) {
+                const int b = N + tid;
+                const unsigned r = parent[b];
+                const unsigned st_ = islWave[r];
+                if ((st_ & 2) && !(st_ & 1) && __uint_as_float(islMin[r]) >= B2_TIME_TO_SLEEP) {
+                    objSlp[tid] = -1.0f; vel[b].x = 0.0f; vel[b].y = 0.0f; objW[tid] = 0.0f;
+                }
+            }
+            __syncthreads();       // islMin is read; the continuous step reuses the staging area
+        }
         // ---- b2World::SolveTOI: continuous step of every dynamic body against the static walls ----
         // Only bodies that come within their contact radius of a wall can have a TOI event.  They are collected in
         // a candidate list (in the staging area, idle after the solve) and processed one per thread, so that
@@ -1604,6 +1701,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
                 const int b = tid + q * nt;
                 cand[q] = -1;
                 if (b >= N) continue;
+                if (SLEEP && slp[q] < 0.0f) continue;           // b2World::SolveTOI skips contacts without an awake dynamic body
                 const float total = p.r_bot + B2_POLYGON_RADIUS;
                 const float xa = COMPACT ? startX[b] : start[b].x, ya = COMPACT ? startY[b] : start[b].y, xb = pos[b].x, yb = pos[b].y;
                 const float m0 = fminf(fminf(xa - p.xmin, p.xmax - xa), fminf(ya - p.ymin, p.ymax - ya));
@@ -1624,7 +1722,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
                 kb_toi_walls_body(p, R, im, COMPACT ? startX[b] : start[b].x, COMPACT ? startY[b] : start[b].y, cTh0[i], x_, y_, a_, vx_, vy_, w_);
                 pos[b].x = x_; pos[b].y = y_; vel[b].x = vx_; vel[b].y = vy_; cTh[i] = a_; cW[i] = w_;
             }
-            if (OBJ && tid < M) {   // objects: the TOI sub-solve runs on the manifold-constraint records of their wall contacts
+            if (OBJ && tid < M && !(SLEEP && objSlp[tid] < 0.0f)) {   // objects: the TOI sub-solve runs on the manifold-constraint records of their wall contacts
                 Arena ar;
                 ar.xmin = p.xmin; ar.ymin = p.ymin; ar.xmax = p.xmax; ar.ymax = p.ymax;
                 toi_walls_object(ox, ar, F, tid, start[N + tid].x, start[N + tid].y, objA0[tid], p.h, p.vel_iters,
@@ -1661,6 +1759,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
         const int b = tid + q * nt;
         if (b < N) {
             g.x[o + b] = pos[b].x; g.y[o + b] = pos[b].y; g.theta[o + b] = th[q];
+            if (SLEEP && p.n_substeps > 0) g.sleep_time[o + b] = slp[q];
             if (p.n_substeps > 0) g.ws_cnt[o + b] = wsCnt[b];
             if (DRIVE_MODE == KB_DRIVE_ACCEL && p.n_substeps > 0 && drive) { g.v[o + b] = cv[q]; g.w[o + b] = cw[q]; }
         }
@@ -1673,6 +1772,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
             g.ox[oi] = t.p.x; g.oy[oi] = t.p.y;
         }
         g.ovx[oi] = vel[N + tid].x; g.ovy[oi] = vel[N + tid].y; g.ow[oi] = objW[tid];
+        if (SLEEP) g.osleep[oi] = objSlp[tid];
     }
     if (tid == 0) {
         if (LIGHT_TYPE == KB_LIGHT_CIRCULAR && p.light_action && drive) { g.light_x[e] = lx; g.light_y[e] = ly; }
@@ -1700,6 +1800,12 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
 // one-wave workgroup (the WIDE instantiation), 3 none at 80 VGPRs (six waves per SIMD)
 template <int DRIVE_MODE, int LIGHT_TYPE>
 static kb_step_fn kb_pick_obj(int objects) {
+    if (objects & KB_PICK_SLEEP) {     // kb_config.allow_sleep: 128-VGPR generic instantiations (none / objects / objects + one wave)
+        const int o_ = objects & ~KB_PICK_SLEEP;
+        if (o_ == 2) return kb_step_kernel<DRIVE_MODE, LIGHT_TYPE, true, 0, 1, true, true, true>;
+        if (o_ == 1) return kb_step_kernel<DRIVE_MODE, LIGHT_TYPE, true, 0, 0, true, true, true>;
+        return kb_step_kernel<DRIVE_MODE, LIGHT_TYPE, false, 0, 0, true, true, true>;
+    }
     if (objects == 2) return kb_step_kernel<DRIVE_MODE, LIGHT_TYPE, true, 0, 1>;
     if (objects == 3) return kb_step_kernel<DRIVE_MODE, LIGHT_TYPE, false, 0, 2>;
     return objects ? kb_step_kernel<DRIVE_MODE, LIGHT_TYPE, true> : kb_step_kernel<DRIVE_MODE, LIGHT_TYPE, false>;

@@ -60,12 +60,14 @@ class KilobotsEnv(object):
                             np.array([cls.world_width / 2, cls.world_height / 2]))
         return super(KilobotsEnv, cls).__new__(cls)
 
-    def __init__(self, num_envs=1, device=None, sim_factory=None, on_status='raise', **kwargs):
+    def __init__(self, num_envs=1, device=None, sim_factory=None, on_status='raise', allow_sleep=True, **kwargs):
         # on_status: what reset() / step() do when the device step reports a capacity overflow (dropped contacts, lost
         # warm-start impulses, staging limits: include/kilobots_hip.h, kb_buffers.status): 'raise' | 'warn' | 'ignore'
         if on_status not in ('raise', 'warn', 'ignore'):
             raise ValueError("on_status must be 'raise', 'warn' or 'ignore'")
         self._on_status = on_status
+        # allow_sleep: the reference creates its world with doSleep=True (kilobots_env.py:45): islands at rest fall asleep
+        self._allow_sleep = bool(allow_sleep)
         self.__sim_steps = 0
         self.__reset_counter = 0
         self.__seed = 0
@@ -265,7 +267,8 @@ class KilobotsEnv(object):
                          vel_iters=self.__sim_velocity_iterations, pos_iters=self.__sim_position_iterations,
                          bot_density=float(type(kbs[0])._density), bot_radius=float(type(kbs[0])._radius),
                          bot_linear_damping=float(type(kbs[0])._linear_damping),
-                         bot_angular_damping=float(type(kbs[0])._angular_damping))
+                         bot_angular_damping=float(type(kbs[0])._angular_damping),
+                         allow_sleep=1 if self._allow_sleep else 0)      # b2World(gravity=(0, 0), doSleep=True), kilobots_env.py:45
         if self._objects:
             ob0 = type(self._objects[0])
             pad = nat.MAX_OBJECTS - len(specs)

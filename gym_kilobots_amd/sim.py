@@ -74,6 +74,12 @@ class KilobotSim:
             self.ox, self.oy, self.otheta = f(E, M), f(E, M), f(E, M)
             self.ovx, self.ovy, self.ow = f(E, M), f(E, M), f(E, M)
             self.ows_acc = torch.full((E, nat.MAX_OBJECTS, nat.OWS_COLS, nat.OWS_WORDS), -1.0, dtype=torch.float32, device=dev)
+        # sleeping (kb_config.allow_sleep): b2Body::m_sleepTime of every kilobot / object, < 0 = asleep
+        self.sleep_time = self.osleep = None
+        if self.cfg.allow_sleep:
+            self.sleep_time = f(E, N)
+            if M > 0:
+                self.osleep = f(E, M)
         # IR-range neighbour sensing (kb_config.sense_radius): counts of the last substep's sensing point
         self.nbr_count = None
         if self.cfg.sense_radius > 0.0:
@@ -125,6 +131,11 @@ class KilobotSim:
         return self._lib.kb_contact_capacity(self._h)
 
     @property
+    def lds_staging_entries(self):
+        """Contacts of one env that are staged in LDS (an env with more takes the global staging slice for that substep)."""
+        return self._lib.kb_lds_staging_entries(self._h)
+
+    @property
     def block_threads(self):
         return self._lib.kb_block_threads(self._h)
 
@@ -139,6 +150,8 @@ class KilobotSim:
         self.x.copy_(torch.from_numpy(np.ascontiguousarray(xy[..., 0].astype(np.float32))).reshape(self.x.shape))
         self.y.copy_(torch.from_numpy(np.ascontiguousarray(xy[..., 1].astype(np.float32))).reshape(self.y.shape))
         self.theta.copy_(torch.from_numpy(np.ascontiguousarray(np.asarray(theta, np.float32))).reshape(self.theta.shape))
+        if self.sleep_time is not None:
+            self.sleep_time.zero_()          # re-created bodies are awake
         self.forget_contacts()
 
     def forget_contacts(self):
@@ -159,6 +172,8 @@ class KilobotSim:
         self.ovx.zero_()
         self.ovy.zero_()
         self.ow.zero_()
+        if self.osleep is not None:
+            self.osleep.zero_()
         self.forget_contacts()
 
     def object_poses(self):

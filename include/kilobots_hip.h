@@ -130,6 +130,17 @@ typedef struct kb_config {
                                                    max(4 N + 64, min(N (N - 1) / 2 + 4 N, 2304)) + 40 objects.  A spawn that
                                                    overlaps more kilobots than that sets status bit 0; raise it (<= 65528) then:
                                                    the entries live in HBM (24 B each), not in LDS */
+    int32_t allow_sleep;                        /* [0] b2World(gravity, doSleep=True) of kilobots_env.py:45: bodies carry
+                                                   b2Body::m_sleepTime (kb_buffers.sleep_time / osleep, seconds; < 0: asleep).  An
+                                                   island whose bodies all stayed below b2_linearSleepTolerance /
+                                                   b2_angularSleepTolerance for b2_timeToSleep = 0.5 s and whose position
+                                                   constraints converged falls asleep (b2Island::Solve: velocities zeroed); islands
+                                                   without an awake body are not simulated (b2World::Solve); a body wakes when a
+                                                   non-zero velocity is assigned to it (Kilobot.step -> b2Body::SetLinearVelocity /
+                                                   SetAngularVelocity) or an awake island reaches it.  The envs of
+                                                   gym_kilobots_amd.envs switch it on like the reference; the fixed-size benchmark
+                                                   instantiations do not carry the state (sleeping cannot change a trajectory in
+                                                   which every kilobot is commanded to move in every substep: DESIGN.md) */
 } kb_config;
 
 enum kb_damping_model { KB_DAMPING_PADE = 0, KB_DAMPING_LINEAR = 1 };
@@ -168,6 +179,9 @@ typedef struct kb_buffers {
                                            contacts: b2ManifoldPoint id / normalImpulse / tangentImpulse; fill with -1
                                            to forget them */
     uint32_t *nbr_count;                /* sense_radius > 0: [num_envs][num_bots] neighbours within IR range (output; required then) */
+    float *sleep_time;                  /* allow_sleep: [num_envs][num_bots] b2Body::m_sleepTime in seconds, < 0 = asleep (required then;
+                                           zero-fill = awake) */
+    float *osleep;                      /* allow_sleep with objects: the same for the objects, [num_envs][num_objects] */
 } kb_buffers;
 
 typedef struct kb_sim kb_sim;
@@ -238,6 +252,8 @@ int kb_lds_bytes(const kb_sim *sim);            /* dynamic LDS per workgroup (on
 int kb_light_action_dim(const kb_sim *sim);     /* floats per env in d_light_action */
 int kb_light_count(const kb_sim *sim);          /* light components per env (0 without a light) */
 int kb_contact_capacity(const kb_sim *sim);     /* contacts (and warm-start entries) per env */
+int kb_lds_staging_entries(const kb_sim *sim);  /* contacts of one env that are staged in LDS; an env with more takes its slice of
+                                                   kb_buffers.scratch for that substep (same results, slower) */
 size_t kb_scratch_bytes(const kb_sim *sim);     /* size of kb_buffers.scratch */
 int kb_block_threads(const kb_sim *sim);
 int kb_resident_envs_per_cu(kb_sim *sim);        /* workgroups (= envs) of this handle's kernel that one CU holds at a time (HIP occupancy query; needs a GPU) */

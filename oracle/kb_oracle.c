@@ -48,6 +48,9 @@
 #define B2_PI 3.14159265359f
 #define B2_LINEAR_SLOP 0.005f
 #define B2_POLYGON_RADIUS (2.0f * B2_LINEAR_SLOP)
+#define B2_TIME_TO_SLEEP 0.5f                                   /* b2Settings.h: b2_timeToSleep */
+#define B2_LINEAR_SLEEP_TOL 0.01f                               /* b2_linearSleepTolerance */
+#define B2_ANGULAR_SLEEP_TOL (2.0f / 180.0f * 3.14159265359f)   /* b2_angularSleepTolerance (b2_pi) */
 #define B2_BAUMGARTE 0.2f
 #define B2_MAX_LINEAR_CORRECTION 0.2f
 #define B2_MAX_TRANSLATION 2.0f
@@ -407,6 +410,7 @@ typedef struct {
     int owner, slot;    /* warm-start slot (owner bot, slot index) or -1 */
     /* kilobot - polygon object (b2CollidePolygonAndCircle; Box2D's A = the polygon = body b, B = the kilobot = body a) */
     int poly, fix;      /* fix: the fixture of the object that is touched */
+    int skip;           /* sleeping: both bodies belong to an island without an awake body, the contact is not solved */
     v2 ln, lp;          /* manifold: localNormal, localPoint in the polygon's frame */
     v2 rA;              /* velocity phase: contact point relative to the polygon's centre */
     float nmass;        /* velocity phase: normalMass */
@@ -428,6 +432,7 @@ typedef struct {
     float nmass[2], tmass[2];
     float k11, k12, k22, n11, n12, n21, n22;   /* K and normalMass = inverse(K) */
     int vcount;
+    int skip;                   /* sleeping island: not solved */
 } mc_t;
 
 static int contact_cmp(const void *pa, const void *pb) {
@@ -450,6 +455,8 @@ typedef struct {
     const derived_t *d;
     float *ang;            /* working copy of the object angles (index N + m) */
     int *parent; unsigned char *active, *next_active;
+    /* sleeping (b2Island::Solve, b2World::Solve): per body sleep time (< 0: asleep), per island root: awake / not solved / min sleep time */
+    float *slp, *isl_min; unsigned char *isl_awake, *isl_unsolved;
     int *woff, *wnoff;     /* packed warm-start offsets: previous / next substep */
     float *x0, *y0, *a0;   /* poses at the start of the step (continuous step) */
     int status;
@@ -1307,7 +1314,29 @@ static void toi_walls_object(const kbo_config *cfg, const derived_t *d, kbo_stat
 static void world_step_env(const kbo_config *cfg, const derived_t *d, kbo_state *st, int e, work_t *w) {
     const int N = w->N;
     const float h = d->h;
+    const int sleeping = cfg->allow_sleep != 0;
     detect_env(cfg, d, st, e, w);
+    /* islands (connected components over the touching dynamic-dynamic contacts; b2World::Solve does not propagate an
+     * island across static bodies): for the per-island early-out of the position solver, and for sleeping */
+    const int T = N + w->M;
+    for (int b = 0; b < T; ++b) { w->parent[b] = b; }
+    for (int i = 0; i < w->ncon; ++i) { w->con[i].skip = 0; if (w->con[i].a >= 0) uf_union(w->parent, w->con[i].a, w->con[i].b); }
+    for (int i = 0; i < w->nmc; ++i) { w->mc[i].skip = 0; if (w->mc[i].a >= 0) uf_union(w->parent, w->mc[i].a, w->mc[i].b); }
+    for (int b = 0; b < T; ++b) { w->parent[b] = uf_find(w->parent, b); w->active[b] = 1; }
+    if (sleeping) {
+        /* b2World::Solve: islands grow from AWAKE seeds and wake every body they reach (b2Body::SetAwake(true): flag set,
+         * m_sleepTime = 0 if it was asleep); components without an awake body are not simulated at all: their bodies do
+         * not move, their contacts keep their impulses */
+        for (int b = 0; b < T; ++b) w->isl_awake[b] = 0;
+        for (int b = 0; b < T; ++b) if (!(w->slp[b] < 0.0f)) w->isl_awake[w->parent[b]] = 1;
+        for (int b = 0; b < T; ++b) {
+            if (w->isl_awake[w->parent[b]]) { if (w->slp[b] < 0.0f) w->slp[b] = 0.0f; }
+            else { w->vx[b] = 0.0f; w->vy[b] = 0.0f; w->bw[b] = 0.0f; }
+            w->active[b] = w->isl_awake[b];        /* (only read at island roots) */
+        }
+        for (int i = 0; i < w->ncon; ++i) w->con[i].skip = !w->isl_awake[w->parent[w->con[i].b]];
+        for (int i = 0; i < w->nmc; ++i) w->mc[i].skip = !w->isl_awake[w->parent[w->mc[i].b]];
+    }
 
     /* integrate velocities: no forces; Pade damping (b2Island.cpp: v *= 1/(1 + h*c)) */
     for (int b = 0; b < N; ++b) {
@@ -1350,6 +1379,7 @@ static void world_step_env(const kbo_config *cfg, const derived_t *d, kbo_state 
     /* WarmStart */
     for (int i = 0; i < w->ncon; ++i) {
         contact_t *c = &w->con[i];
+        if (c->skip) continue;
         float Px = c->acc * c->nx, Py = c->acc * c->ny;
         if (c->poly) {                                      /* A = polygon b, B = kilobot a */
             w->bw[c->b] -= d->ii_obj[c->b - N] * (c->rA.x * Py - c->rA.y * Px);
@@ -1360,11 +1390,12 @@ static void world_step_env(const kbo_config *cfg, const derived_t *d, kbo_state 
         if (c->a >= 0) { w->vx[c->a] -= c->ima * Px; w->vy[c->a] -= c->ima * Py; }
         w->vx[c->b] += c->imb * Px; w->vy[c->b] += c->imb * Py;
     }
-    for (int i = 0; i < w->nmc; ++i) mc_warm_start(d, w, &w->mc[i]);
+    for (int i = 0; i < w->nmc; ++i) if (!w->mc[i].skip) mc_warm_start(d, w, &w->mc[i]);
     /* SolveVelocityConstraints */
     for (int it = 0; it < cfg->vel_iters; ++it) {
         for (int i = 0; i < w->ncon; ++i) {
             contact_t *c = &w->con[i];
+            if (c->skip) continue;
             if (c->poly) {                                  /* one point, friction sqrt(0 * f) = 0; A = polygon b, B = kilobot a */
                 const float wA = w->bw[c->b];
                 float dvx = (w->vx[c->a] - w->vx[c->b]) - (-wA * c->rA.y), dvy = (w->vy[c->a] - w->vy[c->b]) - (wA * c->rA.x);
@@ -1393,7 +1424,7 @@ static void world_step_env(const kbo_config *cfg, const derived_t *d, kbo_state 
             if (c->a >= 0) { w->vx[c->a] = vax - c->ima * Px; w->vy[c->a] = vay - c->ima * Py; }
             w->vx[c->b] += c->imb * Px; w->vy[c->b] += c->imb * Py;
         }
-        for (int i = 0; i < w->nmc; ++i) mc_solve_velocity(d, w, &w->mc[i]);
+        for (int i = 0; i < w->nmc; ++i) if (!w->mc[i].skip) mc_solve_velocity(d, w, &w->mc[i]);
     }
     /* StoreImpulses -> warm-start cache of the next substep */
     memset(st->ws_cnt + (size_t)e * N, 0, (size_t)N);
@@ -1456,13 +1487,9 @@ static void world_step_env(const kbo_config *cfg, const derived_t *d, kbo_state 
         w->px[b] += h * w->vx[b]; w->py[b] += h * w->vy[b];
         w->ang[b] += h * w->bw[b];
     }
-    /* islands (connected components over dynamic-dynamic contacts) for the per-island early-out */
-    const int T = N + w->M;
-    for (int b = 0; b < T; ++b) { w->parent[b] = b; }
-    for (int i = 0; i < w->ncon; ++i) if (w->con[i].a >= 0) uf_union(w->parent, w->con[i].a, w->con[i].b);
-    for (int i = 0; i < w->nmc; ++i) if (w->mc[i].a >= 0) uf_union(w->parent, w->mc[i].a, w->mc[i].b);
-    for (int b = 0; b < T; ++b) { w->parent[b] = uf_find(w->parent, b); w->active[b] = 1; }
-    /* SolvePositionConstraints, b2ContactSolver.cpp; per island: break when minSeparation >= -3 slop */
+    /* SolvePositionConstraints, b2ContactSolver.cpp; per island: break when minSeparation >= -3 slop
+     * (islands without an awake body start inactive: w->active was set with the islands above) */
+    for (int b = 0; b < T; ++b) w->isl_unsolved[b] = (unsigned char)(cfg->pos_iters <= 0);
     for (int it = 0; it < cfg->pos_iters; ++it) {
         int any = 0;
         memset(w->next_active, 0, (size_t)T);
@@ -1519,14 +1546,39 @@ static void world_step_env(const kbo_config *cfg, const derived_t *d, kbo_state 
             if (minSep < -3.0f * B2_LINEAR_SLOP) { w->next_active[isl] = 1; any = 1; }
         }
         memcpy(w->active, w->next_active, (size_t)T);
+        if (it == cfg->pos_iters - 1) memcpy(w->isl_unsolved, w->next_active, (size_t)T);   /* b2Island::Solve: positionSolved stays false */
         if (!any) break;
+    }
+    if (sleeping) {
+        /* b2Island::Solve, the allowSleep block: a body slower than the tolerances accumulates sleep time; an island whose
+         * bodies have all rested for b2_timeToSleep and whose position constraints converged is put to sleep
+         * (b2Body::SetAwake(false): sleep time, velocities and forces zeroed) */
+        const float linTolSqr = B2_LINEAR_SLEEP_TOL * B2_LINEAR_SLEEP_TOL, angTolSqr = B2_ANGULAR_SLEEP_TOL * B2_ANGULAR_SLEEP_TOL;
+        for (int b = 0; b < T; ++b) w->isl_min[b] = 3.402823466e+38f;
+        for (int b = 0; b < T; ++b) {
+            const int r = w->parent[b];
+            if (!w->isl_awake[r]) continue;
+            if (w->bw[b] * w->bw[b] > angTolSqr || w->vx[b] * w->vx[b] + w->vy[b] * w->vy[b] > linTolSqr) {
+                w->slp[b] = 0.0f; w->isl_min[r] = 0.0f;
+            } else {
+                w->slp[b] += h; w->isl_min[r] = fminf(w->isl_min[r], w->slp[b]);
+            }
+        }
+        for (int b = 0; b < T; ++b) {
+            const int r = w->parent[b];
+            if (w->isl_awake[r] && w->isl_min[r] >= B2_TIME_TO_SLEEP && !w->isl_unsolved[r]) {
+                w->slp[b] = -1.0f; w->vx[b] = 0.0f; w->vy[b] = 0.0f; w->bw[b] = 0.0f;
+            }
+        }
     }
     /* b2World::SolveTOI: continuous step of every dynamic body against the static walls */
     if (cfg->toi_walls) {
+        /* (b2World::SolveTOI skips contacts without an awake dynamic body) */
         for (int b = 0; b < N; ++b)
-            toi_walls_body(cfg, d, d->r_bot, d->im_bot, w->x0[b], w->y0[b], w->a0[b], &w->px[b], &w->py[b],
-                           &st->theta[(size_t)e * N + b], &w->vx[b], &w->vy[b], &w->bw[b]);
-        for (int m = 0; m < w->M; ++m) toi_walls_object(cfg, d, st, e, w, m);
+            if (!(sleeping && w->slp[b] < 0.0f))
+                toi_walls_body(cfg, d, d->r_bot, d->im_bot, w->x0[b], w->y0[b], w->a0[b], &w->px[b], &w->py[b],
+                               &st->theta[(size_t)e * N + b], &w->vx[b], &w->vy[b], &w->bw[b]);
+        for (int m = 0; m < w->M; ++m) if (!(sleeping && w->slp[N + m] < 0.0f)) toi_walls_object(cfg, d, st, e, w, m);
     }
 }
 
@@ -1613,6 +1665,7 @@ int kbo_reset(const kbo_config *cfg, kbo_state *st, const kbo_reset_params *rp) 
             if (rp->random_theta) th = ((float)(r[2] >> 8) * (1.0f / 16777216.0f) * 2.0f - 1.0f) * 3.14159265358979323846f;
             st->theta[i] = th;
             st->ws_cnt[i] = 0;
+            if (cfg->allow_sleep && st->sleep_time) st->sleep_time[i] = 0.0f;          /* new bodies are awake (b2BodyDef::awake) */
             if (cfg->drive_mode == KBO_DRIVE_VELOCITY || cfg->drive_mode == KBO_DRIVE_ACCEL) {
                 float v = 0.0f, w = 0.0f;
                 if (rp->random_velocity) {                                            /* kilobot.py:225-229 */
@@ -1707,12 +1760,23 @@ static void substep_env(const kbo_config *cfg, const derived_t *d, kbo_state *st
         }
         w->vx[b] = bvx; w->vy[b] = bvy; w->bw[b] = bw;
         if (st->cmd_vx) { st->cmd_vx[o + b] = bvx; st->cmd_vy[o + b] = bvy; st->cmd_w[o + b] = bw; }
+        if (cfg->allow_sleep) {
+            /* kilobot.py:123-127 assigns body.angularVelocity / body.linearVelocity: b2Body::SetAngularVelocity /
+             * SetLinearVelocity wake a sleeping body iff the assigned value is non-zero (w * w > 0, b2Dot(v, v) > 0) */
+            float sl = st->sleep_time[o + b];
+            if (!(flags & KBO_STEP_NO_DRIVE) && sl < 0.0f && (bw * bw > 0.0f || bvx * bvx + bvy * bvy > 0.0f)) sl = 0.0f;
+            w->slp[b] = sl;
+            /* a body that stays asleep has zero velocity (SetAwake(false) zeroed it and only a zero value was assigned since;
+             * a non-zero command whose square underflows counts as zero here) */
+            if (sl < 0.0f) { w->vx[b] = 0.0f; w->vy[b] = 0.0f; w->bw[b] = 0.0f; }
+        }
     }
     for (int m = 0; m < w->M; ++m) {   /* objects keep their velocities between substeps (plain b2Body) */
         const size_t oi = (size_t)e * w->M + m;
         w->px[N + m] = st->ox[oi]; w->py[N + m] = st->oy[oi];
         w->vx[N + m] = st->ovx[oi]; w->vy[N + m] = st->ovy[oi]; w->bw[N + m] = st->ow[oi];
         w->ang[N + m] = st->otheta[oi];
+        if (cfg->allow_sleep) w->slp[N + m] = st->osleep[oi];
         if (d->lc_obj[m].x != 0.0f || d->lc_obj[m].y != 0.0f) {    /* state holds the body origin, the solver the centre of mass */
             xf_t t = xf_make(st->ox[oi], st->oy[oi], st->otheta[oi]);
             v2 cm = xf_mul(&t, d->lc_obj[m]);
@@ -1721,8 +1785,10 @@ static void substep_env(const kbo_config *cfg, const derived_t *d, kbo_state *st
     }
     world_step_env(cfg, d, st, e, w);
     for (int b = 0; b < N; ++b) { st->x[o + b] = w->px[b]; st->y[o + b] = w->py[b]; }
+    if (cfg->allow_sleep) for (int b = 0; b < N; ++b) st->sleep_time[o + b] = w->slp[b];
     for (int m = 0; m < w->M; ++m) {
         const size_t oi = (size_t)e * w->M + m;
+        if (cfg->allow_sleep) st->osleep[oi] = w->slp[N + m];
         st->ox[oi] = w->px[N + m]; st->oy[oi] = w->py[N + m];
         st->ovx[oi] = w->vx[N + m]; st->ovy[oi] = w->vy[N + m]; st->ow[oi] = w->bw[N + m];
         st->otheta[oi] = w->ang[N + m];
@@ -1786,17 +1852,20 @@ static int work_alloc(work_t *w, const kbo_config *cfg, const derived_t *d) {
     w->cap = kbo_contact_capacity(cfg);
     w->con = (contact_t *)malloc(sizeof(contact_t) * w->cap);
     w->parent = (int *)malloc(sizeof(int) * T * 3); w->woff = w->parent + T; w->wnoff = w->woff + T;
-    w->active = (unsigned char *)malloc(2 * (size_t)T); w->next_active = w->active + T;
-    return (w->px && w->cell && w->cell_start && w->cell_items && w->con && w->parent && w->active) ? 0 : -1;
+    w->active = (unsigned char *)malloc(4 * (size_t)T); w->next_active = w->active + T;
+    w->isl_awake = w->next_active + T; w->isl_unsolved = w->isl_awake + T;
+    w->slp = (float *)malloc(sizeof(float) * T * 2); w->isl_min = w->slp + T;
+    return (w->px && w->cell && w->cell_start && w->cell_items && w->con && w->parent && w->active && w->slp) ? 0 : -1;
 }
 static void work_free(work_t *w) {
-    free(w->px); free(w->cell); free(w->cell_start); free(w->cell_items); free(w->con); free(w->parent); free(w->active);
+    free(w->px); free(w->cell); free(w->cell_start); free(w->cell_items); free(w->con); free(w->parent); free(w->active); free(w->slp);
 }
 
 int kbo_step(const kbo_config *cfg, kbo_state *st, const float *light_action, int n_substeps, int flags,
              int num_threads) {
     if (!cfg || !st || cfg->num_bots < 1 || cfg->num_envs < 1 || cfg->num_objects < 0 || cfg->num_objects > KBO_MAX_OBJECTS) return -1;
     if (cfg->num_objects > 0 && (!st->ox || !st->oy || !st->otheta || !st->ovx || !st->ovy || !st->ow || !st->ows_acc)) return -1;
+    if (cfg->allow_sleep && (!st->sleep_time || (cfg->num_objects > 0 && !st->osleep))) return -1;
     derived_t d; derive(cfg, &d);
     int nt = num_threads > 1 ? num_threads : 1;
     int err = 0;

@@ -50,6 +50,7 @@ class Config(C.Structure):
         ('wall_friction', C.c_float),
         ('num_fixtures', C.c_int32), ('obj_fixture_body', C.c_int32 * MAX_OBJECTS),
         ('damping_model', C.c_int32), ('sense_radius', C.c_float), ('contact_capacity', C.c_int32),
+        ('allow_sleep', C.c_int32),
     ]
 
 
@@ -77,6 +78,7 @@ class State(C.Structure):
         ('status', _PI32),
         ('ows_acc', _PF),
         ('nbr_count', _PU32),
+        ('sleep_time', _PF), ('osleep', _PF),
     ]
 
 
@@ -146,6 +148,7 @@ def default_config(num_envs, num_bots, drive_mode=DRIVE_VELOCITY, light_type=LIG
     c.damping_model = 0    # Pade (Box2D >= 2.3.1)
     c.sense_radius = 0.0
     c.contact_capacity = 0
+    c.allow_sleep = 0      # b2World(doSleep=...): the envs of gym_kilobots_amd.envs turn it on like kilobots_env.py:45
     c.light_count = 1
     for i in range(MAX_LIGHTS):
         c.light_kind[i] = LIGHT_CIRCULAR
@@ -207,6 +210,7 @@ class OracleSim:
         self.ovx, self.ovy, self.ow = f(E, M), f(E, M), f(E, M)
         self.ows_acc = np.full((E, MAX_OBJECTS, OWS_COLS, OWS_WORDS), -1.0, np.float32)
         self.nbr_count = np.zeros((E, N), np.uint32)
+        self.sleep_time, self.osleep = f(E, N), f(E, M)       # b2Body::m_sleepTime (< 0: asleep)
         self._st = State()
         for name, _t in State._fields_:
             arr = getattr(self, name, None)
@@ -221,6 +225,7 @@ class OracleSim:
         self.theta[...] = np.asarray(theta, np.float32)
         self.ws_cnt[...] = 0
         self.ows_acc[...] = -1.0
+        self.sleep_time[...] = 0.0
 
     def poses_m(self):
         return np.stack([self.x.astype(np.float64) / WORLD_SCALE, self.y.astype(np.float64) / WORLD_SCALE,
@@ -277,6 +282,7 @@ class OracleSim:
         self.ovy[...] = 0
         self.ow[...] = 0
         self.ows_acc[...] = -1.0
+        self.osleep[...] = 0.0
 
     def objects_m(self):
         return np.stack([self.ox.astype(np.float64) / WORLD_SCALE, self.oy.astype(np.float64) / WORLD_SCALE,

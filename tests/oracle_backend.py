@@ -17,13 +17,15 @@ class OracleBackend:
         for name in ('x', 'y', 'theta', 'v', 'w', 'acc_v', 'acc_w', 'motor_l', 'motor_r', 'pt_threshold',
                      'pt_update', 'pt_nochange', 'pt_dir', 'light_x', 'light_y', 'light_vx', 'light_vy', 'ws_cnt', 'status',
                      'light_value', 'light_gx', 'light_gy', 'cmd_vx', 'cmd_vy', 'cmd_w',
-                     'ox', 'oy', 'otheta', 'ovx', 'ovy', 'ow', 'nbr_count'):
+                     'ox', 'oy', 'otheta', 'ovx', 'ovy', 'ow', 'nbr_count', 'sleep_time', 'osleep'):
             arr = getattr(self.o, name)
             setattr(self, name, torch.from_numpy(arr.view(np.int32) if arr.dtype == np.uint32 else arr))     # shares memory
         if drive_mode not in (O.DRIVE_MOTORS, O.DRIVE_PHOTOTAXIS):
             self.motor_l = self.motor_r = None
         if not self.cfg.sense_radius > 0.0:
             self.nbr_count = None
+        if not self.cfg.allow_sleep:
+            self.sleep_time = self.osleep = None
         self.lds_bytes, self.block_threads = 0, 0
         self.device = torch.device('cpu')
 
