@@ -23,7 +23,8 @@ FIX = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'mini_solver.json')))
 
 def _oracle_for(sc):
     objs = sc['objects']
-    kw = dict(toi_walls=1 if sc.get('toi') else 0, damping_model=1 if sc['damping'] == 'linear' else 0)
+    kw = dict(toi_walls=1 if sc.get('toi') else 0, damping_model=1 if sc['damping'] == 'linear' else 0,
+              allow_sleep=1 if sc.get('sleep') else 0)
     if objs:
         pad = O.MAX_OBJECTS - len(objs)
         kw.update(num_objects=len(objs),
@@ -48,8 +49,21 @@ def test_oracle_follows_the_independent_solver(name):
     o = _oracle_for(sc)
     tol = sc['tol']
     touched = False
+    slept = woke = False
     for k, ref in enumerate(sc['trajectory']):
+        for first, cmds in sc.get('commands', []):            # the scene's commands change at these steps
+            if first == k:
+                o.set_actions(np.array(cmds, np.float32)[None])
         o.step(1)
+        if sc.get('sleep'):
+            # b2Body::m_sleepTime of every body, -1 = asleep: the same substep falls asleep / wakes in both derivations
+            for got_s, want_s in ((o.sleep_time[0], ref['sleep']), (o.osleep[0][:len(sc['objects'])], ref['osleep'])):
+                want_s = np.array(want_s, np.float64)
+                assert np.array_equal(np.asarray(got_s) < 0, want_s < 0), (name, k, 'asleep flags', got_s, want_s)
+                assert np.abs(np.asarray(got_s, np.float64) - want_s).max(initial=0.0) <= 1e-6, (name, k, 'sleep time')
+            now = np.array(ref['sleep'] + ref['osleep']) < 0
+            slept |= bool(now.any())
+            woke |= slept and not now.all() and k > 0 and bool((np.array(sc['trajectory'][k - 1]['sleep'] + sc['trajectory'][k - 1]['osleep']) < 0)[~now].any())
         got = np.stack([o.x[0], o.y[0], o.theta[0]], -1).astype(np.float64)
         want = np.array(ref['kilobots'])
         assert np.abs(got[:, :2] - want[:, :2]).max() <= tol, (name, k, 'kilobot position', got, want)
@@ -62,7 +76,11 @@ def test_oracle_follows_the_independent_solver(name):
             assert np.abs(g[:, 3:] - w[:, 3:]).max() <= 200 * tol, (name, k, 'object velocity', g, w)
         nb, nw, no = o.count_contacts(0, True)
         touched |= (nb + nw + no) > 0
-    assert touched, 'the scene never made a contact'
+    assert touched or sc.get('contact_free'), 'the scene never made a contact'
+    if sc.get('sleep'):
+        assert slept, 'nothing fell asleep'
+        if 'wake' in name or 'woken' in name:
+            assert woke, 'nothing woke up'
     assert int(o.status.max()) == 0
 
 

@@ -67,6 +67,11 @@ def test_random_scene(seed):
         kw.update(world_width=W, world_height=H)
     if rng2.random() < 0.3:
         kw.update(vel_iters=int(rng2.choice([6, 3, 1])), pos_iters=int(rng2.choice([4, 2, 1, 0])))
+    # sleeping (b2World doSleep): in 40 % of the scenes, with phases in which kilobots rest so that islands fall asleep and
+    # are woken again (drawn last from the second stream: the older scenes keep their layout)
+    sleeping = rng2.random() < 0.4
+    if sleeping:
+        kw.update(allow_sleep=1)
     sx, sy = W / 2.0, H / 1.5
     with_objects = rng.random() < 0.6
     nobj = 0
@@ -93,12 +98,28 @@ def test_random_scene(seed):
         osim.light_x[...] = lx
         gsim.light_x.copy_(dev(lx))
     fields = ('x', 'y', 'theta') + (OBJ_FIELDS[3:] if nobj else ())
+    if sleeping:
+        fields += ('sleep_time',) + (('osleep',) if nobj else ())
+        if mode in (O.DRIVE_MOTORS, O.DRIVE_PHOTOTAXIS):      # a third of the kilobots has its motors off
+            off = rng2.random((E, N)) < 0.35
+            for name in ('motor_l', 'motor_r'):
+                v = getattr(osim, name)
+                v[off] = 0
+                getattr(gsim, name).copy_(dev(v))
     la_dim = {O.LIGHT_NONE: 0, O.LIGHT_GRADIENT: 1}.get(light, 2)
     for k in range(12):
         la = None if la_dim == 0 or k % 3 == 2 else rng.uniform(-0.02, 0.02, (E, la_dim)).astype(np.float32)
         n_sub = int(rng.choice([1, 1, 3, 10]))
         if mode in (O.DRIVE_VELOCITY, O.DRIVE_ACCEL):
             a = scenes.random_actions(E, N, seed=5000 + 31 * seed + k)
+            if sleeping:      # resting phases: everybody for a few steps, then a random half
+                if k % 6 in (1, 2, 3):
+                    a[...] = 0.0
+                elif k % 6 == 4:
+                    a[rng2.random((E, N)) < 0.5] = 0.0
+                if mode == O.DRIVE_ACCEL and k % 6 in (1, 2, 3):
+                    a[..., 0] = -0.005        # decelerate to a halt (the command is clamped at 0)
+                    a[..., 1] = 0.0
             osim.set_actions(a)
             osim.step(n_sub, light_action=la)
             gsim.step(n_sub, actions=dev(a), light_action=None if la is None else dev(la))

@@ -39,6 +39,9 @@ BAUMGARTE = f32(0.2)
 MAX_LINEAR_CORRECTION = f32(0.2)
 MAX_TRANSLATION = f32(2.0)
 MAX_ROTATION = f32(0.5) * PI
+TIME_TO_SLEEP = f32(0.5)                                     # b2_timeToSleep
+LINEAR_SLEEP_TOLERANCE = f32(0.01)                           # b2_linearSleepTolerance
+ANGULAR_SLEEP_TOLERANCE = f32(2.0) / f32(180.0) * PI         # b2_angularSleepTolerance
 EPSILON = f32(1.192092896e-07)
 TOI_BAUMGARTE = f32(0.75)
 MAX_SUB_STEPS = 8
@@ -235,6 +238,33 @@ class Body:
         self.fixtures = []
         self.island_index = -1
         self.alpha0 = f32(0.0)
+        self.awake, self.sleep_time = True, f32(0.0)       # b2BodyDef::awake = true, m_sleepTime = 0
+
+    def set_awake(self, flag):
+        """b2Body::SetAwake (2.3.x): waking an awake body does not touch its sleep time"""
+        if flag:
+            if not self.awake:
+                self.awake, self.sleep_time = True, f32(0.0)
+        else:
+            self.awake, self.sleep_time = False, f32(0.0)
+            self.v, self.w = V(), f32(0.0)
+
+    def set_linear_velocity(self, v):
+        """b2Body::SetLinearVelocity (what pybox2d's `body.linearVelocity = v` calls)"""
+        if not self.dynamic:
+            return
+        if dot(v, v) > f32(0.0):
+            self.set_awake(True)
+        self.v = v
+
+    def set_angular_velocity(self, w):
+        """b2Body::SetAngularVelocity"""
+        if not self.dynamic:
+            return
+        w = f32(w)
+        if w * w > f32(0.0):
+            self.set_awake(True)
+        self.w = w
 
     def advance(self, alpha):
         """b2Body::Advance -> b2Sweep::Advance + SynchronizeTransform"""
@@ -630,13 +660,14 @@ class Contact:
 
 # ---------------------------------------------------------------------------------------------- world
 class World:
-    """b2World with gravity (0, 0), allowSleep False, continuousPhysics False, warmStarting True.
+    """b2World with gravity (0, 0), warmStarting True; allow_sleep = b2World's doSleep, continuous = continuousPhysics.
     damping: 'pade' (Box2D >= 2.3.1) or 'linear' (Box2D <= 2.3.0)."""
 
-    def __init__(self, damping='pade', continuous=False):
+    def __init__(self, damping='pade', continuous=False, allow_sleep=False):
         self.bodies, self.contacts, self.fixtures = [], [], []
         self.damping = damping
         self.continuous = continuous
+        self.allow_sleep = allow_sleep
         self.inv_dt0 = f32(0.0)
 
     def create_body(self, **kw):
@@ -655,7 +686,10 @@ class World:
 
     def step(self, dt, vel_iters, pos_iters):
         dt = f32(dt)
-        for c in self.contacts:          # b2ContactManager::Collide
+        for c in self.contacts:          # b2ContactManager::Collide: contacts without an awake dynamic body are not updated
+            bA, bB = c.fA.body, c.fB.body
+            if not ((bA.dynamic and bA.awake) or (bB.dynamic and bB.awake)):
+                continue
             c.update()
         dt_ratio = self.inv_dt0 * dt
         self._solve(dt, dt_ratio, vel_iters, pos_iters)
@@ -681,6 +715,8 @@ class World:
                     # non-bullet dynamic bodies only have TOI events with non-dynamic bodies
                     if (bA.dynamic and bB.dynamic) or not (bA.dynamic or bB.dynamic):
                         continue
+                    if not ((bA.dynamic and bA.awake) or (bB.dynamic and bB.awake)):
+                        continue                                   # b2World::SolveTOI: "is there a reason to collide?"
                     if not (c.fA.shape.kind == 'edge' and c.fB.shape.kind == 'circle'):
                         continue                                   # (polygons: not covered by this restatement)
                     alpha0 = max(bA.alpha0, bB.alpha0)
@@ -792,6 +828,12 @@ class World:
                 roots.append(find(b))
         for root in roots:
             bodies = [b for b in self.bodies if b.dynamic and find(b) is root]
+            # b2World::Solve: islands grow from awake seeds and wake every body they reach; a component without an awake
+            # body is not simulated
+            if not any(b.awake for b in bodies):
+                continue
+            for b in bodies:
+                b.set_awake(True)
             contacts = [c for c in self.contacts if c.touching and
                         ((c.fA.body.dynamic and find(c.fA.body) is root) or (c.fB.body.dynamic and find(c.fB.body) is root))]
             self._solve_island(bodies, contacts, h, dt_ratio, vel_iters, pos_iters)
@@ -838,16 +880,32 @@ class World:
             a = a + h * w
             pos[id(b)] = [c, a]
             vel[id(b)] = [v, w]
+        position_solved = False
         for _ in range(pos_iters):
             min_sep = f32(0.0)
             for vc in vcs:
                 min_sep = min(min_sep, vc.solve_position(P))
             if min_sep >= f32(-3.0) * LINEAR_SLOP:
+                position_solved = True
                 break
         for b in bodies:
             b.c, b.a = pos[id(b)]
             b.v, b.w = vel[id(b)]
             b.synchronize_transform()
+        if self.allow_sleep:             # b2Island::Solve, the allowSleep block
+            min_sleep = f32(3.402823466e+38)
+            lin_tol_sqr = LINEAR_SLEEP_TOLERANCE * LINEAR_SLEEP_TOLERANCE
+            ang_tol_sqr = ANGULAR_SLEEP_TOLERANCE * ANGULAR_SLEEP_TOLERANCE
+            for b in bodies:
+                if b.w * b.w > ang_tol_sqr or dot(b.v, b.v) > lin_tol_sqr:
+                    b.sleep_time = f32(0.0)
+                    min_sleep = f32(0.0)
+                else:
+                    b.sleep_time = b.sleep_time + h
+                    min_sleep = min(min_sleep, b.sleep_time)
+            if min_sleep >= TIME_TO_SLEEP and position_solved:
+                for b in bodies:
+                    b.set_awake(False)
 
 
 class VelocityConstraint:

@@ -56,13 +56,23 @@ SCENES = {
                            steps=30, tol=5e-5, toi=True),
     # several contacts: Box2D sweeps in contact-creation order, the oracle in its canonical key order -> looser tolerance
     'chain_of_three': dict(kilobots=[[-0.9, 0.0, 0.0, 0.01, 0.0], [-0.05, 0.03, 0.0, 0.0, 0.0], [0.8, -0.02, 0.0, 0.0, 0.0]], objects=[], steps=60, tol=2e-3),
+    # sleeping (b2World doSleep = True, kilobots_env.py:45): `commands` = [[first step, [[v_cmd, omega_cmd] per kilobot]], ...]
+    # replaces the per-kilobot commands from that step on.  Single contacts / no contacts: tight tolerance.
+    'sleep_overlap_at_rest': dict(kilobots=[[0.0, 0.0, 0.0, 0.0, 0.0], [0.5, 0.0, 0.0, 0.0, 0.0], [12.5, 12.5, 0.0, 0.0, 0.0]], objects=[],
+                                  steps=14, tol=2e-5, sleep=True),
+    'sleep_and_wake_by_command': dict(kilobots=[[0.0, 0.0, 0.3, 0.01, 0.2], [6.0, 3.0, 0.0, 0.0, 0.0]], objects=[], steps=30, tol=2e-5, sleep=True, contact_free=True,
+                                      commands=[[6, [[0.0, 0.0], [0.0, 0.0]]], [16, [[0.0003, 0.0], [0.0, 0.0]]], [24, [[0.008, -0.3], [0.0, 0.0]]]]),
+    'sleeping_bot_woken_by_a_pusher': dict(kilobots=[[0.0, 0.0, 0.0, 0.0, 0.0], [1.5, 0.05, math.pi, 0.0, 0.0]], objects=[], steps=60, tol=5e-5, sleep=True,
+                                           commands=[[8, [[0.0, 0.0], [0.01, 0.0]]]]),
+    'disc_coasts_to_sleep': dict(kilobots=[[20.0, 15.0, 0.0, 0.0, 0.0]], objects=[dict(shape='circle', r=1.5, x=0.0, y=0.0, theta=0.0, vx=0.6, vy=0.2, w=0.3)],
+                                 steps=70, tol=5e-5, sleep=True, contact_free=True),
     'two_bots_push_box': dict(kilobots=[[-2.9, 0.9, 0.0, 0.01, 0.0], [-2.9, -0.8, 0.0, 0.01, 0.0]],
                               objects=[dict(shape='box', hx=1.875, hy=1.875, x=0.0, y=0.0, theta=0.0, vx=0, vy=0, w=0)], steps=60, tol=2e-3),
 }
 
 
 def run(scene, damping='pade', dt=0.1, vel_iters=10, pos_iters=10):
-    w = B.World(damping=damping, continuous=bool(scene.get('toi')))
+    w = B.World(damping=damping, continuous=bool(scene.get('toi')), allow_sleep=bool(scene.get('sleep')))
     table = w.create_body(dynamic=False)
     x0, x1, y0, y1 = -W / 2, W / 2, -H / 2, H / 2
     for a, b in (((x0, y1), (x0, y0)), ((x0, y0), (x1, y0)), ((x1, y0), (x1, y1)), ((x1, y1), (x0, y1))):   # kilobots_env.py:48-51
@@ -71,7 +81,7 @@ def run(scene, damping='pade', dt=0.1, vel_iters=10, pos_iters=10):
     for x, y, th, v, om in scene['kilobots']:
         b = w.create_body(position=(x, y), angle=th, linear_damping=0.8, angular_damping=0.8)
         b.create_fixture(B.Circle(R_BOT), density=2.0, friction=0.0, restitution=0.0)
-        bots.append((b, np.float32(v), np.float32(om)))
+        bots.append([b, np.float32(v), np.float32(om)])
     for o in scene['objects']:
         b = w.create_body(position=(o['x'], o['y']), angle=o['theta'], linear_damping=0.8, angular_damping=0.8)
         shape = B.Circle(o['r']) if o['shape'] == 'circle' else B.Polygon.box(o['hx'], o['hy'])
@@ -79,14 +89,22 @@ def run(scene, damping='pade', dt=0.1, vel_iters=10, pos_iters=10):
         b.v, b.w = B.V(o['vx'], o['vy']), np.float32(o['w'])
         objs.append(b)
     traj = []
-    for _ in range(scene['steps']):
-        for b, v, om in bots:                 # SimpleVelocityControlKilobot.step, kilobot.py:253-258
-            sp = v * np.float32(25.0)
-            b.v = B.V(np.float32(math.cos(float(b.a))) * sp, np.float32(math.sin(float(b.a))) * sp)
-            b.w = om
+    for k in range(scene['steps']):
+        for first, cmds in scene.get('commands', []):
+            if first == k:
+                for bot, (v, om) in zip(bots, cmds):
+                    bot[1], bot[2] = np.float32(v), np.float32(om)
+        for b, v, om in bots:                 # SimpleVelocityControlKilobot.step, kilobot.py:253-258 (assignments through the
+            sp = v * np.float32(25.0)         # b2Body setters, which wake a sleeping body iff the value is non-zero)
+            b.set_angular_velocity(om)
+            b.set_linear_velocity(B.V(np.float32(math.cos(float(b.a))) * sp, np.float32(math.sin(float(b.a))) * sp))
         w.step(dt, vel_iters, pos_iters)
-        traj.append({'kilobots': [[float(b.position.x), float(b.position.y), float(b.angle)] for b, _, _ in bots],
-                     'objects': [[float(b.position.x), float(b.position.y), float(b.angle), float(b.v.x), float(b.v.y), float(b.w)] for b in objs]})
+        rec = {'kilobots': [[float(b.position.x), float(b.position.y), float(b.angle)] for b, _, _ in bots],
+               'objects': [[float(b.position.x), float(b.position.y), float(b.angle), float(b.v.x), float(b.v.y), float(b.w)] for b in objs]}
+        if scene.get('sleep'):                # m_sleepTime, -1 = asleep (the encoding of kb_buffers.sleep_time)
+            rec['sleep'] = [float(b.sleep_time) if b.awake else -1.0 for b, _, _ in bots]
+            rec['osleep'] = [float(b.sleep_time) if b.awake else -1.0 for b in objs]
+        traj.append(rec)
     touched = any(c.touching for c in w.contacts)
     return traj, touched
 
