@@ -55,6 +55,9 @@ def parse_args(argv=None):
     ap.add_argument('--boxes', action='store_true', help='with --objects: 0.15 m boxes (Quad) instead of discs')
     ap.add_argument('--sense', type=float, default=0.0, help='IR neighbour sensing radius in metres (0 = off; adds 4 B per kilobot-step)')
     ap.add_argument('--no-toi', action='store_true', help='disable the continuous step against the walls (A/B only)')
+    ap.add_argument('--sleep', action='store_true', help='A/B only: the generic instantiation WITH the sleep state (b2World doSleep); the headline '
+                    'workload commands every kilobot to move in every substep, where sleeping cannot change a bit (tests/test_sleeping.py), '
+                    'so the fixed-size benchmark instantiation leaves the bookkeeping out')
     ap.add_argument('--vel-iters', type=int, default=10, help='solver velocity iterations (A/B only; the reference uses 10)')
     ap.add_argument('--pos-iters', type=int, default=10, help='solver position iterations (A/B only; the reference uses 10)')
     ap.add_argument('--arena', type=float, nargs=2, default=None, metavar=('W', 'H'), help='arena size in metres (A/B only; default 2.0 x 1.5)')
@@ -212,6 +215,8 @@ def main():
         okw['sense_radius'] = args.sense
     if args.arena:
         okw.update(world_width=args.arena[0], world_height=args.arena[1])
+    if args.sleep:
+        okw['allow_sleep'] = 1
     if args.vel_iters != 10 or args.pos_iters != 10:
         okw.update(vel_iters=args.vel_iters, pos_iters=args.pos_iters)
     sim = KilobotSim(E, N, device=dev, num_objects=args.objects, toi_walls=0 if args.no_toi else 1, **okw)
@@ -337,7 +342,11 @@ def main():
                    'parallelism': 'env-shard x%d' % world + (' (REHEARSAL: all ranks on one GPU, gloo)' if rehearsal else ''), 'workgroup_threads': sim.block_threads,
                    'lds_bytes_per_env': sim.lds_bytes, 'resident_envs_per_cu': sim.resident_envs_per_cu, 'seed': args.seed,
                    'settle_substeps': settled, 'settle_stationary': bool(stationary),
-                   'sense_radius_m': args.sense},
+                   'sense_radius_m': args.sense,
+                   'sleep_state': bool(args.sleep),
+                   'sleep_note': 'b2World(doSleep=True) bookkeeping ' + ('carried (generic instantiation)' if args.sleep else
+                                 'left out: every kilobot is commanded to move in every substep, so sleeping cannot change a bit '
+                                 '(proved + tested: tests/test_sleeping.py); `--sleep` times the instantiation that carries it')},
         'contacts_per_env': c_before, 'contacts_per_env_after': c_after,
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_source,

@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 def _sim_for(sc):
     from gym_kilobots_amd.sim import KilobotSim
     objs = sc['objects']
-    kw = dict(toi_walls=1 if sc.get('toi') else 0, damping_model=1 if sc['damping'] == 'linear' else 0)
+    kw = dict(toi_walls=1 if sc.get('toi') else 0, damping_model=1 if sc['damping'] == 'linear' else 0,
+              allow_sleep=1 if sc.get('sleep') else 0)
     if objs:
         pad = O.MAX_OBJECTS - len(objs)
         kw.update(num_objects=len(objs),
@@ -42,7 +43,17 @@ def test_hip_path_follows_the_independent_solver(name):
     g = _sim_for(sc)
     tol = sc['tol']
     for k, ref in enumerate(sc['trajectory']):
+        for first, cmds in sc.get('commands', []):
+            if first == k:
+                g.set_actions(torch.tensor([cmds], dtype=torch.float32, device=g.x.device).contiguous())
         g.step(1)
+        if sc.get('sleep'):          # the same substep falls asleep / wakes on the device as in the independent derivation
+            st = g.sleep_time[0].double().cpu().numpy()
+            want_s = np.array(ref['sleep'])
+            assert np.array_equal(st < 0, want_s < 0) and np.abs(st - want_s).max() <= 1e-6, (name, k, 'sleep time', st, want_s)
+            if sc['objects']:
+                so = g.osleep[0].double().cpu().numpy()
+                assert np.array_equal(so < 0, np.array(ref['osleep']) < 0), (name, k, 'object asleep', so)
         got = torch.stack([g.x[0], g.y[0], g.theta[0]], -1).double().cpu().numpy()
         want = np.array(ref['kilobots'])
         assert np.abs(got[:, :2] - want[:, :2]).max() <= tol, (name, k, 'kilobot position')

@@ -262,3 +262,29 @@ def test_env_api_sleeps_like_the_reference_world():
         last = og['kilobots']
     assert np.array_equal(g.sim.sleep_time.cpu().numpy(), o.sim.sleep_time.numpy())
     g.close()
+
+
+@pytest.mark.gpu
+def test_benchmark_kernel_without_the_sleep_state_equals_the_sleeping_kernel_on_a_commanded_swarm():
+    """cfg3 slice (1024 kilobots, every kilobot commanded to move in every substep): the fixed-size benchmark instantiation
+    (no sleep state) and the generic instantiation with the sleep state give the same bits -- kilobots do fall asleep
+    (pressed against their neighbours they rest for 0.5 s) and are woken by their next command before anything is simulated."""
+    from tests.test_parity_gpu import dev, make_pair
+    from gym_kilobots_amd.sim import KilobotSim
+    E, N = 6, 1024
+    xy, th = scenes.lattice_spawn(E, N, seed=9)
+    plain = KilobotSim(E, N)
+    sleepy = KilobotSim(E, N, allow_sleep=1)
+    for s in (plain, sleepy):
+        s.set_poses_m(xy, th)
+    slept = 0
+    for k in range(60):
+        a = scenes.random_actions(E, N, seed=300 + k)
+        a[..., 0] = np.maximum(a[..., 0], 1e-4)
+        for s in (plain, sleepy):
+            s.step(1, actions=dev(a))
+        slept += int((sleepy.sleep_time < 0).sum().item())
+        for f in ('x', 'y', 'theta', 'ws_acc'):
+            assert torch.equal(getattr(plain, f), getattr(sleepy, f)), (k, f)
+    assert sleepy.sleep_time.max().item() > 0.0
+    assert plain.lds_bytes == 53168 and sleepy.lds_bytes != plain.lds_bytes        # really two different instantiations
