@@ -51,6 +51,17 @@ class Kilobot(Circle):
         v = self._get('light_value')
         return v if v else 0
 
+    def set_light_value_and_gradient(self, value, gradient):
+        """kilobot.py:50-52: what the reference env calls per kilobot per substep (kilobots_env.py:179-180).  Here the device
+        evaluates the light at every sensor itself; a caller that sets a value by hand writes this kilobot's sensing outputs,
+        which hold until the next sensing point."""
+        be = self._world.backend
+        if self._live() and getattr(be, 'light_value', None) is not None:
+            self._set('light_value', float(value))
+            if gradient is not None:
+                self._set('light_gx', float(gradient[0]))
+                self._set('light_gy', float(gradient[1]))
+
     def set_motors(self, left, right):
         self._motor_left = left
         self._motor_right = right

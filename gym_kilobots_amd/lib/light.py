@@ -255,3 +255,22 @@ class CompositeLight(Light):
 
     def get_state(self):
         return np.concatenate([l.get_state() for l in self._lights])
+
+
+class SmoothGridLight(Light):
+    """light.py:198-215: declared but not implemented in the reference (every method raises)."""
+
+    def __init__(self):
+        super().__init__()
+
+    def step(self, action, time_step):
+        raise NotImplementedError
+
+    def get_value(self, position):
+        raise NotImplementedError
+
+    def get_gradient(self, position):
+        raise NotImplementedError
+
+    def get_state(self):
+        raise NotImplementedError
