@@ -295,6 +295,30 @@ def main():
     ret = -torch.sqrt((sim.x - x0) ** 2 + (sim.y - y0) ** 2).mean(dim=1) / 25.0
     all_ret = gather_returns(ret.to(cdev), dist)
 
+    # the same workload on the instantiation that carries Box2D's sleep state (b2World doSleep=True): reported next to the
+    # headline, never mixed into it (the results of this workload are the same bits either way: tests/test_sleeping.py); it takes
+    # over the state right behind the timed region, before the fused launches change the contact population
+    with_sleep = None
+    if rank == 0 and not args.no_fused and not args.sleep and not args.objects:
+        okw2 = dict(okw, allow_sleep=1)
+        sim2 = KilobotSim(E, N, device=dev, toi_walls=0 if args.no_toi else 1, **okw2)
+        for name in ('x', 'y', 'theta', 'ws_key', 'ws_acc', 'ws_cnt'):
+            getattr(sim2, name).copy_(getattr(sim, name))
+        ns = max(10, min(40, K))
+        for k in range(5):
+            sim2.step(1, actions=actions[k % n_sets])
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for k in range(ns):
+            sim2.step(1, actions=actions[k % n_sets])
+        e1.record()
+        torch.cuda.synchronize()
+        sms = e0.elapsed_time(e1) / ns
+        with_sleep = {'ms_per_launch': sms, 'kilobot_steps_per_s_one_gpu': E * N / (sms * 1e-3), 'launches': ns,
+                      'bytes_per_kilobot_step': 56, 'asleep_at_the_end': int((sim2.sleep_time < 0).sum().item()),
+                      'status_flags': int(sim2.status.max().item())}
+        sim2.close()
+        del sim2
     # fused variant: one launch = one env.step = 10 substeps, state LDS-resident in between
     fused = None
     if rank == 0 and not args.no_fused:
@@ -356,6 +380,7 @@ def main():
                      'algorithmic_bytes_per_launch': algo_bytes * E * N},
         'per_rank_kilobot_steps_per_s': rates,
         'fused_env_step': fused,
+        'with_sleep_state': with_sleep,
         'status_flags': status,
         'returns_gathered': int(all_ret.numel()),
     }

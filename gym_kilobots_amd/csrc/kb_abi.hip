@@ -225,7 +225,7 @@ struct kb_sim {
 // scenes with objects (namespace lds, kb_common.h)
 static bool uses_fixed_1024(const kb::Params &p, int threads) {   // the instantiation kb_step picks: the ONE place that decides
     const long cap1024 = (4L * 1024 + 64 + 7) & ~7L;
-    if (p.allow_sleep) return false;            // (the fixed-size instantiations do not carry the sleep state)
+    if (p.allow_sleep && p.M > 0) return false;            // (the fixed-size instantiations with objects do not carry the sleep state)
     return p.drive_mode == KB_DRIVE_VELOCITY && p.N == 1024 && p.light_type == KB_LIGHT_NONE && threads == 64 * kb::MAX_WAVES &&
            kb::BPT * 64 * kb::MAX_WAVES == 1024 && p.NP == 1024 && p.NB == 1024 + KB_MAX_OBJECTS + 4 &&
            (p.M > 0 || p.cap == (int)cap1024);      // (without objects the contact capacity is a compile-time constant of the kernel)
@@ -250,7 +250,7 @@ static int resident_envs(int lds, int threads, int wps) {
 }
 // register budget of a kernel without objects: 80 VGPRs (tier 2) where that holds more envs than 128 VGPRs
 static int pick_tier(const kb::Params &p, int threads, int lds) {
-    if (p.M > 0 || p.allow_sleep) return 0;      // (the instantiations with the sleep state exist at 128 VGPRs only)
+    if (p.M > 0) return 0;
     if (const char *t = getenv("KB_TIER")) return atoi(t) == 2 ? 2 : 0;      // experiment knob (A/B of the register budgets)
     return resident_envs(lds, threads, KB_COMPACT_WAVES_PER_SIMD) > resident_envs(lds, threads, KB_MIN_WAVES_PER_SIMD) ? 2 : 0;
 }
@@ -576,14 +576,15 @@ static kb_step_fn select_kernel(const kb_sim *sim, const kb::Params &p) {
     // scenes whose objects are all discs: instantiations without the kilobot - polygon contact code (5 / 6)
     bool discs = obj;
     for (int f = 0; f < p.F; ++f) discs = discs && ot_kind(p.otab[f]) == KB_SHAPE_CIRCLE;
-    if (p.allow_sleep) { discs = false; objsel = (obj ? (sim->threads <= 64 ? 2 : 1) : 0) | KB_PICK_SLEEP; }   // generic 128-VGPR instantiations with the sleep state
+    if (p.allow_sleep) { discs = false; objsel |= KB_PICK_SLEEP; }   // generic instantiations with the sleep state (no disc-only variants)
     if (discs) objsel += 4;
     switch (p.drive_mode) {
     case KB_DRIVE_VELOCITY: {
         // the flagship size has its own instantiation with a compile-time LDS layout
         const bool fixed = uses_fixed_1024(p, sim->threads);
         if (fixed && !obj && p.capL != ldsc::CAPL) return nullptr;      // (cannot happen: kb_create / kb_set_block_threads keep them in step)
-        return kb_pick_velocity(fixed ? (p.sense_s > 0 ? KB_PICK_FIXED_1024_SENSE : KB_PICK_FIXED_1024) : p.light_type, fixed ? (discs ? 5 : (int)obj) : objsel);
+        return kb_pick_velocity(fixed ? (p.sense_s > 0 ? KB_PICK_FIXED_1024_SENSE : KB_PICK_FIXED_1024) : p.light_type,
+                                fixed ? ((discs ? 5 : (int)obj) | (p.allow_sleep ? KB_PICK_SLEEP : 0)) : objsel);
     }
     case KB_DRIVE_ACCEL: return kb_pick_accel(p.light_type, objsel);
     case KB_DRIVE_MOTORS: return kb_pick_motors(p.light_type, objsel);

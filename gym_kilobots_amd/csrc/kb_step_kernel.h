@@ -26,12 +26,12 @@ namespace kb {
 // The fixed-size kernel without objects is always tier 2.
 // SLEEP = true: b2World(doSleep=True) of kilobots_env.py:45 -- bodies carry b2Body::m_sleepTime, islands without an awake
 // body are not solved (b2World::Solve), islands at rest for b2_timeToSleep whose position constraints converged fall asleep
-// (b2Island::Solve).  Generic kernels only; kb_step picks it when kb_config.allow_sleep != 0.
+// (b2Island::Solve).  Generic kernels and the fixed-size one without objects; kb_step picks it when kb_config.allow_sleep != 0.
 template <int DRIVE_MODE, int LIGHT_TYPE, bool OBJ, int FN = 0, int TIER = 0, bool POLY = true, bool SENSE = true, bool SLEEP = false>
 __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 ? 2 : ((TIER == 2 || (FN != 0 && !OBJ)) ? KB_COMPACT_WAVES_PER_SIMD : KB_MIN_WAVES_PER_SIMD)) kb_step_kernel(const Params p) {
     constexpr bool WIDE = TIER == 1;
     constexpr bool COMPACT = !OBJ;
-    static_assert(!SLEEP || FN == 0, "the fixed-size instantiations do not carry the sleep state");
+    static_assert(!SLEEP || FN == 0 || !OBJ, "the fixed-size instantiations with objects do not carry the sleep state");
     constexpr bool FOLD = FN != 0 && !OBJ;       // lCbk over nextb (needs capL <= NP)
     extern __shared__ __align__(16) unsigned char smem[];
     int e = blockIdx.x;
@@ -1800,10 +1800,11 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
 // one-wave workgroup (the WIDE instantiation), 3 none at 80 VGPRs (six waves per SIMD)
 template <int DRIVE_MODE, int LIGHT_TYPE>
 static kb_step_fn kb_pick_obj(int objects) {
-    if (objects & KB_PICK_SLEEP) {     // kb_config.allow_sleep: 128-VGPR generic instantiations (none / objects / objects + one wave)
+    if (objects & KB_PICK_SLEEP) {     // kb_config.allow_sleep: generic instantiations with the sleep state (none at 128 / 80 VGPRs, objects, objects + one wave)
         const int o_ = objects & ~KB_PICK_SLEEP;
         if (o_ == 2) return kb_step_kernel<DRIVE_MODE, LIGHT_TYPE, true, 0, 1, true, true, true>;
         if (o_ == 1) return kb_step_kernel<DRIVE_MODE, LIGHT_TYPE, true, 0, 0, true, true, true>;
+        if (o_ == 3) return kb_step_kernel<DRIVE_MODE, LIGHT_TYPE, false, 0, 2, true, true, true>;
         return kb_step_kernel<DRIVE_MODE, LIGHT_TYPE, false, 0, 0, true, true, true>;
     }
     if (objects == 2) return kb_step_kernel<DRIVE_MODE, LIGHT_TYPE, true, 0, 1>;

@@ -18,6 +18,8 @@ def main():
         for r in csv.DictReader(open(path)):
             if 'kb_step_kernel' not in r['Kernel_Name']:
                 continue
+            if name is not None and r['Kernel_Name'] != name:
+                continue                      # the headline instantiation only (the sleep-state leg launches another one)
             name = r['Kernel_Name']
             per[r['Counter_Name']].append((int(r.get('Dispatch_Id', 0) or 0), float(r['Counter_Value'])))
         print('# %s' % path.split('/')[-1])

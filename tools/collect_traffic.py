@@ -15,10 +15,12 @@ import sys
 
 
 def launches(path, counter):
-    vals = []
+    vals, name0 = [], None
     for r in csv.DictReader(open(path)):
         if 'kb_step_kernel' in r['Kernel_Name'] and r['Counter_Name'] == counter:
-            vals.append(float(r['Counter_Value']))
+            name0 = name0 or r['Kernel_Name']      # the headline instantiation only (the sleep-state leg launches another one)
+            if r['Kernel_Name'] == name0:
+                vals.append(float(r['Counter_Value']))
     return vals
 
 
