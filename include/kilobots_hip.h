@@ -138,9 +138,10 @@ typedef struct kb_config {
                                                    without an awake body are not simulated (b2World::Solve); a body wakes when a
                                                    non-zero velocity is assigned to it (Kilobot.step -> b2Body::SetLinearVelocity /
                                                    SetAngularVelocity) or an awake island reaches it.  The envs of
-                                                   gym_kilobots_amd.envs switch it on like the reference; the fixed-size benchmark
-                                                   instantiations do not carry the state (sleeping cannot change a trajectory in
-                                                   which every kilobot is commanded to move in every substep: DESIGN.md) */
+                                                   gym_kilobots_amd.envs switch it on like the reference; bench.py's headline
+                                                   runs without the state (sleeping cannot change a trajectory in which every
+                                                   kilobot is commanded to move in every substep: DESIGN.md 4c) and reports the
+                                                   instantiation with it next to it */
 } kb_config;
 
 enum kb_damping_model { KB_DAMPING_PADE = 0, KB_DAMPING_LINEAR = 1 };
