@@ -361,9 +361,13 @@ __device__ __forceinline__ void wall_geom(const AR &p, int wl, float x, float y,
 
 #ifdef KB_PROFILE
 // diagnostic build: thread 0 accumulates shader cycles per phase into g.status[E + 8*e + phase]
-#define KB_STAMP(ph) do { if (tid == 0) { long long t_ = clock64(); prof_acc[ph] += t_ - prof_t; prof_t = t_; } } while (0)
+// (light-weight: one 32-bit time register and fire-and-forget LDS atomics on the free words 24.. of the misc area; the first
+//  version kept 24 64-bit accumulators in registers, which the allocator spilled: every stamp was a scratch round trip and a
+//  fifth of the profiled time was the profile itself)
+#define KB_PROF(k) misc[24 + (k)]
+#define KB_STAMP(ph) do { if (tid == 0) { const unsigned t_ = (unsigned)clock64(); atomicAdd(&KB_PROF(ph), t_ - prof_t); prof_t = t_; } } while (0)
 // time since the last stamp without closing the interval: wave 0's own work before it waits at the barrier
-#define KB_STAMP_PRE(ph) do { if (tid == 0) { prof_acc[ph] += clock64() - prof_t; } } while (0)
+#define KB_STAMP_PRE(ph) do { if (tid == 0) { atomicAdd(&KB_PROF(ph), (unsigned)clock64() - prof_t); } } while (0)
 #else
 #define KB_STAMP(ph) do { } while (0)
 #define KB_STAMP_PRE(ph) do { } while (0)

@@ -128,9 +128,11 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
     KB_ENV_ADDRESSES();
 
 #ifdef KB_PROFILE
-    long long prof_acc[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    static_assert(M_COUNT <= 24, "profile words start at misc[24]");
     constexpr int M_PROF_DEPTH = 12;
-    long long prof_t = clock64();
+    if (tid < 40) misc[24 + tid] = 0;
+    __syncthreads();
+    unsigned prof_t = (unsigned)clock64();
 #endif
 
     // ---- load state; optional fused set_action (kilobot.py:235-241, 283-289) ----
@@ -930,7 +932,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
             const unsigned long long keymask = ((unsigned long long)mhi << 32) | mlo;
             wave_sync();   // bkMaxRank of this wave
 #ifdef KB_PROFILE
-            if (tid == 0) { prof_acc[8] += __popcll(keymask); prof_acc[11] += 1; }
+            if (tid == 0) { atomicAdd(&KB_PROF(8), (unsigned)__popcll(keymask)); atomicAdd(&KB_PROF(11), 1u); }
 #endif
 
 #define KB_REG_KEY_ROUNDS(...)                                                                      \
@@ -1099,7 +1101,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
             }
 #ifdef KB_PROFILE
             if (lane == 0) atomicMax(&misc[M_PROF], (unsigned)maxD);
-            if (tid == 0) prof_acc[M_PROF_DEPTH] += maxD;
+            if (tid == 0) atomicAdd(&KB_PROF(M_PROF_DEPTH), (unsigned)maxD);
             KB_STAMP(7);     // register load + depth sweep of wave 0 (no barrier: wave-local time)
 #endif
 #define KB_REG_ROUNDS(...)                                                                          \
@@ -1209,7 +1211,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
             KB_RETID();
             mc_store();
 #ifdef KB_PROFILE
-            if (tid == 0) prof_acc[9] += misc[M_PROF];   // deepest wave of the env (replaces the contacts-per-wave slot)
+            if (tid == 0) atomicAdd(&KB_PROF(9), misc[M_PROF]);   // deepest wave of the env (replaces the contacts-per-wave slot)
 #endif
             // StoreImpulses -> packed warm-start list of the next substep (LDS image and/or global)
             const bool last = sub == p.n_substeps - 1;
@@ -1338,7 +1340,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
                 }
                 if (OBJ && myMc) { viol |= mc_position_pass(myMc, lane == 0, act, nxt, it == p.pos_iters - 1); wave_sync(); }
 #ifdef KB_PROFILE
-                if (tid == 0) prof_acc[10] += 1;
+                if (tid == 0) atomicAdd(&KB_PROF(10), 1u);
 #endif
                 if (!__any(viol)) break;
                 // the flags the next sweep sets must start cleared (only this wave's islands)
@@ -1787,10 +1789,10 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
         }
         if (misc[M_STATUS]) atomicOr(&g.status[e], (int)misc[M_STATUS]);
 #ifdef KB_PROFILE
-        prof_acc[7] += clock64() - prof_t;
-        for (int k = 0; k < 8; ++k) g.status[p.E + 24 * e + k] += (int)(prof_acc[k] >> 4);   // units of 16 cycles
-        for (int k = 8; k < 13; ++k) g.status[p.E + 24 * e + k] += (int)prof_acc[k];
-        for (int k = 13; k < 24; ++k) g.status[p.E + 24 * e + k] += (int)(prof_acc[k] >> 4);
+        atomicAdd(&KB_PROF(22), (unsigned)clock64() - prof_t);     // write-back (thread 0's own stores)
+        for (int k = 0; k < 8; ++k) g.status[p.E + 24 * e + k] += (int)(KB_PROF(k) >> 4);   // units of 16 cycles
+        for (int k = 8; k < 13; ++k) g.status[p.E + 24 * e + k] += (int)KB_PROF(k);
+        for (int k = 13; k < 24; ++k) g.status[p.E + 24 * e + k] += (int)(KB_PROF(k) >> 4);
 #endif
     }
 }

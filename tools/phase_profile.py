@@ -70,7 +70,7 @@ def main():
     print('  %-18s %9.0f' % ('total', mean.sum()))
     ex = raw[:, 8:13].mean(0)
     extra = raw[:, 13:16].mean(0) * 16
-    print('  kernel start (per launch) %.0f, flatten+scan (part of islands+buckets) %.0f' % (extra[0], extra[1]))
+    print('  kernel start (per launch) %.0f, flatten+scan (part of islands+buckets) %.0f, write-back issue (thread 0) %.0f' % (extra[0], extra[1], raw[:, 22].mean() * 16))
     pre = raw[:, 16:19].mean(0) * 16
     print('  wave 0 before the barrier (own work): drive+grid %.0f, count pass %.0f, emit pass %.0f' % tuple(pre))
     sub_ = raw[:, 19:22].mean(0) * 16
