@@ -1137,6 +1137,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
                 }
             })
             if (OBJ && myMc) { mc_warm_pass(myMc, lane == 0); wave_sync(); }
+            KB_STAMP_PRE(29);    // (profile build) warm start of wave 0, since the register set-up
             // SolveVelocityConstraints: friction 0, restitution 0, one manifold point.
             // Branch-free rounds: slots that are not part of the current depth level work on a scratch body, so
             // the LDS reads of all KREG slots are issued together (one LDS round trip per round).
@@ -1206,6 +1207,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
                 }
                 if (OBJ && myMc) { mc_velocity_pass(myMc, lane == 0); wave_sync(); }
             }
+            KB_STAMP_PRE(30);    // ... + its 10 velocity sweeps, before the barrier
             __syncthreads();
             KB_STAMP(4);
             KB_RETID();
@@ -1349,6 +1351,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
                 if (OBJ && myMc) mc_clear_flags(myMc, lane == 0, act);
                 wave_sync();
             }
+            KB_STAMP_PRE(24);    // (profile build) wave 0's own position sweeps, before it waits for the slowest wave
 #undef KB_VEL_ROUND
 #undef KB_REG_ROUNDS
 #undef KB_REG_KEY_ROUNDS
@@ -1631,6 +1634,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
             if (big) solve_list(gPair, gInfo, gAcc, gCbk, gOrder); else solve_list(lPair, lInfo, lAcc, lCbk, lOrder);
         }
         __syncthreads();
+        KB_STAMP_PRE(25);        // ... + waiting for the wave with the most position sweeps
         KB_RETID();
         if (SLEEP) {
             // ---- b2Island::Solve, the allowSleep block: a body slower than the sleep tolerances accumulates sleep time; an
@@ -1715,6 +1719,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
                 lPair[i] = (unsigned)b; cTh0[i] = sth0[q]; cTh[i] = th[q]; cW[i] = bw[q];
             }
             __syncthreads();
+            KB_STAMP_PRE(26);    // ... + candidates of the continuous step collected
             const int ncand = min((int)misc[M_NCON], capL_ / 2);
             for (int i = tid; i < ncand; i += nt) {
                 const int b = (int)lPair[i];
@@ -1730,7 +1735,9 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
                 toi_walls_object(ox, ar, F, tid, start[N + tid].x, start[N + tid].y, objA0[tid], p.h, p.vel_iters,
                                  g.ows_acc + (size_t)e * (MAXOBJ * KB_OWS_COLS * KB_OWS_WORDS));
             }
+            KB_STAMP_PRE(27);    // ... + wave 0's own candidates processed
             __syncthreads();
+            KB_STAMP_PRE(28);    // ... + every wave's
 #pragma unroll
             for (int q = 0; q < BPT; ++q)
                 if (cand[q] >= 0) { th[q] = cTh[cand[q]]; bw[q] = cW[cand[q]]; }
@@ -1790,9 +1797,9 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
         if (misc[M_STATUS]) atomicOr(&g.status[e], (int)misc[M_STATUS]);
 #ifdef KB_PROFILE
         atomicAdd(&KB_PROF(22), (unsigned)clock64() - prof_t);     // write-back (thread 0's own stores)
-        for (int k = 0; k < 8; ++k) g.status[p.E + 24 * e + k] += (int)(KB_PROF(k) >> 4);   // units of 16 cycles
-        for (int k = 8; k < 13; ++k) g.status[p.E + 24 * e + k] += (int)KB_PROF(k);
-        for (int k = 13; k < 24; ++k) g.status[p.E + 24 * e + k] += (int)(KB_PROF(k) >> 4);
+        for (int k = 0; k < 8; ++k) g.status[p.E + 40 * e + k] += (int)(KB_PROF(k) >> 4);   // units of 16 cycles
+        for (int k = 8; k < 13; ++k) g.status[p.E + 40 * e + k] += (int)KB_PROF(k);
+        for (int k = 13; k < 40; ++k) g.status[p.E + 40 * e + k] += (int)(KB_PROF(k) >> 4);
 #endif
     }
 }

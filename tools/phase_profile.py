@@ -36,7 +36,7 @@ def main():
     if args.objects and args.boxes:
         okw = dict(obj_shape=[1] * args.objects, obj_nverts=[4] * args.objects, obj_verts=[[[0.075 * 25.0, 0.075 * 25.0]]] * args.objects)
     sim = KilobotSim(E, N, num_objects=args.objects, **okw)
-    sim.status = torch.zeros(E + 24 * E, dtype=torch.int32, device=sim.device)   # status + stamp area
+    sim.status = torch.zeros(E + 40 * E, dtype=torch.int32, device=sim.device)   # status + stamp area
     sim._bind()
     xy1, th1 = scenes.lattice_spawn(8, N, seed=1000)
     reps = (E + 7) // 8
@@ -61,7 +61,7 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / args.steps
-    raw = sim.status[E:].reshape(E, 24).double().cpu().numpy() / (args.steps * args.fused)
+    raw = sim.status[E:].reshape(E, 40).double().cpu().numpy() / (args.steps * args.fused)
     st = raw[:, :8] * 16
     mean = st.mean(0)
     print('launch %.3f ms (%d substeps per launch); cycles per env-substep (wave 0), mean over %d envs:' % (ms, args.fused, E))
@@ -75,6 +75,10 @@ def main():
     print('  wave 0 before the barrier (own work): drive+grid %.0f, count pass %.0f, emit pass %.0f' % tuple(pre))
     sub_ = raw[:, 19:22].mean(0) * 16
     print('  wave 0 inside the register set-up, cumulative since the sort barrier: light load %.0f, + depth pass %.0f, + dealing %.0f' % tuple(sub_))
+    fine = raw[:, 24:31].mean(0) * 16
+    print('  since the register set-up: warm start %.0f, + 10 velocity sweeps of wave 0 %.0f (then the barrier)' % (fine[5], fine[6]))
+    print('  since the integration: own position sweeps %.0f, + waiting for the slowest wave %.0f, + continuous-step candidates collected %.0f, '
+          '+ own candidates processed %.0f, + every wave\'s %.0f (then copies, cell heads cleared, barrier)' % tuple(fine[:5]))
     print('  wave 0 per substep: keys %.1f, depth rounds/sweep %.1f (deepest wave of the env %.1f), position sweeps %.2f, reg-path fraction %.2f' % (ex[0], ex[4], ex[1], ex[2], ex[3]))
 
 
