@@ -116,6 +116,15 @@ def lint_codegen(verbose=False):
     objects it links and fails on a finding; this entry point re-derives the assembly from the sources.)"""
     sys.path.insert(0, os.path.join(ROOT, 'tools'))
     import lint_spills
+    # the assembly that build() kept next to the objects it linked is the shipped code: use it while it is current
+    reldir = os.path.join(HERE, '_obj', 'rel')
+    kept = [_device_asm(reldir, s_) for s_ in sources() if os.path.basename(s_).startswith('kb_inst_')]
+    deps = sources() + glob.glob(os.path.join(CSRC, '*.h')) + [os.path.join(INC, 'kilobots_hip.h')]
+    if os.path.exists(LIB) and all(os.path.exists(a) and os.path.getmtime(a) >= max(os.path.getmtime(d) for d in deps) for a in kept):
+        findings = []
+        for a in kept:
+            findings += lint_spills.lint(a)
+        return findings
     asmdir = os.path.join(HERE, '_obj', 'asm')
     os.makedirs(asmdir, exist_ok=True)
     units = [s_ for s_ in sources() if os.path.basename(s_).startswith('kb_inst_')]
