@@ -810,3 +810,41 @@ def test_cfg3_full_size_invariants_and_slice_parity():
         d = np.hypot(px[e][:, None] - px[e][None, :], py[e][:, None] - py[e][None, :])
         d[np.diag_indices(N)] = 10.0
         assert d.min() > 0.825 - 0.015 - 0.13
+
+
+@pytest.mark.parametrize('variant', ['cfg3', 'cfg3_sleep', 'cfg4_discs', 'cfg4_boxes_sleep'])
+def test_long_horizon_stays_bit_exact(variant):
+    """Hundreds of substeps of the benchmark scenes (the settled regime the bench times: ~550 contacts per env, kilobots
+    against the walls, continuous-step events, objects in the crowd), substep by substep launches and fused ones mixed:
+    every bit of the state still equals the oracle at the end -- rare events do not drift apart."""
+    N, E = 1024, 2
+    xy, th = scenes.lattice_spawn(E, N, seed=77)
+    kw, objects = {}, None
+    if 'sleep' in variant:
+        kw['allow_sleep'] = 1
+    if variant.startswith('cfg4'):
+        objects = np.tile(scenes.CFG4_OBJECTS[None], (E, 1, 1))
+        if 'boxes' in variant:
+            kw.update(obj_shape=[1] * 4 + [0] * 4, obj_nverts=[4] * 4 + [0] * 4,
+                      obj_verts=[[[0.075 * 25.0, 0.075 * 25.0]] + [[0.0, 0.0]] * 3] * 4 + [[[0.0, 0.0]] * 4] * 4)
+    osim, gsim = make_pair(E, N, xy=xy, th=th, objects=objects, **kw)
+    steps = 240 if variant.startswith('cfg4') else 400
+    k = 0
+    while k < steps:
+        a = scenes.random_actions(E, N, seed=9000 + k)
+        if variant.startswith('cfg4'):
+            a[:, ::2] = (0.01, 0.0)                 # every second kilobot rams ahead (the bench's cfg4 actions)
+        if 'sleep' in variant and (k // 40) % 3 == 2:
+            a[:, N // 3:] = 0.0                     # two thirds of the swarm rest for 40 substeps at a time
+        n = 10 if (k // 10) % 4 == 3 else 1         # fused env.step launches in between
+        osim.set_actions(a)
+        osim.step(n, threads=2)
+        gsim.step(n, actions=dev(a))
+        k += n
+    fields = ('x', 'y', 'theta') + (OBJ_FIELDS[3:] if objects is not None else ()) + (('sleep_time',) if 'sleep' in variant else ())
+    assert_same(osim, gsim, variant, fields)
+    assert_ws_same(osim, gsim, variant)
+    assert int(cpu(gsim.status).max()) == 0 and int(osim.status.max()) == 0
+    assert osim.ws_cnt.sum() / E > (600 if variant.startswith('cfg4') else 450)       # the settled, contact-rich regime
+    if 'sleep' in variant:
+        assert (osim.sleep_time < 0).any()
