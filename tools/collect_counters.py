@@ -26,7 +26,7 @@ def main():
         print('# kernel: %s' % name)
         for c in sorted(per):
             v = [x for _, x in sorted(per[c])]
-            t = v[-(steps + nf):-nf]
+            t = v[-(2 * steps + nf):-(steps + nf)]      # the timed region (behind it: its audit pass, then the fused launches)
             print('%-28s %16.1f   (mean of %d timed launches; launch 0: %.1f)' % (c, sum(t) / len(t), len(t), v[0]))
 
 

@@ -28,8 +28,8 @@ def main():
     fetch_csv, write_csv, envs, bots, out = sys.argv[1:6]
     f = launches(fetch_csv, 'FETCH_SIZE')
     w = launches(write_csv, 'WRITE_SIZE')
-    n = 20     # the timed launches are the last ones of the run (after warm-up; the fused extra launches come last)
-    f_t, w_t = f[-(n + 3):-3], w[-(n + 3):-3]
+    n = 20     # bench.py --steps 20: the timed region, then its audit pass (20 more), then 3 fused launches
+    f_t, w_t = f[-(2 * n + 3):-(n + 3)], w[-(2 * n + 3):-(n + 3)]
     fetch_b = sum(f_t) / len(f_t) * 1024 * 2
     write_b = sum(w_t) / len(w_t) * 1024
     res = {'envs': int(envs), 'bots': int(bots), 'launches_averaged': len(f_t),
