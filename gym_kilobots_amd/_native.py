@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('KB_HIP_LIB', os.path.join(HERE, 'libkilobots_hip.so'))
 
 KB_OK, KB_EINVAL, KB_ENOTBOUND, KB_EHIP, KB_ELDS = 0, -1, -2, -3, -4
-DRIVE_VELOCITY, DRIVE_ACCEL, DRIVE_MOTORS, DRIVE_SIMPLE_PHOTOTAXIS, DRIVE_PHOTOTAXIS = range(5)
+DRIVE_VELOCITY, DRIVE_ACCEL, DRIVE_MOTORS, DRIVE_SIMPLE_PHOTOTAXIS, DRIVE_PHOTOTAXIS, DRIVE_MIXED = range(6)
 LIGHT_NONE, LIGHT_CIRCULAR, LIGHT_GRADIENT, LIGHT_MOMENTUM, LIGHT_COMPOSITE = range(5)
 MAX_LIGHTS = 4
 STEP_NO_DRIVE = 1
@@ -50,6 +50,7 @@ class KbConfig(C.Structure):
         ('wall_friction', C.c_float),
         ('num_fixtures', C.c_int32), ('obj_fixture_body', C.c_int32 * MAX_OBJECTS),
         ('damping_model', C.c_int32), ('sense_radius', C.c_float), ('contact_capacity', C.c_int32),
+        ('mode_density', C.c_float * 5),
         ('allow_sleep', C.c_int32),
     ]
 
@@ -67,7 +68,7 @@ BUFFER_FIELDS = ['x', 'y', 'theta', 'v', 'w', 'acc_v', 'acc_w', 'motor_l', 'moto
                  'ox', 'oy', 'otheta', 'ovx', 'ovy', 'ow',
                  'ws_key', 'ws_acc', 'ws_cnt',
                  'light_value', 'light_gx', 'light_gy', 'cmd_vx', 'cmd_vy', 'cmd_w', 'status', 'scratch', 'ows_acc', 'nbr_count',
-                 'sleep_time', 'osleep']
+                 'sleep_time', 'osleep', 'bot_mode']
 
 
 class KbBuffers(C.Structure):

@@ -40,11 +40,12 @@ __global__ void kb_set_actions_kernel(const Params p) {
     if (i >= T) return;
     float a0 = 0.0f, a1 = 0.0f;
     if (p.actions) { const float2 a = reinterpret_cast<const float2 *>(p.actions)[i]; a0 = a.x; a1 = a.y; }
-    if (p.drive_mode == KB_DRIVE_VELOCITY) {
+    const int law = p.drive_mode == KB_DRIVE_MIXED ? (int)p.buf.bot_mode[i] : p.drive_mode;
+    if (law == KB_DRIVE_VELOCITY) {
         const float mw = 0.5f * 3.14159265358979323846f;
         p.buf.v[i] = fmaxf(fminf(a0, 0.01f), 0.0f);
         p.buf.w[i] = fmaxf(fminf(a1, mw), -mw);
-    } else {
+    } else if (law == KB_DRIVE_ACCEL) {
         const float aw = 0.2f * 3.14159265358979323846f;
         p.buf.acc_v[i] = fmaxf(fminf(a0, 0.005f), -0.005f);
         p.buf.acc_w[i] = fmaxf(fminf(a1, aw), -aw);
@@ -134,7 +135,7 @@ __global__ void __launch_bounds__(256) kb_light_sense_kernel(const Params p, con
     for (int b = tid; b < N; b += nt) {
         const float bx = g.x[o + b], by = g.y[o + b];
         float sx = bx, sy = by;
-        if (p.drive_mode != KB_DRIVE_SIMPLE_PHOTOTAXIS) {  // kilobot.py:54-55: world point of (0, -r)
+        if ((p.drive_mode == KB_DRIVE_MIXED ? (int)g.bot_mode[o + b] : p.drive_mode) != KB_DRIVE_SIMPLE_PHOTOTAXIS) {  // kilobot.py:54-55: world point of (0, -r)
             float s, c;
             kb_sincosf(g.theta[o + b], s, c);
             const float lx0 = 0.0f, ly0 = -p.r_bot;
@@ -175,7 +176,8 @@ __global__ void kb_reset_kernel(const Params p, const ResetArgs a) {
     if (a.random_theta) th = ((float)(r.z >> 8) * (1.0f / 16777216.0f) * 2.0f - 1.0f) * 3.14159265358979323846f;
     p.buf.theta[i] = th;
     p.buf.ws_cnt[i] = 0;
-    if (p.drive_mode == KB_DRIVE_VELOCITY || p.drive_mode == KB_DRIVE_ACCEL) {
+    const int law = p.drive_mode == KB_DRIVE_MIXED ? (int)p.buf.bot_mode[i] : p.drive_mode;
+    if (law == KB_DRIVE_VELOCITY || law == KB_DRIVE_ACCEL) {
         float v = 0.0f, w = 0.0f;
         if (a.random_velocity) {                                                       // kilobot.py:225-229
             v = (float)(r.w & 0xFFFFu) * (1.0f / 65536.0f) * 0.01f;
@@ -183,9 +185,9 @@ __global__ void kb_reset_kernel(const Params p, const ResetArgs a) {
         }
         p.buf.v[i] = v; p.buf.w[i] = w;
     }
-    if (p.drive_mode == KB_DRIVE_ACCEL) { p.buf.acc_v[i] = 0.0f; p.buf.acc_w[i] = 0.0f; }
-    if (p.drive_mode == KB_DRIVE_MOTORS || p.drive_mode == KB_DRIVE_PHOTOTAXIS) { p.buf.motor_l[i] = 255; p.buf.motor_r[i] = 0; }   // turn_left
-    if (p.drive_mode == KB_DRIVE_PHOTOTAXIS) {
+    if (law == KB_DRIVE_ACCEL) { p.buf.acc_v[i] = 0.0f; p.buf.acc_w[i] = 0.0f; }
+    if (law == KB_DRIVE_MOTORS || law == KB_DRIVE_PHOTOTAXIS) { p.buf.motor_l[i] = 255; p.buf.motor_r[i] = 0; }   // turn_left
+    if (law == KB_DRIVE_PHOTOTAXIS) {
         p.buf.pt_threshold[i] = -INFINITY; p.buf.pt_update[i] = 0; p.buf.pt_nochange[i] = 0; p.buf.pt_dir[i] = 0;
     }
     if (b == 0) p.buf.status[e] = 0;
@@ -230,12 +232,18 @@ static bool uses_fixed_1024(const kb::Params &p, int threads) {   // the instant
            kb::BPT * 64 * kb::MAX_WAVES == 1024 && p.NP == 1024 && p.NB == 1024 + KB_MAX_OBJECTS + 4 &&
            (p.M > 0 || p.cap == (int)cap1024);      // (without objects the contact capacity is a compile-time constant of the kernel)
 }
+static int lds_image_bytes(const kb::Params &p, int threads, int capL);
 static int lds_bytes_for(const kb::Params &p, int threads, int capL) {
-    if (p.M == 0) {      // kernels without objects: the compact image (namespace ldsc)
+    const int img = lds_image_bytes(p, threads, capL);
+    // KB_DRIVE_MIXED: the drive law of every kilobot (one byte each) lies behind the image (Params.botlaw_off)
+    return p.drive_mode == KB_DRIVE_MIXED ? ((img + 15) & ~15) + ((p.NP + 15) & ~15) : img;
+}
+static int lds_image_bytes(const kb::Params &p, int threads, int capL) {
+    if (p.M == 0 && p.drive_mode != KB_DRIVE_MIXED) {      // kernels without objects: the compact image (namespace ldsc)
         const bool fold = uses_fixed_1024(p, threads);
         return kb::ldsc::total(p.NB, fold ? kb::ldsc::CAPL : capL, p.NP, fold, p.nhead, threads / 64);
     }
-    const bool objarea = p.M > 0 || uses_fixed_1024(p, threads);
+    const bool objarea = p.M > 0 || p.drive_mode == KB_DRIVE_MIXED || uses_fixed_1024(p, threads);
     return kb::lds::total(kb::lds::fixed(objarea, threads / 64), p.NB, capL, p.NP, p.nhead, p.nmc);
 }
 
@@ -250,7 +258,7 @@ static int resident_envs(int lds, int threads, int wps) {
 }
 // register budget of a kernel without objects: 80 VGPRs (tier 2) where that holds more envs than 128 VGPRs
 static int pick_tier(const kb::Params &p, int threads, int lds) {
-    if (p.M > 0) return 0;
+    if (p.M > 0 || p.drive_mode == KB_DRIVE_MIXED) return 0;
     if (const char *t = getenv("KB_TIER")) return atoi(t) == 2 ? 2 : 0;      // experiment knob (A/B of the register budgets)
     return resident_envs(lds, threads, KB_COMPACT_WAVES_PER_SIMD) > resident_envs(lds, threads, KB_MIN_WAVES_PER_SIMD) ? 2 : 0;
 }
@@ -303,7 +311,9 @@ int kb_create(const kb_config *cfg, kb_sim **out) {
     if (cfg->num_objects > 0 && (!(cfg->obj_friction >= 0.0f) || !(cfg->wall_friction >= 0.0f)))
         return fail(KB_EINVAL, "kb_create: friction coefficients must be non-negative");
     if (cfg->num_objects > 0 && !(cfg->obj_density > 0.0f)) return fail(KB_EINVAL, "kb_create: obj_density must be positive");
-    if (cfg->drive_mode < 0 || cfg->drive_mode > KB_DRIVE_PHOTOTAXIS) return fail(KB_EINVAL, "kb_create: bad drive_mode");
+    if (cfg->drive_mode < 0 || cfg->drive_mode > KB_DRIVE_MIXED) return fail(KB_EINVAL, "kb_create: bad drive_mode");
+    if (cfg->drive_mode == KB_DRIVE_MIXED && cfg->num_bots > kb::BPT * 64)
+        return fail(KB_EINVAL, "kb_create: KB_DRIVE_MIXED runs as one-wave workgroups: num_bots <= 128");
     if (cfg->light_type < KB_LIGHT_NONE || cfg->light_type > KB_LIGHT_COMPOSITE)
         return fail(KB_EINVAL, "kb_create: unsupported light_type");
     if (cfg->light_type == KB_LIGHT_COMPOSITE) {
@@ -358,6 +368,14 @@ int kb_create(const kb_config *cfg, kb_sim **out) {
     p.r_bot = cfg->bot_radius * WORLD_SCALE;
     const float m = cfg->bot_density * B2_PI * p.r_bot * p.r_bot;  // b2CircleShape::ComputeMass
     p.im_bot = m > 0.0f ? 1.0f / m : 0.0f;
+    for (int k = 0; k < 5; ++k) {       // KB_DRIVE_MIXED: the classes have different fixture densities (kilobot.py:25 / :214)
+        p.im_mode[k] = p.im_bot;
+        if (cfg->drive_mode == KB_DRIVE_MIXED && cfg->mode_density[k] > 0.0f) {
+            const float mk = cfg->mode_density[k] * B2_PI * p.r_bot * p.r_bot;
+            p.im_mode[k] = mk > 0.0f ? 1.0f / mk : 0.0f;
+        }
+    }
+    p.botlaw_off = 0;
     // b2Island::Solve damping factor per step: Pade (Box2D >= 2.3.1) or the older clamped linear form
     auto damp = [&](float c) -> float {
         if (cfg->damping_model == KB_DAMPING_LINEAR) return kb_clampf_host(1.0f - p.h * c, 0.0f, 1.0f);
@@ -498,6 +516,7 @@ int kb_create(const kb_config *cfg, kb_sim **out) {
         // with objects, up to 128 kilobots run as one wave: that selects the spill-free 256-VGPR instantiation
         // (kb_step), measured + 6 ... 9 % at 100 kilobots and - 3 % at 128 against two-wave workgroups
         if (p.M > 0 && p.N <= BPT * 64) T = 64;
+        if (p.drive_mode == KB_DRIVE_MIXED) T = 64;       // (num_bots <= 128 checked above)
         s->threads = T;
     }
     {   // trade a few staging entries for one more env per CU when the LDS footprint is just above a divisor of 160 KiB
@@ -510,6 +529,7 @@ int kb_create(const kb_config *cfg, kb_sim **out) {
     s->capL_regular = p.capL;
     if (p.M == 0 && uses_fixed_1024(p, s->threads)) p.capL = ldsc::CAPL;
     p.lds_total = lds_bytes_for(p, s->threads, p.capL);
+    p.botlaw_off = (lds_image_bytes(p, s->threads, p.capL) + 15) & ~15;
     s->tier = pick_tier(p, s->threads, p.lds_total);
     if (p.lds_total > LDS_CU) {
         delete s;
@@ -526,6 +546,9 @@ int kb_bind(kb_sim *sim, const kb_buffers *b) {
     if (!b->x || !b->y || !b->theta || !b->ws_key || !b->ws_acc || !b->ws_cnt || !b->status || !b->scratch)
         return fail(KB_ENOTBOUND, "kb_bind: x, y, theta, ws_key, ws_acc, ws_cnt, status and scratch are required");
     const int m = sim->cfg.drive_mode;
+    if (m == KB_DRIVE_MIXED && (!b->bot_mode || !b->v || !b->w || !b->acc_v || !b->acc_w || !b->motor_l || !b->motor_r ||
+                                !b->pt_threshold || !b->pt_update || !b->pt_nochange || !b->pt_dir))
+        return fail(KB_ENOTBOUND, "kb_bind: KB_DRIVE_MIXED needs bot_mode and the state buffers of every drive law");
     if ((m == KB_DRIVE_VELOCITY || m == KB_DRIVE_ACCEL) && (!b->v || !b->w))
         return fail(KB_ENOTBOUND, "kb_bind: v and w are required in the velocity / acceleration modes");
     if (m == KB_DRIVE_ACCEL && (!b->acc_v || !b->acc_w)) return fail(KB_ENOTBOUND, "kb_bind: acc_v, acc_w required");
@@ -558,7 +581,7 @@ int kb_bind(kb_sim *sim, const kb_buffers *b) {
 int kb_set_actions(kb_sim *sim, const float *d_actions, void *stream) {
     if (!sim) return fail(KB_EINVAL, "kb_set_actions: NULL handle");
     if (!sim->bound) return fail(KB_ENOTBOUND, "kb_set_actions: kb_bind() first");
-    if (sim->cfg.drive_mode != KB_DRIVE_VELOCITY && sim->cfg.drive_mode != KB_DRIVE_ACCEL)
+    if (sim->cfg.drive_mode != KB_DRIVE_VELOCITY && sim->cfg.drive_mode != KB_DRIVE_ACCEL && sim->cfg.drive_mode != KB_DRIVE_MIXED)
         return fail(KB_EINVAL, "kb_set_actions: only the velocity / acceleration drive modes take actions");
     Params p = sim->p;
     p.actions = d_actions;
@@ -590,6 +613,7 @@ static kb_step_fn select_kernel(const kb_sim *sim, const kb::Params &p) {
     case KB_DRIVE_MOTORS: return kb_pick_motors(p.light_type, objsel);
     case KB_DRIVE_SIMPLE_PHOTOTAXIS: return kb_pick_simple_phototaxis(p.light_type, objsel);
     case KB_DRIVE_PHOTOTAXIS: return kb_pick_phototaxis(p.light_type, objsel);
+    case KB_DRIVE_MIXED: return sim->threads == 64 ? kb_pick_mixed(p.light_type, p.allow_sleep) : nullptr;
     default: return nullptr;
     }
 }
@@ -612,7 +636,7 @@ int kb_step(kb_sim *sim, const float *d_actions, const float *d_light_action, in
     if (!sim) return fail(KB_EINVAL, "kb_step: NULL handle");
     if (!sim->bound) return fail(KB_ENOTBOUND, "kb_step: kb_bind() first");
     if (n_substeps < 0) return fail(KB_EINVAL, "kb_step: n_substeps < 0");
-    if (d_actions && sim->cfg.drive_mode != KB_DRIVE_VELOCITY && sim->cfg.drive_mode != KB_DRIVE_ACCEL)
+    if (d_actions && sim->cfg.drive_mode != KB_DRIVE_VELOCITY && sim->cfg.drive_mode != KB_DRIVE_ACCEL && sim->cfg.drive_mode != KB_DRIVE_MIXED)
         return fail(KB_EINVAL, "kb_step: only the velocity / acceleration drive modes take actions");
     if (n_substeps == 0 && !d_actions) return KB_OK;
     Params p = sim->p;
@@ -706,9 +730,11 @@ int kb_set_block_threads(kb_sim *sim, int threads) {
     const int capL = (sim->p.M == 0 && uses_fixed_1024(sim->p, threads)) ? ldsc::CAPL : sim->capL_regular;
     const int need = lds_bytes_for(sim->p, threads, capL);
     if (need > 160 * 1024) return fail(KB_ELDS, "kb_set_block_threads: more than 160 KiB of LDS per env at this workgroup size");
+    if (sim->p.drive_mode == KB_DRIVE_MIXED && threads != 64) return fail(KB_EINVAL, "kb_set_block_threads: KB_DRIVE_MIXED runs as one-wave workgroups");
     sim->threads = threads;
     sim->p.capL = capL;
     sim->p.lds_total = need;
+    sim->p.botlaw_off = (lds_image_bytes(sim->p, threads, capL) + 15) & ~15;
     sim->tier = pick_tier(sim->p, threads, need);
     return KB_OK;
 }

@@ -177,6 +177,8 @@ struct Params {
     int lds_total;
     int nhead, hmask;                         // cell heads: nhead entries; hmask != 0: a hash table of the cells (slot = cell & hmask)
     int allow_sleep;                          // kb_config.allow_sleep: the SLEEP instantiations are launched
+    float im_mode[5];                         // KB_DRIVE_MIXED: inverse mass of a kilobot by drive law
+    int botlaw_off;                           // ... and the LDS offset of the per-kilobot law bytes (behind the image)
     int sense_s;                              // IR neighbour sensing: reach of the stencil in cells (0 = off)
     float sense_r2;                           // ... and the squared radius in world units
 };
@@ -633,5 +635,6 @@ kb_step_fn kb_pick_simple_phototaxis(int light_type, int objects);
 kb_step_fn kb_pick_simple_phototaxis_discs(int light_type, int objects);   // objects: 0 none, 1 yes, 2 yes + one-wave workgroup
 kb_step_fn kb_pick_phototaxis(int light_type, int objects);
 kb_step_fn kb_pick_phototaxis_discs(int light_type, int objects);   // objects: 0 none, 1 yes, 2 yes + one-wave workgroup
+kb_step_fn kb_pick_mixed(int light_type, int sleep);                // KB_DRIVE_MIXED: one-wave workgroups (kb_inst_d5.hip)
 
 }  // namespace kb

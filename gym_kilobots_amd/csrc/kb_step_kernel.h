@@ -83,9 +83,17 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
     unsigned long long *mcMask = (unsigned long long *)(smem + ot_ + lds::MCMASK);   // manifold constraints owned by wave w
     float *objSlp = (float *)(smem + ot_ + lds::OBJSLP);                              // sleep time of object m (< 0: asleep)
     const int M = OBJ ? p.M : 0;   // OBJ = false: every object loop below folds away
+    // MIX: KB_DRIVE_MIXED, any mix of the five drive laws in one env (the reference steps whatever is in _kilobots,
+    // kilobots_env.py:183-184): the law of every kilobot comes from kb_buffers.bot_mode, its inverse mass (the classes have
+    // different densities, kilobot.py:25 / :214) from p.im_mode[law].  Instantiated on the code path with objects (per-body
+    // masses in the contacts' registers), one-wave workgroups.
+    constexpr bool MIX = DRIVE_MODE == KB_DRIVE_MIXED;
+    static_assert(!MIX || (OBJ && FN == 0), "mixed drive laws run on the generic code path with per-body masses");
+    unsigned char *botLaw = smem + (MIX ? p.botlaw_off : 0);     // MIX: [NP] law of every kilobot of the env (masses of contact partners)
+#define KB_IM_BOT(a_) (MIX ? p.im_mode[botLaw[a_]] : p.im_bot)     // inverse mass of kilobot a_
     // inverse mass / radius of a body id: kilobot < N, object N + m, wall >= WALL_CODE (static, edge skin radius)
     auto bim = [&](int id) __attribute__((always_inline)) -> float {
-        return id >= WALL_CODE ? 0.0f : ((!OBJ || id < N) ? p.im_bot : objBody[(id - N) * BT_WORDS + BT_IM]);
+        return id >= WALL_CODE ? 0.0f : ((!OBJ || id < N) ? KB_IM_BOT(id) : objBody[(id - N) * BT_WORDS + BT_IM]);
     };
     auto brad = [&](int id) __attribute__((always_inline)) -> float {
         return id >= WALL_CODE ? B2_POLYGON_RADIUS : ((!OBJ || id < N) ? p.r_bot : objBody[(id - N) * BT_WORDS + BT_RADIUS]);
@@ -139,26 +147,29 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
     float th[BPT], bw[BPT], cv[BPT], cw[BPT], av[BPT], aw[BPT];
     float sth0[BPT];     // angle at the start of the substep (continuous step against the walls)
     float slp[BPT];      // SLEEP: b2Body::m_sleepTime; < 0: the kilobot is asleep
-    const bool velmode = DRIVE_MODE == KB_DRIVE_VELOCITY || DRIVE_MODE == KB_DRIVE_ACCEL;
+    int law[BPT];        // drive law of this thread's kilobots
+#define KB_LAW(q) (MIX ? law[q] : DRIVE_MODE)
 #pragma unroll
     for (int q = 0; q < BPT; ++q) {
         const int b = tid + q * nt;
-        th[q] = 0.0f; bw[q] = 0.0f; cv[q] = 0.0f; cw[q] = 0.0f; av[q] = 0.0f; aw[q] = 0.0f; slp[q] = 0.0f;
+        th[q] = 0.0f; bw[q] = 0.0f; cv[q] = 0.0f; cw[q] = 0.0f; av[q] = 0.0f; aw[q] = 0.0f; slp[q] = 0.0f; law[q] = DRIVE_MODE;
         if (b < N) {
             pos[b].x = g.x[o + b]; pos[b].y = g.y[o + b]; th[q] = g.theta[o + b];
+            if (MIX) { law[q] = min((int)g.bot_mode[o + b], 4); botLaw[b] = (unsigned char)law[q]; }
             if (SLEEP) slp[q] = g.sleep_time[o + b];
             wsCnt[b] = g.ws_cnt[o + b];
             // (a velocity action replaces the stored command: nothing to load then)
-            if (velmode && !(DRIVE_MODE == KB_DRIVE_VELOCITY && p.actions)) { cv[q] = g.v[o + b]; cw[q] = g.w[o + b]; }
-            if (DRIVE_MODE == KB_DRIVE_ACCEL) { av[q] = g.acc_v[o + b]; aw[q] = g.acc_w[o + b]; }
+            const bool velmode = KB_LAW(q) == KB_DRIVE_VELOCITY || KB_LAW(q) == KB_DRIVE_ACCEL;
+            if (velmode && !(KB_LAW(q) == KB_DRIVE_VELOCITY && p.actions)) { cv[q] = g.v[o + b]; cw[q] = g.w[o + b]; }
+            if (KB_LAW(q) == KB_DRIVE_ACCEL) { av[q] = g.acc_v[o + b]; aw[q] = g.acc_w[o + b]; }
             if (p.actions) {
                 const float2 a = reinterpret_cast<const float2 *>(p.actions)[o + b];
                 const float mw = 0.5f * 3.14159265358979323846f;
-                if (DRIVE_MODE == KB_DRIVE_VELOCITY) {
+                if (KB_LAW(q) == KB_DRIVE_VELOCITY) {
                     cv[q] = fmaxf(fminf(a.x, 0.01f), 0.0f);
                     cw[q] = fmaxf(fminf(a.y, mw), -mw);
                     g.v[o + b] = cv[q]; g.w[o + b] = cw[q];
-                } else if (DRIVE_MODE == KB_DRIVE_ACCEL) {
+                } else if (KB_LAW(q) == KB_DRIVE_ACCEL) {
                     const float aw_ = 0.2f * 3.14159265358979323846f;
                     av[q] = fmaxf(fminf(a.x, 0.005f), -0.005f);
                     aw[q] = fmaxf(fminf(a.y, aw_), -aw_);
@@ -264,7 +275,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
                 float lval = 0.0f, lgx = 0.0f, lgy = 0.0f;
                 if (LIGHT_TYPE != KB_LIGHT_NONE) {
                     float sx = bx, sy = by;
-                    if (DRIVE_MODE != KB_DRIVE_SIMPLE_PHOTOTAXIS) {  // kilobot.py:54-55: world point of (0, -r)
+                    if (KB_LAW(q) != KB_DRIVE_SIMPLE_PHOTOTAXIS) {  // kilobot.py:54-55: world point of (0, -r)
                         float s, c;
                         kb_sincosf(t, s, c);
                         const float lx0 = 0.0f, ly0 = -p.r_bot;
@@ -275,7 +286,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
                     else kb_light_circular(sx / WORLD_SCALE, sy / WORLD_SCALE, lx, ly, p.light_radius, lval, lgx, lgy);
                     if (g.light_value) { g.light_value[o + b] = lval; g.light_gx[o + b] = lgx; g.light_gy[o + b] = lgy; }
                 }
-                switch (DRIVE_MODE) {
+                switch (KB_LAW(q)) {
                 case KB_DRIVE_ACCEL: {  // kilobot.py:294-300
                     float v = cv[q] + av[q] * h, ww = cw[q] + aw[q] * h;
                     const float mw = 0.5f * 3.14159265358979323846f;
@@ -328,7 +339,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
                 active[b] = 0;       // "the island rooted here has an awake body": set in the flatten phase
             }
             // b2Island::Solve: v *= 1/(1 + h c)  (SimplePhototaxisKilobot sets linearDamping = 0, kilobot.py:203)
-            const float kl = (DRIVE_MODE == KB_DRIVE_SIMPLE_PHOTOTAXIS) ? 1.0f / (1.0f + h * 0.0f) : p.kl_bot;
+            const float kl = (KB_LAW(q) == KB_DRIVE_SIMPLE_PHOTOTAXIS) ? 1.0f / (1.0f + h * 0.0f) : p.kl_bot;
             vel[b].x = bvx * kl; vel[b].y = bvy * kl; bw[q] = bww * p.ka_bot;
             parent[b] = b;
             // broadphase: push the bot on its cell's list
@@ -1073,7 +1084,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
                         const V2 point = v_scale(0.5f, v_add(cA, cB));
                         const V2 rA = v_sub(point, mk2(pos[b].x, pos[b].y));
                         const float rnA = v_cross(rA, normal);
-                        const float kNormal = T[OT_IM] + p.im_bot + T[OT_II] * rnA * rnA;
+                        const float kNormal = T[OT_IM] + KB_IM_BOT(a) + T[OT_II] * rnA * rnA;
                         rpoly[j] = true; rnx[j] = normal.x; rny[j] = normal.y; rrAx[j] = rA.x; rrAy[j] = rA.y;
                         rlnx[j] = ln.x; rlny[j] = ln.y; rlpx[j] = lp.x; rlpy[j] = lp.y;
                         rnm[j] = kNormal > 0.0f ? 1.0f / kNormal : 0.0f;
@@ -1304,12 +1315,12 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
                             if (sep < -3.0f * B2_LINEAR_SLOP) { nxt[isl] = 1; viol = true; if (SLEEP && it == p.pos_iters - 1) islWave[isl] = 3; }
                             const float C = kb_clampf(B2_BAUMGARTE * (sep + B2_LINEAR_SLOP), -B2_MAX_LINEAR_CORRECTION, 0.0f);
                             const float rnA = v_cross(rA, normal);
-                            const float K = T[BT_IM] + p.im_bot + T[BT_II] * rnA * rnA;
+                            const float K = T[BT_IM] + KB_IM_BOT(a) + T[BT_II] * rnA * rnA;
                             const float imp = K > 0.0f ? -C / K : 0.0f;
                             const V2 P = v_scale(imp, normal);
                             pos[b].x -= T[BT_IM] * P.x; pos[b].y -= T[BT_IM] * P.y;
                             objA[m] -= T[BT_II] * v_cross(rA, P);
-                            pos[a].x += p.im_bot * P.x; pos[a].y += p.im_bot * P.y;
+                            pos[a].x += KB_IM_BOT(a) * P.x; pos[a].y += KB_IM_BOT(a) * P.y;
                             continue;
                         }
                         float nx, ny, sep;
@@ -1423,12 +1434,12 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
                         const int m = b - N;
                         const float *T = objTab + ((sInfo[c] >> 24) & 15u) * OT_WORDS;      // the fixture that is touched
                         PolyCon pc;
-                        poly_contact_setup(T, body_xf(ox, b), pos[b].x, pos[b].y, mk2(pos[a].x, pos[a].y), p.r_bot, p.im_bot, pc);
+                        poly_contact_setup(T, body_xf(ox, b), pos[b].x, pos[b].y, mk2(pos[a].x, pos[a].y), p.r_bot, KB_IM_BOT(a), pc);
                         const float acc = sAcc[c];
                         const float Px = acc * pc.normal.x, Py = acc * pc.normal.y;
                         objW[m] -= T[OT_II] * (pc.rA.x * Py - pc.rA.y * Px);
                         vel[b].x -= T[OT_IM] * Px; vel[b].y -= T[OT_IM] * Py;
-                        vel[a].x += p.im_bot * Px; vel[a].y += p.im_bot * Py;
+                        vel[a].x += KB_IM_BOT(a) * Px; vel[a].y += KB_IM_BOT(a) * Py;
                     } else {
                     KB_VEL_NORMAL(a, b, flip, nx, ny)
                     const float acc = sAcc[c];
@@ -1449,7 +1460,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
                             const int m = b - N;
                             const float *T = objTab + ((sInfo[c] >> 24) & 15u) * OT_WORDS;
                             PolyCon pc;
-                            poly_contact_setup(T, body_xf(ox, b), pos[b].x, pos[b].y, mk2(pos[a].x, pos[a].y), p.r_bot, p.im_bot, pc);
+                            poly_contact_setup(T, body_xf(ox, b), pos[b].x, pos[b].y, mk2(pos[a].x, pos[a].y), p.r_bot, KB_IM_BOT(a), pc);
                             const float wA = objW[m];
                             const float dvx = (vel[a].x - vel[b].x) - (-wA * pc.rA.y), dvy = (vel[a].y - vel[b].y) - (wA * pc.rA.x);
                             const float vn = dvx * pc.normal.x + dvy * pc.normal.y;
@@ -1461,7 +1472,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
                             const float Px = lambda * pc.normal.x, Py = lambda * pc.normal.y;
                             vel[b].x -= T[OT_IM] * Px; vel[b].y -= T[OT_IM] * Py;
                             objW[m] = wA - T[OT_II] * (pc.rA.x * Py - pc.rA.y * Px);
-                            vel[a].x += p.im_bot * Px; vel[a].y += p.im_bot * Py;
+                            vel[a].x += KB_IM_BOT(a) * Px; vel[a].y += KB_IM_BOT(a) * Py;
                             continue;
                         }
                         KB_VEL_NORMAL(a, b, flip, nx, ny)
@@ -1572,12 +1583,12 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
                             if (sep < -3.0f * B2_LINEAR_SLOP) { nxt[isl] = 1; viol = true; if (SLEEP && it == p.pos_iters - 1) islWave[isl] = 3; }
                             const float C = kb_clampf(B2_BAUMGARTE * (sep + B2_LINEAR_SLOP), -B2_MAX_LINEAR_CORRECTION, 0.0f);
                             const float rnA = v_cross(rA, normal);
-                            const float K = T[OT_IM] + p.im_bot + T[OT_II] * rnA * rnA;
+                            const float K = T[OT_IM] + KB_IM_BOT(a) + T[OT_II] * rnA * rnA;
                             const float imp = K > 0.0f ? -C / K : 0.0f;
                             const V2 P = v_scale(imp, normal);
                             pos[b].x -= T[OT_IM] * P.x; pos[b].y -= T[OT_IM] * P.y;
                             objA[m] -= T[OT_II] * v_cross(rA, P);
-                            pos[a].x += p.im_bot * P.x; pos[a].y += p.im_bot * P.y;
+                            pos[a].x += KB_IM_BOT(a) * P.x; pos[a].y += KB_IM_BOT(a) * P.y;
                         } else if (act[isl]) {
                             float nx, ny, sep;
                             const float ima = bim(a), imb = bim(b), rda = brad(a), rdb = brad(b);
@@ -1723,7 +1734,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
             const int ncand = min((int)misc[M_NCON], capL_ / 2);
             for (int i = tid; i < ncand; i += nt) {
                 const int b = (int)lPair[i];
-                float R = p.r_bot, im = p.im_bot;
+                float R = p.r_bot, im = KB_IM_BOT(b);
                 asm volatile("" : "+v"(R), "+v"(im));   // per-lane copies: keeps the two constants out of the scalar file over the event loop
                 float x_ = pos[b].x, y_ = pos[b].y, a_ = cTh[i], vx_ = vel[b].x, vy_ = vel[b].y, w_ = cW[i];
                 kb_toi_walls_body(p, R, im, COMPACT ? startX[b] : start[b].x, COMPACT ? startY[b] : start[b].y, cTh0[i], x_, y_, a_, vx_, vy_, w_);
@@ -1770,7 +1781,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 
             g.x[o + b] = pos[b].x; g.y[o + b] = pos[b].y; g.theta[o + b] = th[q];
             if (SLEEP && p.n_substeps > 0) g.sleep_time[o + b] = slp[q];
             if (p.n_substeps > 0) g.ws_cnt[o + b] = wsCnt[b];
-            if (DRIVE_MODE == KB_DRIVE_ACCEL && p.n_substeps > 0 && drive) { g.v[o + b] = cv[q]; g.w[o + b] = cw[q]; }
+            if (KB_LAW(q) == KB_DRIVE_ACCEL && p.n_substeps > 0 && drive) { g.v[o + b] = cv[q]; g.w[o + b] = cw[q]; }
         }
     }
     if (tid < M && p.n_substeps > 0) {

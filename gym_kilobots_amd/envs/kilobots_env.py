@@ -245,7 +245,7 @@ class KilobotsEnv(object):
         # Kilobots with their own _loop (the reference's extension point, kilobot.py:86-88,164-168) and mixes of the classes
         # that share Kilobot.step (the motor law) are "host-programmed": every substep the device senses the light, the
         # host runs each kilobot's _loop, and the device applies the motor law and steps the world (_step_host_programmed).
-        self._host_programmed = any(type(k)._host_programmed() for k in kbs) or (motor_family and len(kinds) > 1)
+        self._host_programmed = any(type(k)._host_programmed() for k in kbs)
         if self._host_programmed:
             if not motor_family:
                 raise ValueError('host-programmed kilobots (own _loop) only mix with classes that use the motor law of '
@@ -254,14 +254,24 @@ class KilobotsEnv(object):
                 raise ValueError('kilobots with their own _loop are Python objects of ONE world: use num_envs=1 '
                                  '(the batched device laws are the classes of gym_kilobots_amd.lib.kilobot)')
             kinds = {nat.DRIVE_MOTORS}
-        if len(kinds) != 1:
-            raise ValueError('all kilobots of an env must share one drive law (got %s); only classes built on the motor law '
-                             '(Kilobot.step) can be mixed' % sorted(kinds))
-        props = {(float(type(k)._density), float(type(k)._radius), float(type(k)._linear_damping), float(type(k)._angular_damping))
-                 for k in kbs}
+        # Kilobots of several classes in one env (the reference steps whatever is in _kilobots, kilobots_env.py:183-184): the
+        # device step takes the drive law per kilobot (KB_DRIVE_MIXED) and the fixture density per law (the velocity /
+        # acceleration kilobots are twice as dense, kilobot.py:214)
+        mixed = len(kinds) > 1
+        mode_density = [0.0] * 5
+        if mixed:
+            if len(kbs) > 128:
+                raise ValueError('an env that mixes drive laws holds at most 128 kilobots (one-wave workgroups of the device step)')
+            for law in kinds:
+                dens = {float(type(k)._density) for k in kbs if type(k).drive_mode == law}
+                if len(dens) != 1:
+                    raise ValueError('kilobots of one drive law must share their density (got %s)' % sorted(dens))
+                mode_density[law] = dens.pop()
+        props = {((0.0 if mixed else float(type(k)._density)), float(type(k)._radius), float(type(k)._linear_damping),
+                  float(type(k)._angular_damping)) for k in kbs}
         if len(props) != 1:
-            raise ValueError('all kilobots of an env must share density, radius and damping (got %s)' % sorted(props))
-        mode = kinds.pop()
+            raise ValueError('all kilobots of an env must share radius and damping, and (unless drive laws are mixed) density (got %s)' % sorted(props))
+        mode = nat.DRIVE_MIXED if mixed else kinds.pop()
         light_type = nat.LIGHT_NONE
         overrides = dict(world_width=self.world_width, world_height=self.world_height, dt=self.sim_step,
                          vel_iters=self.__sim_velocity_iterations, pos_iters=self.__sim_position_iterations,
@@ -269,6 +279,8 @@ class KilobotsEnv(object):
                          bot_linear_damping=float(type(kbs[0])._linear_damping),
                          bot_angular_damping=float(type(kbs[0])._angular_damping),
                          allow_sleep=1 if self._allow_sleep else 0)      # b2World(gravity=(0, 0), doSleep=True), kilobots_env.py:45
+        if mixed:
+            overrides['mode_density'] = mode_density
         if self._objects:
             ob0 = type(self._objects[0])
             pad = nat.MAX_OBJECTS - len(specs)
@@ -330,19 +342,22 @@ class KilobotsEnv(object):
             op = np.array([ob._init_pose for ob in self._objects], dtype=np.float64)
             sim.set_objects_m(np.broadcast_to(op[None, :, :2], (self.num_envs, len(self._objects), 2)),
                               np.broadcast_to(op[None, :, 2], (self.num_envs, len(self._objects))))
-        if mode in (nat.DRIVE_VELOCITY, nat.DRIVE_ACCEL):
-            v0 = np.array([k._velocity for k in kbs], dtype=np.float32)
+        if mode == nat.DRIVE_MIXED:
+            laws = np.array([type(k).drive_mode for k in kbs], dtype=np.uint8)
+            sim.bot_mode.copy_(torch.from_numpy(np.broadcast_to(laws[None], (self.num_envs, N)).copy()))
+        if mode in (nat.DRIVE_VELOCITY, nat.DRIVE_ACCEL, nat.DRIVE_MIXED):
+            v0 = np.array([getattr(k, '_velocity', (0.0, 0.0)) for k in kbs], dtype=np.float32)
             sim.v.copy_(torch.from_numpy(np.broadcast_to(v0[None, :, 0], (self.num_envs, N)).copy()))
             sim.w.copy_(torch.from_numpy(np.broadcast_to(v0[None, :, 1], (self.num_envs, N)).copy()))
-        if mode == nat.DRIVE_ACCEL:
+        if mode in (nat.DRIVE_ACCEL, nat.DRIVE_MIXED):
             sim.acc_v.zero_()
             sim.acc_w.zero_()
-        if mode in (nat.DRIVE_MOTORS, nat.DRIVE_PHOTOTAXIS):
+        if mode in (nat.DRIVE_MOTORS, nat.DRIVE_PHOTOTAXIS, nat.DRIVE_MIXED):
             ml = np.array([k._motor_left for k in kbs], dtype=np.uint8)
             mr = np.array([k._motor_right for k in kbs], dtype=np.uint8)
             sim.motor_l.copy_(torch.from_numpy(np.broadcast_to(ml[None], (self.num_envs, N)).copy()))
             sim.motor_r.copy_(torch.from_numpy(np.broadcast_to(mr[None], (self.num_envs, N)).copy()))
-        if mode == nat.DRIVE_PHOTOTAXIS:
+        if mode in (nat.DRIVE_PHOTOTAXIS, nat.DRIVE_MIXED):
             sim.pt_threshold.fill_(float('-inf'))
             sim.pt_update.zero_()
             sim.pt_nochange.zero_()

@@ -44,15 +44,17 @@ class KilobotSim:
         self.motor_l = self.motor_r = None
         self.pt_threshold = self.pt_update = self.pt_nochange = self.pt_dir = None
         self.light_x = self.light_y = None
-        if drive_mode in (DRIVE_VELOCITY, DRIVE_ACCEL):
+        mixed = drive_mode == nat.DRIVE_MIXED      # every per-law state buffer + the per-kilobot law
+        self.bot_mode = torch.full((E, N), DRIVE_MOTORS, dtype=torch.uint8, device=dev) if mixed else None
+        if drive_mode in (DRIVE_VELOCITY, DRIVE_ACCEL) or mixed:
             self.v, self.w = f(E, N), f(E, N)
-        if drive_mode == DRIVE_ACCEL:
+        if drive_mode == DRIVE_ACCEL or mixed:
             self.acc_v, self.acc_w = f(E, N), f(E, N)
-        if drive_mode in (DRIVE_MOTORS, DRIVE_PHOTOTAXIS):
+        if drive_mode in (DRIVE_MOTORS, DRIVE_PHOTOTAXIS) or mixed:
             # Kilobot._setup -> turn_left (kilobot.py:78-81, 315-316)
             self.motor_l = torch.full((E, N), 255, dtype=torch.uint8, device=dev)
             self.motor_r = torch.zeros(E, N, dtype=torch.uint8, device=dev)
-        if drive_mode == DRIVE_PHOTOTAXIS:
+        if drive_mode == DRIVE_PHOTOTAXIS or mixed:
             self.pt_threshold = torch.full((E, N), float('-inf'), dtype=torch.float32, device=dev)
             self.pt_update = torch.zeros(E, N, dtype=torch.int32, device=dev)
             self.pt_nochange = torch.zeros(E, N, dtype=torch.int32, device=dev)

@@ -48,7 +48,11 @@ enum kb_drive_mode {
     KB_DRIVE_ACCEL = 1,             /* SimpleAccelerationControlKilobot  kilobot.py:266-300 */
     KB_DRIVE_MOTORS = 2,            /* Kilobot.step motor law            kilobot.py:86-127  */
     KB_DRIVE_SIMPLE_PHOTOTAXIS = 3, /* SimplePhototaxisKilobot           kilobot.py:171-210 */
-    KB_DRIVE_PHOTOTAXIS = 4         /* PhototaxisKilobot                 kilobot.py:303-333 */
+    KB_DRIVE_PHOTOTAXIS = 4,        /* PhototaxisKilobot                 kilobot.py:303-333 */
+    KB_DRIVE_MIXED = 5              /* any mix of the five in one env (KilobotsEnv.step steps whatever is in _kilobots,
+                                       kilobots_env.py:183-184): the law of every kilobot comes from kb_buffers.bot_mode, the
+                                       fixture density of its class from kb_config.mode_density; every per-law state buffer is
+                                       required; num_bots <= 128 (one-wave workgroups, the spill-free instantiation) */
 };
 
 enum kb_light_type {
@@ -130,6 +134,8 @@ typedef struct kb_config {
                                                    max(4 N + 64, min(N (N - 1) / 2 + 4 N, 2304)) + 40 objects.  A spawn that
                                                    overlaps more kilobots than that sets status bit 0; raise it (<= 65528) then:
                                                    the entries live in HBM (24 B each), not in LDS */
+    float mode_density[5];                      /* KB_DRIVE_MIXED: fixture density of the kilobots of drive law k (Kilobot._density 1.0,
+                                                   SimpleVelocityControlKilobot._density 2.0: kilobot.py:25, :214); 0 = bot_density */
     int32_t allow_sleep;                        /* [0] b2World(gravity, doSleep=True) of kilobots_env.py:45: bodies carry
                                                    b2Body::m_sleepTime (kb_buffers.sleep_time / osleep, seconds; < 0: asleep).  An
                                                    island whose bodies all stayed below b2_linearSleepTolerance /
@@ -183,6 +189,8 @@ typedef struct kb_buffers {
     float *sleep_time;                  /* allow_sleep: [num_envs][num_bots] b2Body::m_sleepTime in seconds, < 0 = asleep (required then;
                                            zero-fill = awake) */
     float *osleep;                      /* allow_sleep with objects: the same for the objects, [num_envs][num_objects] */
+    uint8_t *bot_mode;                  /* KB_DRIVE_MIXED: [num_envs][num_bots] drive law of every kilobot (KB_DRIVE_VELOCITY ..
+                                           KB_DRIVE_PHOTOTAXIS; required then) */
 } kb_buffers;
 
 typedef struct kb_sim kb_sim;

@@ -154,6 +154,7 @@ typedef struct {
     float cell, inv_cell; int gw, gh;
     float r_bot, im_bot;            /* world radius, inverse mass */
     float kl_bot, ka_bot;           /* Pade damping factors 1/(1+h c), b2Island.cpp */
+    float im_mode[5];               /* inverse mass of a kilobot by drive law (KBO_DRIVE_MIXED; otherwise all im_bot) */
     float h;
     float r_obj[KBO_MAX_OBJECTS];   /* per fixture: contact radius (circle) / bounding radius about the body's centre of mass */
     float im_obj[KBO_MAX_OBJECTS], ii_obj[KBO_MAX_OBJECTS];   /* per object: inverse mass, inverse inertia about the centre of mass */
@@ -213,6 +214,13 @@ static void derive(const kbo_config *c, derived_t *d) {
     /* b2CircleShape::ComputeMass: mass = density * pi * r^2 */
     float m = c->bot_density * B2_PI * d->r_bot * d->r_bot;
     d->im_bot = m > 0.0f ? 1.0f / m : 0.0f;
+    for (int k = 0; k < 5; ++k) {
+        d->im_mode[k] = d->im_bot;
+        if (c->drive_mode == KBO_DRIVE_MIXED && c->mode_density[k] > 0.0f) {
+            const float mk = c->mode_density[k] * B2_PI * d->r_bot * d->r_bot;
+            d->im_mode[k] = mk > 0.0f ? 1.0f / mk : 0.0f;
+        }
+    }
     /* b2Island::Solve: `v *= 1.0f / (1.0f + h * damping)` since Box2D 2.3.1; `v *= b2Clamp(1.0f - h * damping, 0, 1)` before */
     d->kl_bot = damping_factor(c->damping_model, d->h, c->bot_linear_damping);
     d->ka_bot = damping_factor(c->damping_model, d->h, c->bot_angular_damping);
@@ -787,6 +795,8 @@ static void detect_env(const kbo_config *cfg, const derived_t *d, const kbo_stat
         free(fill);
     }
     const float rr = d->r_bot + d->r_bot, rr2 = rr * rr;
+    /* inverse mass of kilobot b: by its drive law in a mixed env (the classes have different densities, kilobot.py:25 / :214) */
+#define IM_BOT(b_) (cfg->drive_mode == KBO_DRIVE_MIXED ? d->im_mode[st->bot_mode[(size_t)e * N + (b_)] < 5 ? st->bot_mode[(size_t)e * N + (b_)] : 0] : d->im_bot)
     static const int ddx[5] = {0, 1, 0, 1, -1}, ddy[5] = {0, 0, 1, 1, 1};
     static const int dcls[5] = {CLS_SAME, CLS_E, CLS_N, CLS_NE, CLS_NW};
     w->ncon = 0;
@@ -811,7 +821,7 @@ static void detect_env(const kbo_config *cfg, const derived_t *d, const kbo_stat
                 int slot = nslot < S ? nslot : -1;
                 if (slot < 0) w->status |= 2;
                 nslot++;
-                add_contact(w, a, b, cls, w->cell[a], d->im_bot, d->im_bot, d->r_bot, d->r_bot, acc, a, slot);
+                add_contact(w, a, b, cls, w->cell[a], IM_BOT(a), IM_BOT(b), d->r_bot, d->r_bot, acc, a, slot);
             }
         }
         /* walls: b2CollideEdgeAndCircle (region AB), edges of the chain loop kilobots_env.py:48-51:
@@ -826,7 +836,7 @@ static void detect_env(const kbo_config *cfg, const derived_t *d, const kbo_stat
             int slot = nslot < S ? nslot : -1;
             if (slot < 0) w->status |= 2;
             nslot++;
-            add_contact(w, -1 - wl, a, CLS_WALL, a, 0.0f, d->im_bot, B2_POLYGON_RADIUS, d->r_bot, acc, a, slot);
+            add_contact(w, -1 - wl, a, CLS_WALL, a, 0.0f, IM_BOT(a), B2_POLYGON_RADIUS, d->r_bot, acc, a, slot);
         }
         /* pushable objects: b2CollideCircles / b2CollidePolygonAndCircle kilobot - fixture f of object m */
         for (int f = 0; f < d->nfix; ++f) {
@@ -846,7 +856,7 @@ static void detect_env(const kbo_config *cfg, const derived_t *d, const kbo_stat
             if (slot < 0) w->status |= 2;
             nslot++;
             const int before = w->ncon;
-            add_contact(w, a, N + m, CLS_BOT_OBJ, f, d->im_bot, d->im_obj[m], d->r_bot, sh->radius, acc, a, slot);
+            add_contact(w, a, N + m, CLS_BOT_OBJ, f, IM_BOT(a), d->im_obj[m], d->r_bot, sh->radius, acc, a, slot);
             if (w->ncon > before) {
                 contact_t *c = &w->con[w->ncon - 1];
                 c->fix = f;
@@ -1340,7 +1350,8 @@ static void world_step_env(const kbo_config *cfg, const derived_t *d, kbo_state 
 
     /* integrate velocities: no forces; Pade damping (b2Island.cpp: v *= 1/(1 + h*c)) */
     for (int b = 0; b < N; ++b) {
-        float kl = (cfg->drive_mode == KBO_DRIVE_SIMPLE_PHOTOTAXIS) ? 1.0f / (1.0f + h * 0.0f) : d->kl_bot;
+        const int law = cfg->drive_mode == KBO_DRIVE_MIXED ? st->bot_mode[(size_t)e * N + b] : cfg->drive_mode;
+        float kl = (law == KBO_DRIVE_SIMPLE_PHOTOTAXIS) ? 1.0f / (1.0f + h * 0.0f) : d->kl_bot;
         w->vx[b] *= kl; w->vy[b] *= kl; w->bw[b] *= d->ka_bot;
     }
     for (int m = 0; m < w->M; ++m) { w->vx[N + m] *= d->kl_obj; w->vy[N + m] *= d->kl_obj; w->bw[N + m] *= d->ka_obj; }
@@ -1576,7 +1587,8 @@ static void world_step_env(const kbo_config *cfg, const derived_t *d, kbo_state 
         /* (b2World::SolveTOI skips contacts without an awake dynamic body) */
         for (int b = 0; b < N; ++b)
             if (!(sleeping && w->slp[b] < 0.0f))
-                toi_walls_body(cfg, d, d->r_bot, d->im_bot, w->x0[b], w->y0[b], w->a0[b], &w->px[b], &w->py[b],
+                toi_walls_body(cfg, d, d->r_bot, cfg->drive_mode == KBO_DRIVE_MIXED ? d->im_mode[st->bot_mode[(size_t)e * N + b] < 5 ? st->bot_mode[(size_t)e * N + b] : 0] : d->im_bot,
+                               w->x0[b], w->y0[b], w->a0[b], &w->px[b], &w->py[b],
                                &st->theta[(size_t)e * N + b], &w->vx[b], &w->vy[b], &w->bw[b]);
         for (int m = 0; m < w->M; ++m) if (!(sleeping && w->slp[N + m] < 0.0f)) toi_walls_object(cfg, d, st, e, w, m);
     }
@@ -1666,7 +1678,8 @@ int kbo_reset(const kbo_config *cfg, kbo_state *st, const kbo_reset_params *rp) 
             st->theta[i] = th;
             st->ws_cnt[i] = 0;
             if (cfg->allow_sleep && st->sleep_time) st->sleep_time[i] = 0.0f;          /* new bodies are awake (b2BodyDef::awake) */
-            if (cfg->drive_mode == KBO_DRIVE_VELOCITY || cfg->drive_mode == KBO_DRIVE_ACCEL) {
+            const int law = cfg->drive_mode == KBO_DRIVE_MIXED ? st->bot_mode[i] : cfg->drive_mode;
+            if (law == KBO_DRIVE_VELOCITY || law == KBO_DRIVE_ACCEL) {
                 float v = 0.0f, w = 0.0f;
                 if (rp->random_velocity) {                                            /* kilobot.py:225-229 */
                     v = (float)(r[3] & 0xFFFFu) * (1.0f / 65536.0f) * 0.01f;
@@ -1674,9 +1687,9 @@ int kbo_reset(const kbo_config *cfg, kbo_state *st, const kbo_reset_params *rp) 
                 }
                 st->v[i] = v; st->w[i] = w;
             }
-            if (cfg->drive_mode == KBO_DRIVE_ACCEL) { st->acc_v[i] = 0.0f; st->acc_w[i] = 0.0f; }
-            if (cfg->drive_mode == KBO_DRIVE_MOTORS || cfg->drive_mode == KBO_DRIVE_PHOTOTAXIS) { st->motor_l[i] = 255; st->motor_r[i] = 0; }
-            if (cfg->drive_mode == KBO_DRIVE_PHOTOTAXIS) {
+            if (law == KBO_DRIVE_ACCEL) { st->acc_v[i] = 0.0f; st->acc_w[i] = 0.0f; }
+            if (law == KBO_DRIVE_MOTORS || law == KBO_DRIVE_PHOTOTAXIS) { st->motor_l[i] = 255; st->motor_r[i] = 0; }
+            if (law == KBO_DRIVE_PHOTOTAXIS) {
                 st->pt_threshold[i] = -INFINITY; st->pt_update[i] = 0; st->pt_nochange[i] = 0; st->pt_dir[i] = 0;
             }
         }
@@ -1703,12 +1716,13 @@ static void substep_env(const kbo_config *cfg, const derived_t *d, kbo_state *st
         float th = st->theta[o + b];
         float bvx = 0.0f, bvy = 0.0f, bw = 0.0f;
         w->px[b] = st->x[o + b]; w->py[b] = st->y[o + b];
+        const int law = cfg->drive_mode == KBO_DRIVE_MIXED ? st->bot_mode[o + b] : cfg->drive_mode;
         if (!(flags & KBO_STEP_NO_DRIVE)) {
             float lval = 0.0f, lgx = 0.0f, lgy = 0.0f;
             if (cfg->light_type != KBO_LIGHT_NONE) {
                 /* kilobots_env.py:174-180; sensor position kilobot.py:54-55 / :188-189 */
                 float sx = w->px[b], sy = w->py[b];
-                if (cfg->drive_mode != KBO_DRIVE_SIMPLE_PHOTOTAXIS) {
+                if (law != KBO_DRIVE_SIMPLE_PHOTOTAXIS) {
                     float s, c; kbo_sincosf(th, &s, &c);
                     float lx0 = 0.0f, ly0 = -d->r_bot;
                     sx = (c * lx0 - s * ly0) + w->px[b];
@@ -1717,7 +1731,7 @@ static void substep_env(const kbo_config *cfg, const derived_t *d, kbo_state *st
                 light_sense(cfg, st, e, sx / WORLD_SCALE, sy / WORLD_SCALE, &lval, &lgx, &lgy);
                 if (st->light_value) { st->light_value[o + b] = lval; st->light_gx[o + b] = lgx; st->light_gy[o + b] = lgy; }
             }
-            switch (cfg->drive_mode) {
+            switch (law) {
             case KBO_DRIVE_ACCEL: {
                 /* kilobot.py:294-300 */
                 float v = st->v[o + b] + st->acc_v[o + b] * h, ww = st->w[o + b] + st->acc_w[o + b] * h;
@@ -1814,7 +1828,7 @@ int kbo_light_sense(const kbo_config *cfg, kbo_state *st, const float *light_act
         for (int b = 0; b < N; ++b) {
             const float th = st->theta[o + b], px = st->x[o + b], py = st->y[o + b];
             float sx = px, sy = py;
-            if (cfg->drive_mode != KBO_DRIVE_SIMPLE_PHOTOTAXIS) {
+            if ((cfg->drive_mode == KBO_DRIVE_MIXED ? st->bot_mode[o + b] : cfg->drive_mode) != KBO_DRIVE_SIMPLE_PHOTOTAXIS) {
                 float s, c; kbo_sincosf(th, &s, &c);
                 float lx0 = 0.0f, ly0 = -d.r_bot;
                 sx = (c * lx0 - s * ly0) + px;
@@ -1866,6 +1880,7 @@ int kbo_step(const kbo_config *cfg, kbo_state *st, const float *light_action, in
     if (!cfg || !st || cfg->num_bots < 1 || cfg->num_envs < 1 || cfg->num_objects < 0 || cfg->num_objects > KBO_MAX_OBJECTS) return -1;
     if (cfg->num_objects > 0 && (!st->ox || !st->oy || !st->otheta || !st->ovx || !st->ovy || !st->ow || !st->ows_acc)) return -1;
     if (cfg->allow_sleep && (!st->sleep_time || (cfg->num_objects > 0 && !st->osleep))) return -1;
+    if (cfg->drive_mode == KBO_DRIVE_MIXED && !st->bot_mode) return -1;
     derived_t d; derive(cfg, &d);
     int nt = num_threads > 1 ? num_threads : 1;
     int err = 0;
@@ -1900,16 +1915,17 @@ int kbo_set_actions(const kbo_config *cfg, kbo_state *st, const float *actions) 
     const float mw = 0.5f * 3.14159265358979323846f;
     for (size_t i = 0; i < T; ++i) {
         float a0 = actions ? actions[2 * i] : 0.0f, a1 = actions ? actions[2 * i + 1] : 0.0f;
-        if (cfg->drive_mode == KBO_DRIVE_VELOCITY) {
+        const int law = cfg->drive_mode == KBO_DRIVE_MIXED ? st->bot_mode[i] : cfg->drive_mode;
+        if (law == KBO_DRIVE_VELOCITY) {
             /* kilobot.py:216-218, 235-241 */
             st->v[i] = fmaxf(fminf(a0, 0.01f), 0.0f);
             st->w[i] = fmaxf(fminf(a1, mw), -mw);
-        } else if (cfg->drive_mode == KBO_DRIVE_ACCEL) {
+        } else if (law == KBO_DRIVE_ACCEL) {
             /* kilobot.py:269, 283-289 */
             const float aw = 0.2f * 3.14159265358979323846f;
             st->acc_v[i] = fmaxf(fminf(a0, 0.005f), -0.005f);
             st->acc_w[i] = fmaxf(fminf(a1, aw), -aw);
-        } else return -1;
+        } else if (cfg->drive_mode != KBO_DRIVE_MIXED) return -1;      /* (mixed env: kilobots of the other laws take no action) */
     }
     return 0;
 }

@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, 'libkb_oracle.so')
 
-DRIVE_VELOCITY, DRIVE_ACCEL, DRIVE_MOTORS, DRIVE_SIMPLE_PHOTOTAXIS, DRIVE_PHOTOTAXIS = range(5)
+DRIVE_VELOCITY, DRIVE_ACCEL, DRIVE_MOTORS, DRIVE_SIMPLE_PHOTOTAXIS, DRIVE_PHOTOTAXIS, DRIVE_MIXED = range(6)
 LIGHT_NONE, LIGHT_CIRCULAR, LIGHT_GRADIENT, LIGHT_MOMENTUM, LIGHT_COMPOSITE = range(5)
 MAX_LIGHTS = 4
 STEP_NO_DRIVE = 1
@@ -50,6 +50,7 @@ class Config(C.Structure):
         ('wall_friction', C.c_float),
         ('num_fixtures', C.c_int32), ('obj_fixture_body', C.c_int32 * MAX_OBJECTS),
         ('damping_model', C.c_int32), ('sense_radius', C.c_float), ('contact_capacity', C.c_int32),
+        ('mode_density', C.c_float * 5),
         ('allow_sleep', C.c_int32),
     ]
 
@@ -79,6 +80,7 @@ class State(C.Structure):
         ('ows_acc', _PF),
         ('nbr_count', _PU32),
         ('sleep_time', _PF), ('osleep', _PF),
+        ('bot_mode', _PU8),
     ]
 
 
@@ -211,6 +213,7 @@ class OracleSim:
         self.ows_acc = np.full((E, MAX_OBJECTS, OWS_COLS, OWS_WORDS), -1.0, np.float32)
         self.nbr_count = np.zeros((E, N), np.uint32)
         self.sleep_time, self.osleep = f(E, N), f(E, M)       # b2Body::m_sleepTime (< 0: asleep)
+        self.bot_mode = np.full((E, N), DRIVE_MOTORS, np.uint8)       # DRIVE_MIXED: per-kilobot drive law
         self._st = State()
         for name, _t in State._fields_:
             arr = getattr(self, name, None)

@@ -17,11 +17,13 @@ class OracleBackend:
         for name in ('x', 'y', 'theta', 'v', 'w', 'acc_v', 'acc_w', 'motor_l', 'motor_r', 'pt_threshold',
                      'pt_update', 'pt_nochange', 'pt_dir', 'light_x', 'light_y', 'light_vx', 'light_vy', 'ws_cnt', 'status',
                      'light_value', 'light_gx', 'light_gy', 'cmd_vx', 'cmd_vy', 'cmd_w',
-                     'ox', 'oy', 'otheta', 'ovx', 'ovy', 'ow', 'nbr_count', 'sleep_time', 'osleep'):
+                     'ox', 'oy', 'otheta', 'ovx', 'ovy', 'ow', 'nbr_count', 'sleep_time', 'osleep', 'bot_mode'):
             arr = getattr(self.o, name)
             setattr(self, name, torch.from_numpy(arr.view(np.int32) if arr.dtype == np.uint32 else arr))     # shares memory
-        if drive_mode not in (O.DRIVE_MOTORS, O.DRIVE_PHOTOTAXIS):
+        if drive_mode not in (O.DRIVE_MOTORS, O.DRIVE_PHOTOTAXIS, O.DRIVE_MIXED):
             self.motor_l = self.motor_r = None
+        if drive_mode != O.DRIVE_MIXED:
+            self.bot_mode = None
         if not self.cfg.sense_radius > 0.0:
             self.nbr_count = None
         if not self.cfg.allow_sleep:

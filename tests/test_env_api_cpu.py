@@ -238,8 +238,11 @@ def test_unsupported_scenes_fail_loudly():
         def get_reward(self, *a):
             return 0.
 
-    with pytest.raises(ValueError):
-        MixedEnv(sim_factory=OracleBackend).reset()
+    # (kilobots of different classes in one env run since round 2: KB_DRIVE_MIXED, tests/test_mixed_laws.py)
+    env = MixedEnv(sim_factory=OracleBackend)
+    env.reset()
+    assert env.sim.drive_mode == 5 and env.sim.bot_mode.tolist() == [[4, 3]]
+    env.step(np.array([0.005, 0.0]))
 
     class OddLightEnv(KilobotsEnv):
         def _configure_environment(self):

@@ -72,6 +72,12 @@ def test_random_scene(seed):
     sleeping = rng2.random() < 0.4
     if sleeping:
         kw.update(allow_sleep=1)
+    # mixed drive laws (KB_DRIVE_MIXED, up to 128 kilobots): in a quarter of the small scenes, every kilobot its own law and the
+    # classes' densities (drawn after everything else from the second stream)
+    mixed = N <= 128 and rng2.random() < 0.25
+    if mixed:
+        mode = O.DRIVE_MIXED
+        kw.update(mode_density=[2.0, 2.0, 1.0, 1.0, 1.0])
     sx, sy = W / 2.0, H / 1.5
     with_objects = rng.random() < 0.6
     nobj = 0
@@ -97,6 +103,15 @@ def test_random_scene(seed):
         lx = (rng.uniform(-0.5, 0.5, osim.light_x.shape) * min(sx, sy)).astype(np.float32)
         osim.light_x[...] = lx
         gsim.light_x.copy_(dev(lx))
+    if mixed:
+        laws = rng2.integers(0, 5, (E, N)).astype(np.uint8)
+        osim.bot_mode[...] = laws
+        gsim.bot_mode.copy_(dev(laws))
+        ml, mr = rng2.integers(0, 256, (E, N)).astype(np.uint8), rng2.integers(0, 256, (E, N)).astype(np.uint8)
+        ml[rng2.random((E, N)) < 0.3] = 0
+        for name, v in (('motor_l', ml), ('motor_r', mr)):
+            getattr(osim, name)[...] = v
+            getattr(gsim, name).copy_(dev(v))
     fields = ('x', 'y', 'theta') + (OBJ_FIELDS[3:] if nobj else ())
     if sleeping:
         fields += ('sleep_time',) + (('osleep',) if nobj else ())
@@ -110,7 +125,7 @@ def test_random_scene(seed):
     for k in range(12):
         la = None if la_dim == 0 or k % 3 == 2 else rng.uniform(-0.02, 0.02, (E, la_dim)).astype(np.float32)
         n_sub = int(rng.choice([1, 1, 3, 10]))
-        if mode in (O.DRIVE_VELOCITY, O.DRIVE_ACCEL):
+        if mode in (O.DRIVE_VELOCITY, O.DRIVE_ACCEL, O.DRIVE_MIXED):
             a = scenes.random_actions(E, N, seed=5000 + 31 * seed + k)
             if sleeping:      # resting phases: everybody for a few steps, then a random half
                 if k % 6 in (1, 2, 3):
