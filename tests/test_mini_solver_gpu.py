@@ -24,8 +24,15 @@ def _sim_for(sc):
                   obj_radius=[(o['r'] / 25.0) if o['shape'] == 'circle' else 0.0 for o in objs] + [0.075] * pad,
                   obj_verts=[[[0.0, 0.0]] if o['shape'] == 'circle' else [[o['hx'], o['hy']]] for o in objs] + [[[0.0, 0.0]]] * pad)
     kb = np.array(sc['kilobots'], np.float64)
-    g = KilobotSim(1, len(kb), **kw)
+    mixed = kb.shape[1] > 5
+    if mixed:
+        kw.update(mode_density=[2.0, 2.0, 1.0, 1.0, 1.0])
+    g = KilobotSim(1, len(kb), O.DRIVE_MIXED if mixed else O.DRIVE_VELOCITY, **kw)
     dev = g.x.device
+    if mixed:
+        g.bot_mode.copy_(torch.tensor(np.where(kb[None, :, 5] == 2.0, O.DRIVE_VELOCITY, O.DRIVE_MOTORS), dtype=torch.uint8, device=dev))
+        g.motor_l.zero_()
+        g.motor_r.zero_()
     g.x.copy_(torch.tensor(kb[None, :, 0], dtype=torch.float32, device=dev))
     g.y.copy_(torch.tensor(kb[None, :, 1], dtype=torch.float32, device=dev))
     g.theta.copy_(torch.tensor(kb[None, :, 2], dtype=torch.float32, device=dev))

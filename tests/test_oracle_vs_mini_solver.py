@@ -33,8 +33,15 @@ def _oracle_for(sc):
                   obj_radius=[(o['r'] / 25.0) if o['shape'] == 'circle' else 0.0 for o in objs] + [0.075] * pad,
                   obj_verts=[[[0.0, 0.0]] if o['shape'] == 'circle' else [[o['hx'], o['hy']]] for o in objs] + [[[0.0, 0.0]]] * pad)
     N = len(sc['kilobots'])
-    o = O.OracleSim(O.default_config(1, N, **kw))
     kb = np.array(sc['kilobots'], np.float64)
+    mixed = kb.shape[1] > 5                      # a density column: kilobots of different classes (KB_DRIVE_MIXED)
+    if mixed:
+        kw.update(mode_density=[2.0, 2.0, 1.0, 1.0, 1.0])
+    o = O.OracleSim(O.default_config(1, N, O.DRIVE_MIXED if mixed else O.DRIVE_VELOCITY, **kw))
+    if mixed:                                    # density 2: velocity control; density 1: the motor law with both motors off
+        o.bot_mode[0] = np.where(kb[:, 5] == 2.0, O.DRIVE_VELOCITY, O.DRIVE_MOTORS)
+        o.motor_l[...] = 0
+        o.motor_r[...] = 0
     o.x[0], o.y[0], o.theta[0] = kb[:, 0].astype(np.float32), kb[:, 1].astype(np.float32), kb[:, 2].astype(np.float32)
     o.set_actions(kb[None, :, 3:5].astype(np.float32))
     for m, ob in enumerate(objs):

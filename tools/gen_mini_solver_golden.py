@@ -66,6 +66,11 @@ SCENES = {
                                            commands=[[8, [[0.0, 0.0], [0.01, 0.0]]]]),
     'disc_coasts_to_sleep': dict(kilobots=[[20.0, 15.0, 0.0, 0.0, 0.0]], objects=[dict(shape='circle', r=1.5, x=0.0, y=0.0, theta=0.0, vx=0.6, vy=0.2, w=0.3)],
                                  steps=70, tol=5e-5, sleep=True, contact_free=True),
+    # kilobots of different classes: fixture density 2 (SimpleVelocityControlKilobot, kilobot.py:214) against density 1 (Kilobot,
+    # :25): a sixth column gives the density; the light one is commanded (0, 0) like a kilobot with both motors off
+    'heavy_pushes_light': dict(kilobots=[[-0.6, 0.0, 0.0, 0.01, 0.0, 2.0], [0.45, 0.03, 0.0, 0.0, 0.0, 1.0]], objects=[], steps=50, tol=2e-5),
+    'heavy_light_heavy_chain': dict(kilobots=[[-0.9, 0.0, 0.0, 0.01, 0.0, 2.0], [-0.05, 0.03, 0.0, 0.0, 0.0, 1.0], [0.8, -0.02, 0.0, 0.0, 0.0, 2.0]],
+                                    objects=[], steps=60, tol=2e-3),
     'two_bots_push_box': dict(kilobots=[[-2.9, 0.9, 0.0, 0.01, 0.0], [-2.9, -0.8, 0.0, 0.01, 0.0]],
                               objects=[dict(shape='box', hx=1.875, hy=1.875, x=0.0, y=0.0, theta=0.0, vx=0, vy=0, w=0)], steps=60, tol=2e-3),
 }
@@ -78,9 +83,10 @@ def run(scene, damping='pade', dt=0.1, vel_iters=10, pos_iters=10):
     for a, b in (((x0, y1), (x0, y0)), ((x0, y0), (x1, y0)), ((x1, y0), (x1, y1)), ((x1, y1), (x0, y1))):   # kilobots_env.py:48-51
         table.create_fixture(B.Edge(a, b), density=0.0, friction=0.2)
     bots, objs = [], []
-    for x, y, th, v, om in scene['kilobots']:
+    for kb in scene['kilobots']:
+        x, y, th, v, om = kb[:5]
         b = w.create_body(position=(x, y), angle=th, linear_damping=0.8, angular_damping=0.8)
-        b.create_fixture(B.Circle(R_BOT), density=2.0, friction=0.0, restitution=0.0)
+        b.create_fixture(B.Circle(R_BOT), density=kb[5] if len(kb) > 5 else 2.0, friction=0.0, restitution=0.0)
         bots.append([b, np.float32(v), np.float32(om)])
     for o in scene['objects']:
         b = w.create_body(position=(o['x'], o['y']), angle=o['theta'], linear_damping=0.8, angular_damping=0.8)
