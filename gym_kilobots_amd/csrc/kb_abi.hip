@@ -312,8 +312,6 @@ int kb_create(const kb_config *cfg, kb_sim **out) {
         return fail(KB_EINVAL, "kb_create: friction coefficients must be non-negative");
     if (cfg->num_objects > 0 && !(cfg->obj_density > 0.0f)) return fail(KB_EINVAL, "kb_create: obj_density must be positive");
     if (cfg->drive_mode < 0 || cfg->drive_mode > KB_DRIVE_MIXED) return fail(KB_EINVAL, "kb_create: bad drive_mode");
-    if (cfg->drive_mode == KB_DRIVE_MIXED && cfg->num_bots > kb::BPT * 64)
-        return fail(KB_EINVAL, "kb_create: KB_DRIVE_MIXED runs as one-wave workgroups: num_bots <= 128");
     if (cfg->light_type < KB_LIGHT_NONE || cfg->light_type > KB_LIGHT_COMPOSITE)
         return fail(KB_EINVAL, "kb_create: unsupported light_type");
     if (cfg->light_type == KB_LIGHT_COMPOSITE) {
@@ -516,7 +514,7 @@ int kb_create(const kb_config *cfg, kb_sim **out) {
         // with objects, up to 128 kilobots run as one wave: that selects the spill-free 256-VGPR instantiation
         // (kb_step), measured + 6 ... 9 % at 100 kilobots and - 3 % at 128 against two-wave workgroups
         if (p.M > 0 && p.N <= BPT * 64) T = 64;
-        if (p.drive_mode == KB_DRIVE_MIXED) T = 64;       // (num_bots <= 128 checked above)
+        if (p.drive_mode == KB_DRIVE_MIXED) T = p.N <= BPT * 64 ? 64 : 64 * MAX_WAVES;       // the two spill-free instantiations (256 VGPRs)
         s->threads = T;
     }
     {   // trade a few staging entries for one more env per CU when the LDS footprint is just above a divisor of 160 KiB
@@ -613,7 +611,8 @@ static kb_step_fn select_kernel(const kb_sim *sim, const kb::Params &p) {
     case KB_DRIVE_MOTORS: return kb_pick_motors(p.light_type, objsel);
     case KB_DRIVE_SIMPLE_PHOTOTAXIS: return kb_pick_simple_phototaxis(p.light_type, objsel);
     case KB_DRIVE_PHOTOTAXIS: return kb_pick_phototaxis(p.light_type, objsel);
-    case KB_DRIVE_MIXED: return sim->threads == 64 ? kb_pick_mixed(p.light_type, p.allow_sleep) : nullptr;
+    case KB_DRIVE_MIXED: return sim->threads == 64 ? kb_pick_mixed(p.light_type, p.allow_sleep)
+                                                   : (sim->threads == 64 * MAX_WAVES ? kb_pick_mixed_large(p.light_type, p.allow_sleep) : nullptr);
     default: return nullptr;
     }
 }
@@ -730,7 +729,8 @@ int kb_set_block_threads(kb_sim *sim, int threads) {
     const int capL = (sim->p.M == 0 && uses_fixed_1024(sim->p, threads)) ? ldsc::CAPL : sim->capL_regular;
     const int need = lds_bytes_for(sim->p, threads, capL);
     if (need > 160 * 1024) return fail(KB_ELDS, "kb_set_block_threads: more than 160 KiB of LDS per env at this workgroup size");
-    if (sim->p.drive_mode == KB_DRIVE_MIXED && threads != 64) return fail(KB_EINVAL, "kb_set_block_threads: KB_DRIVE_MIXED runs as one-wave workgroups");
+    if (sim->p.drive_mode == KB_DRIVE_MIXED && threads != 64 && threads != 64 * MAX_WAVES)
+        return fail(KB_EINVAL, "kb_set_block_threads: KB_DRIVE_MIXED runs as one-wave or full workgroups");
     sim->threads = threads;
     sim->p.capL = capL;
     sim->p.lds_total = need;

@@ -636,5 +636,6 @@ kb_step_fn kb_pick_simple_phototaxis_discs(int light_type, int objects);   // ob
 kb_step_fn kb_pick_phototaxis(int light_type, int objects);
 kb_step_fn kb_pick_phototaxis_discs(int light_type, int objects);   // objects: 0 none, 1 yes, 2 yes + one-wave workgroup
 kb_step_fn kb_pick_mixed(int light_type, int sleep);                // KB_DRIVE_MIXED: one-wave workgroups (kb_inst_d5.hip)
+kb_step_fn kb_pick_mixed_large(int light_type, int sleep);          // ... beyond 128 kilobots: the full workgroup at 256 VGPRs (kb_inst_d5w.hip)
 
 }  // namespace kb

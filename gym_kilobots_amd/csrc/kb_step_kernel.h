@@ -22,14 +22,15 @@ namespace kb {
 // Kernels without objects use the compact LDS image (namespace ldsc).  TIER picks the register budget:
 //   0: 128 VGPRs (launch bounds of 4 waves per SIMD);
 //   1: "WIDE", one-wave workgroups in scenes with objects: 256 VGPRs (2 waves per SIMD), no spills;
-//   2: 80 VGPRs (6 waves per SIMD): three 8-wave / six 4-wave workgroups per CU where the LDS image admits them.
+//   2: 80 VGPRs (6 waves per SIMD): three 8-wave / six 4-wave workgroups per CU where the LDS image admits them;
+//   3: 256 VGPRs for the full workgroup (2 waves per SIMD = one 8-wave workgroup per CU), no spills: mixed drive laws beyond 128 kilobots.
 // The fixed-size kernel without objects is always tier 2.
 // SLEEP = true: b2World(doSleep=True) of kilobots_env.py:45 -- bodies carry b2Body::m_sleepTime, islands without an awake
 // body are not solved (b2World::Solve), islands at rest for b2_timeToSleep whose position constraints converged fall asleep
 // (b2Island::Solve).  Generic kernels and the fixed-size one without objects; kb_step picks it when kb_config.allow_sleep != 0.
 template <int DRIVE_MODE, int LIGHT_TYPE, bool OBJ, int FN = 0, int TIER = 0, bool POLY = true, bool SENSE = true, bool SLEEP = false>
-__global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, TIER == 1 ? 2 : ((TIER == 2 || (FN != 0 && !OBJ)) ? KB_COMPACT_WAVES_PER_SIMD : KB_MIN_WAVES_PER_SIMD)) kb_step_kernel(const Params p) {
-    constexpr bool WIDE = TIER == 1;
+__global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1 || TIER == 3) ? 2 : ((TIER == 2 || (FN != 0 && !OBJ)) ? KB_COMPACT_WAVES_PER_SIMD : KB_MIN_WAVES_PER_SIMD)) kb_step_kernel(const Params p) {
+    constexpr bool WIDE = TIER == 1 || TIER == 3;       // (256 VGPRs: no register spills)
     constexpr bool COMPACT = !OBJ;
     static_assert(!SLEEP || FN == 0 || !OBJ, "the fixed-size instantiations with objects do not carry the sleep state");
     constexpr bool FOLD = FN != 0 && !OBJ;       // lCbk over nextb (needs capL <= NP)

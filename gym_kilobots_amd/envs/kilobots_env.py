@@ -260,8 +260,6 @@ class KilobotsEnv(object):
         mixed = len(kinds) > 1
         mode_density = [0.0] * 5
         if mixed:
-            if len(kbs) > 128:
-                raise ValueError('an env that mixes drive laws holds at most 128 kilobots (one-wave workgroups of the device step)')
             for law in kinds:
                 dens = {float(type(k)._density) for k in kbs if type(k).drive_mode == law}
                 if len(dens) != 1:

@@ -52,7 +52,8 @@ enum kb_drive_mode {
     KB_DRIVE_MIXED = 5              /* any mix of the five in one env (KilobotsEnv.step steps whatever is in _kilobots,
                                        kilobots_env.py:183-184): the law of every kilobot comes from kb_buffers.bot_mode, the
                                        fixture density of its class from kb_config.mode_density; every per-law state buffer is
-                                       required; num_bots <= 128 (one-wave workgroups, the spill-free instantiation) */
+                                       required; spill-free 256-VGPR instantiations: one-wave workgroups up to 128 kilobots,
+                                       the full workgroup (one env per CU) beyond */
 };
 
 enum kb_light_type {

@@ -72,9 +72,9 @@ def test_random_scene(seed):
     sleeping = rng2.random() < 0.4
     if sleeping:
         kw.update(allow_sleep=1)
-    # mixed drive laws (KB_DRIVE_MIXED, up to 128 kilobots): in a quarter of the small scenes, every kilobot its own law and the
+    # mixed drive laws (KB_DRIVE_MIXED): in a quarter of the scenes, every kilobot its own law and the
     # classes' densities (drawn after everything else from the second stream)
-    mixed = N <= 128 and rng2.random() < 0.25
+    mixed = rng2.random() < 0.25
     if mixed:
         mode = O.DRIVE_MIXED
         kw.update(mode_density=[2.0, 2.0, 1.0, 1.0, 1.0])
