@@ -75,7 +75,7 @@ class KbBuffers(C.Structure):
     _fields_ = [(n, _P) for n in BUFFER_FIELDS]
 
 
-EXPORTS = ['kb_create', 'kb_destroy', 'kb_bind', 'kb_set_actions', 'kb_step', 'kb_get_poses', 'kb_sense', 'kb_light_sense', 'kb_reset',
+EXPORTS = ['kb_create', 'kb_destroy', 'kb_bind', 'kb_set_actions', 'kb_step', 'kb_get_poses', 'kb_get_state', 'kb_sense', 'kb_light_sense', 'kb_reset',
            'kb_lds_bytes', 'kb_resident_envs_per_cu', 'kb_contact_capacity', 'kb_lds_staging_entries', 'kb_scratch_bytes', 'kb_light_action_dim', 'kb_light_count', 'kb_block_threads', 'kb_set_block_threads',
            'kb_last_error', 'kb_version']
 
@@ -124,6 +124,8 @@ def load():
     lib.kb_step.restype = C.c_int
     lib.kb_get_poses.argtypes = [_P, _P, _P]
     lib.kb_get_poses.restype = C.c_int
+    lib.kb_get_state.argtypes = [_P, _P, _P]
+    lib.kb_get_state.restype = C.c_int
     lib.kb_sense.argtypes = [_P, C.c_float, _P, _P]
     lib.kb_sense.restype = C.c_int
     lib.kb_light_sense.argtypes = [_P, _P, _P]

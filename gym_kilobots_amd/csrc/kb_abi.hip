@@ -61,6 +61,29 @@ __global__ void kb_get_poses_kernel(const float *x, const float *y, const float 
     out[3 * i + 2] = th[i];
 }
 
+// KilobotsEnv.get_state() in one read (kilobots_env.py:115-118): per env 3 N kilobot words, 3 M object words, the status word
+__global__ void kb_get_state_kernel(const Params p, float *out) {
+    const int per = p.N + p.M + 1;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)p.E * per) return;
+    const size_t e = i / per;
+    const int k = (int)(i - e * per);
+    float *row = out + e * (size_t)(3 * per - 2);
+    if (k < p.N) {
+        const size_t j = e * p.N + k;
+        row[3 * k + 0] = p.buf.x[j] / WORLD_SCALE;
+        row[3 * k + 1] = p.buf.y[j] / WORLD_SCALE;
+        row[3 * k + 2] = p.buf.theta[j];
+    } else if (k < p.N + p.M) {
+        const size_t j = e * p.M + (k - p.N);
+        row[3 * k + 0] = p.buf.ox[j] / WORLD_SCALE;
+        row[3 * k + 1] = p.buf.oy[j] / WORLD_SCALE;
+        row[3 * k + 2] = p.buf.otheta[j];
+    } else {
+        row[3 * k] = __int_as_float(p.buf.status[e]);
+    }
+}
+
 
 // IR-range neighbour sensing on the current poses (kb_sense): one workgroup per env builds the cell lists of the
 // broadphase grid in LDS and runs the sensing pass of the step kernel on them
@@ -713,6 +736,16 @@ int kb_get_poses(kb_sim *sim, float *d_out, void *stream) {
                        sim->p.buf.x, sim->p.buf.y, sim->p.buf.theta, d_out, T);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return fail(KB_EHIP, "kb_get_poses: %s", hipGetErrorString(err));
+    return KB_OK;
+}
+
+int kb_get_state(kb_sim *sim, float *d_out, void *stream) {
+    if (!sim || !d_out) return fail(KB_EINVAL, "kb_get_state: NULL argument");
+    if (!sim->bound) return fail(KB_ENOTBOUND, "kb_get_state: kb_bind() first");
+    const size_t T = (size_t)sim->p.E * (size_t)(sim->p.N + sim->p.M + 1);
+    hipLaunchKernelGGL(kb_get_state_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sim->p, d_out);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return fail(KB_EHIP, "kb_get_state: %s", hipGetErrorString(err));
     return KB_OK;
 }
 

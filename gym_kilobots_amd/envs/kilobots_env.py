@@ -85,6 +85,7 @@ class KilobotsEnv(object):
         self._objects = []
         self._light = None
         self._state_cache = None     # (world.version, state dict) of the last device read
+        self._status_seen = None     # (world.version, status words) of the last device read
         self._screen = None
         self.render_mode = 'human'
         self.video_path = None
@@ -160,8 +161,10 @@ class KilobotsEnv(object):
         return {k: (None if v is None else v.copy()) for k, v in state.items()}
 
     def _read_state(self):
-        poses = self._sim.poses()            # one kernel + one copy instead of 3N SWIG reads
-        kb = (poses[0] if self.num_envs == 1 else poses).cpu().numpy().astype(np.float64)
+        # one kernel + ONE copy instead of 3 (N + M) SWIG reads: kilobots, objects and the status word (kb_get_state)
+        poses, oposes, status = self._sim.host_state()
+        self._status_seen = (self.world.version, status)
+        kb = (poses[0] if self.num_envs == 1 else poses).astype(np.float64)
         if self._sim.drive_mode == nat.DRIVE_ACCEL:
             vw = torch.stack([self._sim.v, self._sim.w], -1).cpu().numpy().astype(np.float64)
             kb = np.concatenate([kb, vw[0] if self.num_envs == 1 else vw], -1)
@@ -182,8 +185,7 @@ class KilobotsEnv(object):
                 light = torch.stack(cols, -1).double().cpu().numpy()
         objs = np.array([])
         if self._objects:
-            op = self._sim.object_poses().cpu().numpy().astype(np.float64)
-            objs = op[0] if self.num_envs == 1 else op
+            objs = (oposes[0] if self.num_envs == 1 else oposes).astype(np.float64)
         return {'kilobots': kb, 'objects': objs, 'light': light}
 
     def get_observation(self):
@@ -396,9 +398,13 @@ class KilobotsEnv(object):
         """Capacity overflows of the device step are never silent: raise / warn with the decoded bits."""
         if self._on_status == 'ignore' or self._sim is None:
             return
-        bits = self._sim.status_bits()
+        if self._status_seen is not None and self._status_seen[0] == self.world.version:       # came with the state read
+            bits = int(np.bitwise_or.reduce(self._status_seen[1], initial=0)) & sum(nat.STATUS_BITS)
+        else:
+            bits = self._sim.status_bits()
         if not bits:
             return
+        self._status_seen = None
         msg = '%s: device step status 0x%x: %s' % (where, bits, nat.describe_status(bits))
         if self._on_status == 'raise':
             raise nat.KilobotsStatusError(msg)

@@ -70,6 +70,7 @@ class KilobotSim:
         self.ws_cnt = torch.zeros(E, N, dtype=torch.uint8, device=dev)
         self.scratch = torch.empty(self._lib.kb_scratch_bytes(self._h), dtype=torch.uint8, device=dev)
         self.status = torch.zeros(E, dtype=torch.int32, device=dev)
+        self._status_mask = None
         self.num_objects = M = self.cfg.num_objects
         self.ox = self.oy = self.otheta = self.ovx = self.ovy = self.ow = self.ows_acc = None
         if M > 0:
@@ -191,10 +192,27 @@ class KilobotSim:
             nat.check(self._lib.kb_get_poses(self._h, C.c_void_p(out.data_ptr()), self._stream()), 'kb_get_poses')
         return out
 
+    def host_state(self):
+        """(kilobot poses [num_envs, num_bots, 3], object poses [num_envs, num_objects, 3], status [num_envs]) as numpy
+        arrays, metres / radians: one launch and ONE copy to the host (kb_get_state), for get_state() after every step."""
+        N, M = self.num_bots, self.num_objects
+        out = torch.empty(self.num_envs, 3 * (N + M) + 1, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.kb_get_state(self._h, C.c_void_p(out.data_ptr()), self._stream()), 'kb_get_state')
+        h = out.cpu().numpy()
+        E = self.num_envs
+        return (h[:, :3 * N].reshape(E, N, 3), h[:, 3 * N:3 * (N + M)].reshape(E, M, 3),
+                np.ascontiguousarray(h[:, -1]).view(np.int32))
+
     def status_bits(self):
         """OR of the status flags of all envs (one device read; synchronises the stream)."""
         s = self.status
-        return int(sum(b for b in STATUS_BITS if bool((s & b).any().item())))
+        if s.numel() <= (1 << 16):           # one small copy; OR on the host (4 reductions + 4 syncs cost 0.1 ms per env.step)
+            return int(np.bitwise_or.reduce(s.cpu().numpy(), initial=0)) & sum(STATUS_BITS)
+        if self._status_mask is None:
+            self._status_mask = torch.tensor(sorted(STATUS_BITS), dtype=torch.int32, device=s.device)
+        hit = (s.unsqueeze(-1) & self._status_mask).ne(0).any(0).cpu().numpy()
+        return int(sum(b for b, h in zip(sorted(STATUS_BITS), hit) if h))
 
     def check_status(self, mode='raise', where=''):
         """Surface capacity overflows of the device step: mode 'raise' | 'warn' | 'ignore'.  Returns the bits."""

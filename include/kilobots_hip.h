@@ -257,6 +257,12 @@ int kb_reset(kb_sim *sim, const kb_reset_params *rp, void *stream);
  * d_out [num_envs][num_bots][3] = (x [m], y [m], theta). */
 int kb_get_poses(kb_sim *sim, float *d_out, void *stream);
 
+/* The whole of KilobotsEnv.get_state() of the kilobots and objects (kilobots_env.py:115-118 -> body.py:63-72) and the
+ * status word in ONE buffer, for hosts that read the state back after every step (one copy instead of three):
+ * d_out [num_envs][3 num_bots + 3 num_objects + 1] float32 = per env the kilobots' (x [m], y [m], theta), the objects'
+ * (x [m], y [m], theta), then the bit pattern of the env's int32 kb_buffers.status word. */
+int kb_get_state(kb_sim *sim, float *d_out, void *stream);
+
 /* Introspection */
 int kb_lds_bytes(const kb_sim *sim);            /* dynamic LDS per workgroup (one env per workgroup) */
 int kb_light_action_dim(const kb_sim *sim);     /* floats per env in d_light_action */

@@ -43,6 +43,11 @@ class OracleBackend:
     def status_bits(self):
         return int(np.bitwise_or.reduce(self.o.status)) if self.o.status.size else 0
 
+    def host_state(self):
+        M = self.cfg.num_objects
+        objs = self.o.objects_m().astype(np.float32) if M else np.zeros((self.num_envs, 0, 3), np.float32)
+        return self.o.poses_m().astype(np.float32), objs, self.o.status.view(np.int32).copy()
+
     def set_poses_m(self, xy, th):
         self.o.set_poses_m(xy, th)
 

@@ -264,3 +264,45 @@ def test_three_envs_of_1024_kilobots_resident_per_cu():
         for f in ('x', 'y', 'theta'):
             assert torch.equal(getattr(g, f), getattr(big, f)), (k, f)
     assert int(g.status.max().item()) == 0
+
+
+def test_status_bits_is_the_or_over_envs_in_one_read():
+    """KilobotSim.status_bits: the small-batch path (one copy, OR on the host) and the large-batch path (masked reduction
+    on the device) name the same bits; bits outside kb_status are not reported."""
+    from gym_kilobots_amd.sim import KilobotSim
+    from gym_kilobots_amd import _native as nat
+    small = KilobotSim(8, 16)
+    assert small.status_bits() == 0
+    small.status[3] = 2
+    small.status[6] = 8 | 1
+    assert small.status_bits() == 11
+    small.status[0] = 64                      # not a kb_status flag
+    assert small.status_bits() == 11
+    with pytest.raises(nat.KilobotsStatusError, match='warm-start slot overflow'):
+        small.check_status('raise')
+    big = KilobotSim((1 << 16) + 8, 4)
+    assert big.status_bits() == 0
+    big.status[70000 - 4500] = 4
+    big.status[5] = 1
+    assert big.status_bits() == 5
+
+
+def test_host_state_is_poses_objects_and_status_in_one_copy():
+    """kb_get_state: the packed read-back equals kb_get_poses, the object views divided by 25 and kb_buffers.status, bit for bit."""
+    from gym_kilobots_amd.sim import KilobotSim
+    gsim = KilobotSim(5, 48, num_objects=2, obj_radius=[0.06, 0.09] + [0.075] * 6)
+    gsim.reset(seed=11, std=0.2)
+    gsim.set_objects_m(np.tile(np.array([[0.5, 0.3], [-0.4, -0.2]], np.float32), (5, 1, 1)), theta=np.tile(np.array([0.2, 1.0], np.float32), (5, 1)))
+    a = np.random.RandomState(2).uniform([0.0, -1.0], [0.01, 1.0], (5, 48, 2)).astype(np.float32)
+    gsim.set_actions(dev(a))
+    gsim.step(7)
+    gsim.status[3] = 9
+    kb, objs, status = gsim.host_state()
+    assert kb.shape == (5, 48, 3) and objs.shape == (5, 2, 3) and status.dtype == np.int32
+    assert np.array_equal(kb, cpu(gsim.poses()))
+    assert np.array_equal(objs, cpu(gsim.object_poses()))
+    assert np.array_equal(status, [0, 0, 0, 9, 0])
+    plain = KilobotSim(3, 20)
+    plain.reset(seed=1, std=0.2)
+    kb, objs, status = plain.host_state()
+    assert objs.shape == (3, 0, 3) and np.array_equal(kb, cpu(plain.poses())) and not status.any()

@@ -20,14 +20,23 @@ class Env(DirectControlKilobotsEnv):
         return 0.
 
 
-env = Env()
-env.reset()
-a = np.tile(np.array([[0.01, 0.2]]), (N, 1))
-for _ in range(20):
-    env.step(a)
-t0 = time.perf_counter()
-K = 300
-for _ in range(K):
-    obs, r, d, info = env.step(a)
-dt = (time.perf_counter() - t0) / K
-print('KilobotsEnv.step with %d kilobots + 1 box: %.3f ms per env.step (10 substeps), %.0f env.steps/s' % (N, dt * 1e3, 1.0 / dt))
+for sleep in (True, False):
+    env = Env(allow_sleep=sleep)
+    env.reset()
+    a = np.tile(np.array([[0.01, 0.2]]), (N, 1))
+    for _ in range(20):
+        env.step(a)
+    t0 = time.perf_counter()
+    K = 300
+    for _ in range(K):
+        obs, r, d, info = env.step(a)
+    dt = (time.perf_counter() - t0) / K
+    print('KilobotsEnv.step with %d kilobots + 1 box, allow_sleep=%s: %.3f ms per env.step (10 substeps), %.0f env.steps/s' % (N, sleep, dt * 1e3, 1.0 / dt))
+    import torch
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        env.sim.step(10)
+    torch.cuda.synchronize()
+    print('   the launch alone (sim.step(10), no host round trip): %.3f ms' % ((time.perf_counter() - t0) / K * 1e3))
+    env.close()
