@@ -29,13 +29,20 @@ def main():
     ap.add_argument('--fused', type=int, default=1)
     ap.add_argument('--objects', type=int, default=0, help='cfg4: pushable objects per env')
     ap.add_argument('--boxes', action='store_true')
+    ap.add_argument('--cluster', action='store_true', help='SimplePhototaxis swarm jamming around a light in the middle (one giant island): tools/cluster_probe.py')
     args = ap.parse_args()
     E, N = args.envs, args.bots
     assert 'prof' in os.environ.get('KB_HIP_LIB', ''), 'run with KB_HIP_LIB=.../libkilobots_hip_prof.so'
     okw = {}
     if args.objects and args.boxes:
         okw = dict(obj_shape=[1] * args.objects, obj_nverts=[4] * args.objects, obj_verts=[[[0.075 * 25.0, 0.075 * 25.0]]] * args.objects)
-    sim = KilobotSim(E, N, num_objects=args.objects, **okw)
+    if args.cluster:
+        from gym_kilobots_amd import _native as nat
+        sim = KilobotSim(E, N, nat.DRIVE_SIMPLE_PHOTOTAXIS, nat.LIGHT_CIRCULAR, light_radius=2.0)
+        sim.light_x.zero_()
+        sim.light_y.zero_()
+    else:
+        sim = KilobotSim(E, N, num_objects=args.objects, **okw)
     sim.status = torch.zeros(E + 40 * E, dtype=torch.int32, device=sim.device)   # status + stamp area
     sim._bind()
     xy1, th1 = scenes.lattice_spawn(8, N, seed=1000)
@@ -51,13 +58,13 @@ def main():
             a1[:, ::2, 1] = 0.0
         acts.append(torch.from_numpy(np.tile(a1, (reps, 1, 1))[:E].copy()).cuda())
     for k in range(args.warm):
-        sim.step(1, actions=acts[k % 8])
+        sim.step(1, actions=None if args.cluster else acts[k % 8])
     torch.cuda.synchronize()
     sim.status[E:].zero_()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for k in range(args.steps):
-        sim.step(args.fused, actions=acts[k % 8])
+        sim.step(args.fused, actions=None if args.cluster else acts[k % 8])
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / args.steps
