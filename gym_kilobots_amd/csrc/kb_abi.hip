@@ -620,8 +620,8 @@ static kb_step_fn select_kernel(const kb_sim *sim, const kb::Params &p) {
     // scenes whose objects are all discs: instantiations without the kilobot - polygon contact code (5 / 6)
     bool discs = obj;
     for (int f = 0; f < p.F; ++f) discs = discs && ot_kind(p.otab[f]) == KB_SHAPE_CIRCLE;
-    if (p.allow_sleep) { discs = false; objsel |= KB_PICK_SLEEP; }   // generic instantiations with the sleep state (no disc-only variants)
     if (discs) objsel += 4;
+    if (p.allow_sleep) objsel |= KB_PICK_SLEEP;      // instantiations with the sleep state
     switch (p.drive_mode) {
     case KB_DRIVE_VELOCITY: {
         // the flagship size has its own instantiation with a compile-time LDS layout

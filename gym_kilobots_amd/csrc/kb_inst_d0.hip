@@ -3,7 +3,7 @@
 
 namespace kb {
 kb_step_fn kb_pick_velocity(int light_type, int objects) {
-    if (objects >= 5 && !(objects & KB_PICK_SLEEP)) return kb_pick_velocity_discs(light_type, objects);      // all objects are discs: kb_inst_d0_discs.hip
+    if ((objects & ~KB_PICK_SLEEP) >= 5) return kb_pick_velocity_discs(light_type, objects);      // all objects are discs: kb_inst_d0_discs.hip
     if ((objects & KB_PICK_SLEEP) && (light_type == KB_PICK_FIXED_1024 || light_type == KB_PICK_FIXED_1024_SENSE))      // (no objects: kb_abi.hip)
         return light_type == KB_PICK_FIXED_1024 ? kb_step_kernel<KB_DRIVE_VELOCITY, KB_LIGHT_NONE, false, 1024, 0, true, false, true>
                                                 : kb_step_kernel<KB_DRIVE_VELOCITY, KB_LIGHT_NONE, false, 1024, 0, true, true, true>;

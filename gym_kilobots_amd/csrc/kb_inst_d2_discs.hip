@@ -4,7 +4,10 @@
 
 namespace kb {
 template <int LIGHT_TYPE>
-static kb_step_fn pick(int objects) {    // 5: objects, 6: objects + one-wave workgroup
+static kb_step_fn pick(int objects) {    // 5: objects, 6: objects + one-wave workgroup; | KB_PICK_SLEEP: with the sleep state
+    if (objects & KB_PICK_SLEEP)
+        return (objects & ~KB_PICK_SLEEP) == 6 ? kb_step_kernel<KB_DRIVE_MOTORS, LIGHT_TYPE, true, 0, 1, false, true, true>
+                                               : kb_step_kernel<KB_DRIVE_MOTORS, LIGHT_TYPE, true, 0, 0, false, true, true>;
     return objects == 6 ? kb_step_kernel<KB_DRIVE_MOTORS, LIGHT_TYPE, true, 0, 1, false>
                         : kb_step_kernel<KB_DRIVE_MOTORS, LIGHT_TYPE, true, 0, 0, false>;
 }
