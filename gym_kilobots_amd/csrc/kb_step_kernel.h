@@ -1391,25 +1391,114 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                     myMc &= NMC >= 64 ? ~0ull : ((1ull << NMC) - 1ull);      // only candidates that exist
                 }
                 const bool leader = lid == 0;
+#ifdef KB_PROFILE
+#define KB_ROUND_SYNC() do { if (tid == 0) atomicAdd(&KB_PROF(8), 1u); if (coop) __syncthreads(); else wave_sync(); } while (0)   // rounds of wave 0 (all passes)
+#else
 #define KB_ROUND_SYNC() do { if (coop) __syncthreads(); else wave_sync(); } while (0)
-#define KB_FOR_ROUNDS(...)                                                                          \
+#endif
+                // The records of a round are staged (global scratch for dense envs) behind dependent indirections (bucket list
+                // -> bucket bounds -> order -> record).  None of them changes during the solve and the thread that sweeps a
+                // record is the same in every pass, so they run two list entries ahead of the sweep: the bounds and the index of
+                // this thread's first record of entry li + 2 are requested behind the sweep of entry li (before its barrier),
+                // the record of entry li + 1 (pair, info, impulse) in front of it.  A round then only waits for the body
+                // velocities / positions in LDS.  Nothing waits for a request in the round that issues it (the index is kept
+                // as loaded and resolved one entry later).  Further records of a thread in one entry (buckets larger than
+                // the sweeping group) are read in place.
+                auto pf_entry = [&](int li_, int &bk_, int &s_, int &e_, unsigned &raw_) __attribute__((always_inline)) {
+                    bk_ = 0; s_ = 0; e_ = 0; raw_ = 0u;
+                    if (li_ < nl) {
+                        bk_ = bkList[myw * BK_PER_WAVE + li_];
+                        s_ = (int)bkStart[bk_]; e_ = (int)bkStart[bk_ + 1];
+                        raw_ = order[s_ + lid < e_ ? s_ + lid : 0];
+                    }
+                };
+#define KB_FOR_ROUNDS_PF(WITH_ACC, ...)                                                             \
+                {                                                                                   \
+                int bk0_, s0_, e0_, bk1_, s1_, e1_; unsigned raw0_, raw1_;                          \
+                pf_entry(0, bk0_, s0_, e0_, raw0_);                                                 \
+                pf_entry(1, bk1_, s1_, e1_, raw1_);                                                 \
+                int c0_ = s0_ + lid < e0_ ? (int)raw0_ : -1;                                        \
+                unsigned pr0_ = sPair[c0_ < 0 ? 0 : c0_], inf0_ = sInfo[c0_ < 0 ? 0 : c0_];         \
+                float acc0_ = WITH_ACC ? sAcc[c0_ < 0 ? 0 : c0_] : 0.0f;                            \
+                for (int li = 0; li < nl; ++li) {                                                   \
+                    const int c1_ = s1_ + lid < e1_ ? (int)raw1_ : -1;                              \
+                    const unsigned pr1_ = sPair[c1_ < 0 ? 0 : c1_], inf1_ = sInfo[c1_ < 0 ? 0 : c1_]; \
+                    const float acc1_ = WITH_ACC ? sAcc[c1_ < 0 ? 0 : c1_] : 0.0f;                  \
+                    int bk2_, s2_, e2_; unsigned raw2_;                                             \
+                    const int bk = bk0_, s_ = s0_, e_ = e0_;                                        \
+                    if ((bk % RK) < RK - 1) {                                                       \
+                        if (c0_ >= 0) do {                                                          \
+                            const int c = c0_;                                                      \
+                            const unsigned KB_PR = pr0_, KB_INF = inf0_;                            \
+                            const float KB_ACC = acc0_;                                             \
+                            __VA_ARGS__                                                             \
+                        } while (0);                                                                \
+                        for (int i_ = s_ + lid + stride; i_ < e_; i_ += stride) {                   \
+                            const int c = (int)order[i_];                                           \
+                            const unsigned KB_PR = sPair[c], KB_INF = sInfo[c];                     \
+                            const float KB_ACC = WITH_ACC ? sAcc[c] : 0.0f;                         \
+                            __VA_ARGS__                                                             \
+                        }                                                                           \
+                        pf_entry(li + 2, bk2_, s2_, e2_, raw2_);                                    \
+                        KB_ROUND_SYNC();                                                            \
+                    } else {                                                                        \
+                        pf_entry(li + 2, bk2_, s2_, e2_, raw2_);                                    \
+                        const int maxr_ = (int)bkMaxRank[bk / RK];                                  \
+                        for (int r_ = RK - 1; r_ <= maxr_; ++r_) {                                  \
+                            if (c0_ >= 0 && (int)((inf0_ >> 8) & 0xFF) == r_) do {                  \
+                                const int c = c0_;                                                  \
+                                const unsigned KB_PR = pr0_, KB_INF = inf0_;                        \
+                                const float KB_ACC = acc0_;                                         \
+                                __VA_ARGS__                                                         \
+                            } while (0);                                                            \
+                            for (int i_ = s_ + lid + stride; i_ < e_; i_ += stride) {               \
+                                const int c = (int)order[i_];                                       \
+                                const unsigned KB_PR = sPair[c], KB_INF = sInfo[c];                 \
+                                if ((int)((KB_INF >> 8) & 0xFF) == r_) {                            \
+                                    const float KB_ACC = WITH_ACC ? sAcc[c] : 0.0f;                 \
+                                    __VA_ARGS__                                                     \
+                                }                                                                   \
+                            }                                                                       \
+                            KB_ROUND_SYNC();                                                        \
+                        }                                                                           \
+                    }                                                                               \
+                    c0_ = c1_; pr0_ = pr1_; inf0_ = inf1_; acc0_ = acc1_;                           \
+                    bk0_ = bk1_; s0_ = s1_; e0_ = e1_;                                              \
+                    bk1_ = bk2_; s1_ = s2_; e1_ = e2_; raw1_ = raw2_;                               \
+                }                                                                                   \
+                }
+#define KB_FOR_ROUNDS_PLAIN(WITH_ACC, ...)                                                          \
                 for (int li = 0; li < nl; ++li) {                                                   \
                     const int bk = bkList[myw * BK_PER_WAVE + li];                                  \
                     const int s_ = (int)bkStart[bk], e_ = (int)bkStart[bk + 1];                     \
                     if ((bk % RK) < RK - 1) {                                                       \
-                        for (int i_ = s_ + lid; i_ < e_; i_ += stride) { const int c = order[i_]; __VA_ARGS__ } \
+                        for (int i_ = s_ + lid; i_ < e_; i_ += stride) {                            \
+                            const int c = order[i_];                                                \
+                            const unsigned KB_PR = sPair[c], KB_INF = sInfo[c];                     \
+                            const float KB_ACC = WITH_ACC ? sAcc[c] : 0.0f;                         \
+                            __VA_ARGS__                                                             \
+                        }                                                                           \
                         KB_ROUND_SYNC();                                                            \
                     } else {                                                                        \
                         const int maxr_ = (int)bkMaxRank[bk / RK];                                  \
                         for (int r_ = RK - 1; r_ <= maxr_; ++r_) {                                  \
                             for (int i_ = s_ + lid; i_ < e_; i_ += stride) {                        \
                                 const int c = order[i_];                                            \
-                                if ((int)((sInfo[c] >> 8) & 0xFF) == r_) { __VA_ARGS__ }            \
+                                const unsigned KB_PR = sPair[c], KB_INF = sInfo[c];                 \
+                                if ((int)((KB_INF >> 8) & 0xFF) == r_) {                            \
+                                    const float KB_ACC = WITH_ACC ? sAcc[c] : 0.0f;                 \
+                                    __VA_ARGS__                                                     \
+                                }                                                                   \
                             }                                                                       \
                             KB_ROUND_SYNC();                                                        \
                         }                                                                           \
                     }                                                                               \
                 }
+                // (the instantiations at the 80-VGPR budget and the object kernels keep the plain walk: the requests in flight
+                // cost ~ 15 VGPRs, which there end in spills of the shape tools/lint_spills.py rejects)
+                constexpr bool PF = !OBJ && FN == 0 && (TIER == 0 || WIDE);
+#define KB_FOR_ROUNDS(WITH_ACC, ...)                                                                \
+                if constexpr (PF) { KB_FOR_ROUNDS_PF(WITH_ACC, __VA_ARGS__) } else { KB_FOR_ROUNDS_PLAIN(WITH_ACC, __VA_ARGS__) }
 #define KB_VEL_NORMAL(a, b, flip, nx, ny)                                                           \
                 float nx, ny;                                                                       \
                 if (a >= WALL_CODE) {                                                               \
@@ -1427,23 +1516,23 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                     }                                                                               \
                 }
                 // b2ContactSolver::WarmStart
-                KB_FOR_ROUNDS({
-                    const unsigned pr = sPair[c];
+                KB_FOR_ROUNDS(true, {
+                    const unsigned pr = KB_PR;
                     const int a = pr & 0xFFFF, b = pr >> 16;
-                    const bool flip = (sInfo[c] & 0x80) != 0;
+                    const bool flip = (KB_INF & 0x80) != 0;
                     if (bpoly(b)) {   // kilobot a - polygon b: Box2D's A = the polygon, B = the kilobot
                         const int m = b - N;
-                        const float *T = objTab + ((sInfo[c] >> 24) & 15u) * OT_WORDS;      // the fixture that is touched
+                        const float *T = objTab + ((KB_INF >> 24) & 15u) * OT_WORDS;      // the fixture that is touched
                         PolyCon pc;
                         poly_contact_setup(T, body_xf(ox, b), pos[b].x, pos[b].y, mk2(pos[a].x, pos[a].y), p.r_bot, KB_IM_BOT(a), pc);
-                        const float acc = sAcc[c];
+                        const float acc = KB_ACC;
                         const float Px = acc * pc.normal.x, Py = acc * pc.normal.y;
                         objW[m] -= T[OT_II] * (pc.rA.x * Py - pc.rA.y * Px);
                         vel[b].x -= T[OT_IM] * Px; vel[b].y -= T[OT_IM] * Py;
                         vel[a].x += KB_IM_BOT(a) * Px; vel[a].y += KB_IM_BOT(a) * Py;
                     } else {
                     KB_VEL_NORMAL(a, b, flip, nx, ny)
-                    const float acc = sAcc[c];
+                    const float acc = KB_ACC;
                     const float Px = acc * nx, Py = acc * ny;
                     const float ima = bim(a), imb = bim(b);
                     if (a < WALL_CODE) { vel[a].x -= ima * Px; vel[a].y -= ima * Py; }
@@ -1453,20 +1542,20 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                 if (OBJ && myMc) { mc_warm_pass(myMc, leader); KB_ROUND_SYNC(); }
                 // SolveVelocityConstraints
                 for (int it = 0; it < p.vel_iters; ++it) {
-                    KB_FOR_ROUNDS({
-                        const unsigned pr = sPair[c];
+                    KB_FOR_ROUNDS(true, {
+                        const unsigned pr = KB_PR;
                         const int a = pr & 0xFFFF, b = pr >> 16;
-                        const bool flip = (sInfo[c] & 0x80) != 0;
+                        const bool flip = (KB_INF & 0x80) != 0;
                         if (bpoly(b)) {   // kilobot a - polygon b: one point, friction sqrt(0 * f) = 0
                             const int m = b - N;
-                            const float *T = objTab + ((sInfo[c] >> 24) & 15u) * OT_WORDS;
+                            const float *T = objTab + ((KB_INF >> 24) & 15u) * OT_WORDS;
                             PolyCon pc;
                             poly_contact_setup(T, body_xf(ox, b), pos[b].x, pos[b].y, mk2(pos[a].x, pos[a].y), p.r_bot, KB_IM_BOT(a), pc);
                             const float wA = objW[m];
                             const float dvx = (vel[a].x - vel[b].x) - (-wA * pc.rA.y), dvy = (vel[a].y - vel[b].y) - (wA * pc.rA.x);
                             const float vn = dvx * pc.normal.x + dvy * pc.normal.y;
                             float lambda = -(pc.nmass * vn);
-                            const float accOld = sAcc[c];
+                            const float accOld = KB_ACC;
                             const float newimp = fmaxf(accOld + lambda, 0.0f);
                             lambda = newimp - accOld;
                             sAcc[c] = newimp;
@@ -1476,17 +1565,17 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                             vel[a].x += KB_IM_BOT(a) * Px; vel[a].y += KB_IM_BOT(a) * Py;
                             continue;
                         }
-                        KB_VEL_NORMAL(a, b, flip, nx, ny)
                         float vax = 0.0f, vay = 0.0f;
-                        const float ima = bim(a), imb = bim(b);
-                        if (a < WALL_CODE) { vax = vel[a].x; vay = vel[a].y; }
+                        if (a < WALL_CODE) { vax = vel[a].x; vay = vel[a].y; }       // (requested together with the positions)
                         const float vbx = vel[b].x, vby = vel[b].y;
+                        KB_VEL_NORMAL(a, b, flip, nx, ny)
+                        const float ima = bim(a), imb = bim(b);
                         const float dvx = vbx - vax, dvy = vby - vay;
                         const float vn = dvx * nx + dvy * ny;
                         const float k = ima + imb;
                         const float nm = k > 0.0f ? 1.0f / k : 0.0f;
                         float lambda = -(nm * vn);
-                        const float accOld = sAcc[c];
+                        const float accOld = KB_ACC;
                         const float newimp = fmaxf(accOld + lambda, 0.0f);
                         lambda = newimp - accOld;
                         sAcc[c] = newimp;
@@ -1564,15 +1653,15 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                 for (int it = 0; it < p.pos_iters; ++it) {
                     unsigned char *act = active + (it & 1) * NB, *nxt = active + ((it + 1) & 1) * NB;
                     bool viol = false;
-                    KB_FOR_ROUNDS({
-                        const unsigned pr = sPair[c];
+                    KB_FOR_ROUNDS(false, {
+                        const unsigned pr = KB_PR;
                         const int a = pr & 0xFFFF, b = pr >> 16;
                         const int isl = (int)parent[b];
                         if (act[isl] && bpoly(b)) {
                             // b2PositionSolverManifold e_faceA, A = polygon b, B = kilobot a; the manifold is the one of
                             // the start-of-substep poses
                             const int m = b - N;
-                            const float *T = objTab + ((sInfo[c] >> 24) & 15u) * OT_WORDS;
+                            const float *T = objTab + ((KB_INF >> 24) & 15u) * OT_WORDS;
                             V2 ln, lp;
                             collide_poly_circle(T, xf_of_body(objBody + m * BT_WORDS, start[b].x, start[b].y, objA0[m]), mk2(start[a].x, start[a].y), p.r_bot, ln, lp);
                             const XF xo = body_xf(ox, b);
@@ -1598,7 +1687,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                             if (a >= WALL_CODE) {
                                 float dist, wx, wy;
                                 wall_geom(p, a - WALL_CODE, bx, by, dist, wx, wy);
-                                const bool flipped = (sInfo[c] & 0x80) != 0;   // manifold normal fixed at detection
+                                const bool flipped = (KB_INF & 0x80) != 0;   // manifold normal fixed at detection
                                 nx = flipped ? -wx : wx; ny = flipped ? -wy : wy;
                                 const float along = flipped ? -dist : dist;
                                 sep = along - rda - rdb;
@@ -1620,6 +1709,9 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                         }
                     })
                     if (OBJ && myMc) { viol |= mc_position_pass(myMc, leader, act, nxt, it == p.pos_iters - 1); KB_ROUND_SYNC(); }
+#ifdef KB_PROFILE
+                    if (tid == 0) atomicAdd(&KB_PROF(10), 1u);
+#endif
                     bool any;
                     if (coop) {
                         if (viol) misc[M_ANY] = 1u;
@@ -1640,6 +1732,8 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                     KB_ROUND_SYNC();
                 }
 #undef KB_FOR_ROUNDS
+#undef KB_FOR_ROUNDS_PF
+#undef KB_FOR_ROUNDS_PLAIN
 #undef KB_VEL_NORMAL
 #undef KB_ROUND_SYNC
             };

@@ -848,3 +848,24 @@ def test_long_horizon_stays_bit_exact(variant):
     assert osim.ws_cnt.sum() / E > (600 if variant.startswith('cfg4') else 450)       # the settled, contact-rich regime
     if 'sleep' in variant:
         assert (osim.sleep_time < 0).any()
+
+
+@pytest.mark.parametrize('N', [1024, 640])
+def test_jammed_swarm_one_giant_island(N):
+    """A swarm driven at a light jams into ONE island of more contacts than the LDS staging holds: the whole workgroup
+    sweeps it key by key on records in the global scratch slice (tools/cluster_probe.py is the timing twin of this scene).
+    Bit-exact against the oracle all the way into the jam."""
+    E = 2
+    xy, th = scenes.lattice_spawn(E, N, seed=77)
+    osim, gsim = make_pair(E, N, O.DRIVE_SIMPLE_PHOTOTAXIS, O.LIGHT_CIRCULAR, xy=xy, th=th, light_radius=2.0)
+    for s in (osim, gsim):
+        s.light_x[...] = 0.0
+        s.light_y[...] = 0.0
+    for k in range(5):
+        osim.step(50)
+        gsim.step(50)
+        assert_same(osim, gsim, 'jam, substep %d' % (50 * (k + 1)))
+        assert_ws_same(osim, gsim)
+    contacts = int(cpu(gsim.ws_cnt).sum(axis=1).min())
+    assert contacts > (1024 if N == 1024 else 600), contacts       # N = 1024: beyond the LDS staging (CAP_LDS)
+    assert int(cpu(gsim.status).max()) == 0 and int(osim.status.max()) == 0
