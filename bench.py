@@ -14,6 +14,9 @@ The timed state does not depend on --warmup: before the warm-up launches the sce
 `--settle` substeps and then further until the contact population is stationary (contacts per env
 within 1 % over 10 substeps); `contacts_per_env` in the JSON line is what the timed launches ran on.
 
+Behind the timed region (N = 1, never mixed into `value`): `with_sleep_state` (the instantiation that carries Box2D's sleep
+state), `fused_env_step` (10 substeps per launch) and `jammed_swarm` (the slow corner: the swarm jammed into one island).
+
 N > 1: `--gpus N` without a torchrun environment starts N child processes itself (one per GPU,
 RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, fresh children -- the parent never touches a GPU);
 under `python -m torch.distributed.run` the ranks are taken from the environment.  Every rank steps its
@@ -346,6 +349,35 @@ def main():
         fused = {'substeps_per_launch': 10, 'ms_per_launch': fms,
                  'kilobot_steps_per_s_one_gpu': E * N * 10 / (fms * 1e-3)}
 
+    # the slow corner, reported next to the headline and never mixed into it: the same swarm driven at a light in the middle
+    # of the arena (SimplePhototaxis) jams into ONE island of ~ 2 800 contacts, which the whole workgroup sweeps key by key
+    # on records in the global staging slice (tools/cluster_probe.py, tests/test_parity_gpu.py::test_jammed_swarm_*)
+    jammed = None
+    plain = not (args.objects or args.sleep or args.sense > 0.0 or args.threads or args.no_toi or args.arena
+                 or args.vel_iters != 10 or args.pos_iters != 10)
+    if rank == 0 and not args.no_fused and plain and world == 1:
+        from gym_kilobots_amd import _native as nat
+        Ej, settle_j, nj = min(E, 1024), 350, 30
+        sim3 = KilobotSim(Ej, N, nat.DRIVE_SIMPLE_PHOTOTAXIS, nat.LIGHT_CIRCULAR, device=dev, light_radius=2.0)
+        sim3.x.copy_(x0[:Ej]); sim3.y.copy_(y0[:Ej]); sim3.theta.copy_(th[:Ej])
+        sim3.forget_contacts()
+        sim3.light_x.zero_(); sim3.light_y.zero_()
+        for _ in range(settle_j):
+            sim3.step(1)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(nj):
+            sim3.step(1)
+        e1.record()
+        torch.cuda.synchronize()
+        jms = e0.elapsed_time(e1) / nj
+        jammed = {'workload': '%d envs x %d SimplePhototaxis kilobots around a CircularGradientLight in the middle of the arena, '
+                              '%d substeps after the lattice spawn' % (Ej, N, settle_j),
+                  'ms_per_launch': jms, 'kilobot_steps_per_s_one_gpu': Ej * N / (jms * 1e-3), 'launches': nj,
+                  'contacts_per_env': contacts_per_env(sim3), 'status_flags': int(sim3.status.max().item())}
+        sim3.close()
+        del sim3
+
     if rank != 0:
         if dist is not None:
             dist.barrier()
@@ -394,6 +426,7 @@ def main():
         'per_rank_kilobot_steps_per_s': rates,
         'fused_env_step': fused,
         'with_sleep_state': with_sleep,
+        'jammed_swarm': jammed,
         'status_flags': status,
         'returns_gathered': int(all_ret.numel()),
     }

@@ -47,3 +47,14 @@ def test_rocprof_summary_agrees_with_the_live_launch_time():
     assert m, txt
     assert abs(float(m.group(1)) * 1e-3 - d['roofline']['avg_launch_ms']) < 0.05 * d['roofline']['avg_launch_ms']
     assert 'kb_step_kernel' in txt
+
+
+def test_bench_line_reports_the_legs_next_to_the_headline():
+    """with_sleep_state, fused_env_step and jammed_swarm ride along, none of them is the value."""
+    d = json.loads(open(_latest('bench_line.json')).readline())
+    for k in ('with_sleep_state', 'fused_env_step', 'jammed_swarm'):
+        assert d.get(k), k
+    j = d['jammed_swarm']
+    assert j['contacts_per_env'] > 2000 and j['status_flags'] == 0          # one island, far beyond the LDS staging
+    assert abs(j['kilobot_steps_per_s_one_gpu'] - 1024 * 1024 / (j['ms_per_launch'] * 1e-3)) < 1e-6 * j['kilobot_steps_per_s_one_gpu']
+    assert j['kilobot_steps_per_s_one_gpu'] < d['value']                    # the slow corner, reported as such
