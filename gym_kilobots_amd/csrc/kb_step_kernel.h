@@ -1374,8 +1374,16 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
 #undef R_NM
         } else {
             // =========================== list solver (staged contact arrays) ===========================
+            // (the instantiations at the 80-VGPR budget and the object kernels keep the plain walk: the requests in flight
+            // cost ~ 15 VGPRs, which there end in spills of the shape tools/lint_spills.py rejects)
+            constexpr bool PF = !OBJ && FN == 0 && (TIER == 0 || WIDE);
+            // sN: normal (x, y) and effective mass of every record, written by the warm-start pass and read by the velocity
+            // sweeps instead of an IEEE sqrt and two divisions per record and sweep (global staging of the PF kernels only:
+            // the LDS staging has no room for them); haveN is a literal at both call sites
             auto solve_list = [&](unsigned *sPair, unsigned *sInfo, float *sAcc, unsigned short *cbk,
-                                  unsigned short *order) __attribute__((always_inline)) {
+                                  unsigned short *order, float *sN, const bool haveN) __attribute__((always_inline)) {
+                const bool HN = PF && haveN;
+                float *sNx = sN, *sNy = sN + p.cap, *sNm = sN + 2 * p.cap;
                 // a "round" = all contacts of one key owned by this (virtual) wave.  coop: the workgroup is one
                 // virtual wave and rounds are separated by s_barrier; otherwise every wave runs alone.
                 const int myw = coop ? 0 : wave;
@@ -1412,7 +1420,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                         raw_ = order[s_ + lid < e_ ? s_ + lid : 0];
                     }
                 };
-#define KB_FOR_ROUNDS_PF(WITH_ACC, ...)                                                             \
+#define KB_FOR_ROUNDS_PF(WITH_ACC, WITH_N, ...)                                                           \
                 {                                                                                   \
                 int bk0_, s0_, e0_, bk1_, s1_, e1_; unsigned raw0_, raw1_;                          \
                 pf_entry(0, bk0_, s0_, e0_, raw0_);                                                 \
@@ -1420,10 +1428,14 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                 int c0_ = s0_ + lid < e0_ ? (int)raw0_ : -1;                                        \
                 unsigned pr0_ = sPair[c0_ < 0 ? 0 : c0_], inf0_ = sInfo[c0_ < 0 ? 0 : c0_];         \
                 float acc0_ = WITH_ACC ? sAcc[c0_ < 0 ? 0 : c0_] : 0.0f;                            \
+                float nx0_ = 0.0f, ny0_ = 0.0f, nm0_ = 0.0f;                                        \
+                if (WITH_N && HN) { nx0_ = sNx[c0_ < 0 ? 0 : c0_]; ny0_ = sNy[c0_ < 0 ? 0 : c0_]; nm0_ = sNm[c0_ < 0 ? 0 : c0_]; } \
                 for (int li = 0; li < nl; ++li) {                                                   \
                     const int c1_ = s1_ + lid < e1_ ? (int)raw1_ : -1;                              \
                     const unsigned pr1_ = sPair[c1_ < 0 ? 0 : c1_], inf1_ = sInfo[c1_ < 0 ? 0 : c1_]; \
                     const float acc1_ = WITH_ACC ? sAcc[c1_ < 0 ? 0 : c1_] : 0.0f;                  \
+                    float nx1_ = 0.0f, ny1_ = 0.0f, nm1_ = 0.0f;                                    \
+                    if (WITH_N && HN) { nx1_ = sNx[c1_ < 0 ? 0 : c1_]; ny1_ = sNy[c1_ < 0 ? 0 : c1_]; nm1_ = sNm[c1_ < 0 ? 0 : c1_]; } \
                     int bk2_, s2_, e2_; unsigned raw2_;                                             \
                     const int bk = bk0_, s_ = s0_, e_ = e0_;                                        \
                     if ((bk % RK) < RK - 1) {                                                       \
@@ -1431,12 +1443,15 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                             const int c = c0_;                                                      \
                             const unsigned KB_PR = pr0_, KB_INF = inf0_;                            \
                             const float KB_ACC = acc0_;                                             \
+                            const float KB_NX = nx0_, KB_NY = ny0_, KB_NM = nm0_;                   \
                             __VA_ARGS__                                                             \
                         } while (0);                                                                \
                         for (int i_ = s_ + lid + stride; i_ < e_; i_ += stride) {                   \
                             const int c = (int)order[i_];                                           \
                             const unsigned KB_PR = sPair[c], KB_INF = sInfo[c];                     \
                             const float KB_ACC = WITH_ACC ? sAcc[c] : 0.0f;                         \
+                            float KB_NX = 0.0f, KB_NY = 0.0f, KB_NM = 0.0f;                         \
+                            if (WITH_N && HN) { KB_NX = sNx[c]; KB_NY = sNy[c]; KB_NM = sNm[c]; }   \
                             __VA_ARGS__                                                             \
                         }                                                                           \
                         pf_entry(li + 2, bk2_, s2_, e2_, raw2_);                                    \
@@ -1449,6 +1464,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                                 const int c = c0_;                                                  \
                                 const unsigned KB_PR = pr0_, KB_INF = inf0_;                        \
                                 const float KB_ACC = acc0_;                                         \
+                                const float KB_NX = nx0_, KB_NY = ny0_, KB_NM = nm0_;               \
                                 __VA_ARGS__                                                         \
                             } while (0);                                                            \
                             for (int i_ = s_ + lid + stride; i_ < e_; i_ += stride) {               \
@@ -1456,13 +1472,15 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                                 const unsigned KB_PR = sPair[c], KB_INF = sInfo[c];                 \
                                 if ((int)((KB_INF >> 8) & 0xFF) == r_) {                            \
                                     const float KB_ACC = WITH_ACC ? sAcc[c] : 0.0f;                 \
+                                    float KB_NX = 0.0f, KB_NY = 0.0f, KB_NM = 0.0f;                 \
+                                    if (WITH_N && HN) { KB_NX = sNx[c]; KB_NY = sNy[c]; KB_NM = sNm[c]; } \
                                     __VA_ARGS__                                                     \
                                 }                                                                   \
                             }                                                                       \
                             KB_ROUND_SYNC();                                                        \
                         }                                                                           \
                     }                                                                               \
-                    c0_ = c1_; pr0_ = pr1_; inf0_ = inf1_; acc0_ = acc1_;                           \
+                    c0_ = c1_; pr0_ = pr1_; inf0_ = inf1_; acc0_ = acc1_; nx0_ = nx1_; ny0_ = ny1_; nm0_ = nm1_; \
                     bk0_ = bk1_; s0_ = s1_; e0_ = e1_;                                              \
                     bk1_ = bk2_; s1_ = s2_; e1_ = e2_; raw1_ = raw2_;                               \
                 }                                                                                   \
@@ -1476,6 +1494,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                             const int c = order[i_];                                                \
                             const unsigned KB_PR = sPair[c], KB_INF = sInfo[c];                     \
                             const float KB_ACC = WITH_ACC ? sAcc[c] : 0.0f;                         \
+                            const float KB_NX = 0.0f, KB_NY = 0.0f, KB_NM = 0.0f;                   \
                             __VA_ARGS__                                                             \
                         }                                                                           \
                         KB_ROUND_SYNC();                                                            \
@@ -1487,6 +1506,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                                 const unsigned KB_PR = sPair[c], KB_INF = sInfo[c];                 \
                                 if ((int)((KB_INF >> 8) & 0xFF) == r_) {                            \
                                     const float KB_ACC = WITH_ACC ? sAcc[c] : 0.0f;                 \
+                                    const float KB_NX = 0.0f, KB_NY = 0.0f, KB_NM = 0.0f;           \
                                     __VA_ARGS__                                                     \
                                 }                                                                   \
                             }                                                                       \
@@ -1494,11 +1514,8 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                         }                                                                           \
                     }                                                                               \
                 }
-                // (the instantiations at the 80-VGPR budget and the object kernels keep the plain walk: the requests in flight
-                // cost ~ 15 VGPRs, which there end in spills of the shape tools/lint_spills.py rejects)
-                constexpr bool PF = !OBJ && FN == 0 && (TIER == 0 || WIDE);
-#define KB_FOR_ROUNDS(WITH_ACC, ...)                                                                \
-                if constexpr (PF) { KB_FOR_ROUNDS_PF(WITH_ACC, __VA_ARGS__) } else { KB_FOR_ROUNDS_PLAIN(WITH_ACC, __VA_ARGS__) }
+#define KB_FOR_ROUNDS(WITH_ACC, WITH_N, ...)                                                        \
+                if constexpr (PF) { KB_FOR_ROUNDS_PF(WITH_ACC, WITH_N, __VA_ARGS__) } else { KB_FOR_ROUNDS_PLAIN(WITH_ACC, __VA_ARGS__) }
 #define KB_VEL_NORMAL(a, b, flip, nx, ny)                                                           \
                 float nx, ny;                                                                       \
                 if (a >= WALL_CODE) {                                                               \
@@ -1516,7 +1533,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                     }                                                                               \
                 }
                 // b2ContactSolver::WarmStart
-                KB_FOR_ROUNDS(true, {
+                KB_FOR_ROUNDS(true, false, {
                     const unsigned pr = KB_PR;
                     const int a = pr & 0xFFFF, b = pr >> 16;
                     const bool flip = (KB_INF & 0x80) != 0;
@@ -1535,6 +1552,10 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                     const float acc = KB_ACC;
                     const float Px = acc * nx, Py = acc * ny;
                     const float ima = bim(a), imb = bim(b);
+                    if (HN) {
+                        const float k_ = ima + imb;
+                        sNx[c] = nx; sNy[c] = ny; sNm[c] = k_ > 0.0f ? 1.0f / k_ : 0.0f;
+                    }
                     if (a < WALL_CODE) { vel[a].x -= ima * Px; vel[a].y -= ima * Py; }
                     vel[b].x += imb * Px; vel[b].y += imb * Py;
                     }
@@ -1542,7 +1563,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                 if (OBJ && myMc) { mc_warm_pass(myMc, leader); KB_ROUND_SYNC(); }
                 // SolveVelocityConstraints
                 for (int it = 0; it < p.vel_iters; ++it) {
-                    KB_FOR_ROUNDS(true, {
+                    KB_FOR_ROUNDS(true, true, {
                         const unsigned pr = KB_PR;
                         const int a = pr & 0xFFFF, b = pr >> 16;
                         const bool flip = (KB_INF & 0x80) != 0;
@@ -1568,12 +1589,15 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                         float vax = 0.0f, vay = 0.0f;
                         if (a < WALL_CODE) { vax = vel[a].x; vay = vel[a].y; }       // (requested together with the positions)
                         const float vbx = vel[b].x, vby = vel[b].y;
-                        KB_VEL_NORMAL(a, b, flip, nx, ny)
                         const float ima = bim(a), imb = bim(b);
+                        float nx = KB_NX, ny = KB_NY, nm = KB_NM;        // (the warm-start pass left them with the record)
+                        if (!HN) {
+                            KB_VEL_NORMAL(a, b, flip, nx2_, ny2_)
+                            const float k = ima + imb;
+                            nx = nx2_; ny = ny2_; nm = k > 0.0f ? 1.0f / k : 0.0f;
+                        }
                         const float dvx = vbx - vax, dvy = vby - vay;
                         const float vn = dvx * nx + dvy * ny;
-                        const float k = ima + imb;
-                        const float nm = k > 0.0f ? 1.0f / k : 0.0f;
                         float lambda = -(nm * vn);
                         const float accOld = KB_ACC;
                         const float newimp = fmaxf(accOld + lambda, 0.0f);
@@ -1653,7 +1677,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                 for (int it = 0; it < p.pos_iters; ++it) {
                     unsigned char *act = active + (it & 1) * NB, *nxt = active + ((it + 1) & 1) * NB;
                     bool viol = false;
-                    KB_FOR_ROUNDS(false, {
+                    KB_FOR_ROUNDS(false, false, {
                         const unsigned pr = KB_PR;
                         const int a = pr & 0xFFFF, b = pr >> 16;
                         const int isl = (int)parent[b];
@@ -1737,7 +1761,11 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
 #undef KB_VEL_NORMAL
 #undef KB_ROUND_SYNC
             };
-            if (big) solve_list(gPair, gInfo, gAcc, gCbk, gOrder); else solve_list(lPair, lInfo, lAcc, lCbk, lOrder);
+            if (big) {
+                // normals + effective masses of the records: 12 B per contact behind the 16-byte records of all envs
+                float *gN = reinterpret_cast<float *>(g.scratch) + (size_t)p.E * p.cap * 4 + wo * 3;
+                solve_list(gPair, gInfo, gAcc, gCbk, gOrder, gN, true);
+            } else solve_list(lPair, lInfo, lAcc, lCbk, lOrder, nullptr, false);
         }
         __syncthreads();
         KB_STAMP_PRE(25);        // ... + waiting for the wave with the most position sweeps
