@@ -134,7 +134,7 @@ typedef struct kb_config {
     int32_t contact_capacity;                   /* [0] contacts (and warm-start entries) per env; 0 = the default rule
                                                    max(4 N + 64, min(N (N - 1) / 2 + 4 N, 2304)) + 40 objects.  A spawn that
                                                    overlaps more kilobots than that sets status bit 0; raise it (<= 65528) then:
-                                                   the entries live in HBM (24 B each), not in LDS */
+                                                   the entries live in HBM (36 B each), not in LDS */
     float mode_density[5];                      /* KB_DRIVE_MIXED: fixture density of the kilobots of drive law k (Kilobot._density 1.0,
                                                    SimpleVelocityControlKilobot._density 2.0: kilobot.py:25, :214); 0 = bot_density */
     int32_t allow_sleep;                        /* [0] b2World(gravity, doSleep=True) of kilobots_env.py:45: bodies carry
