@@ -242,7 +242,7 @@ struct kb_sim {
     bool bound;
     const void *attr_fn;   // kernel whose dynamic-LDS limit has been raised
     int threads;
-    int capL_regular;      // LDS staging entries of the regular image (the compact fixed-size image has its own: ldsc::CAPL)
+    int capL_regular;      // LDS staging entries of the regular image (the fixed-size sorted-bin image has its own: ldsb::CAPL)
     int tier;              // register budget of the kernels without objects: 0 = 128 VGPRs, 2 = 80 VGPRs (6 waves per SIMD)
 };
 
@@ -256,15 +256,30 @@ static bool uses_fixed_1024(const kb::Params &p, int threads) {   // the instant
            (p.M > 0 || p.cap == (int)cap1024);      // (without objects the contact capacity is a compile-time constant of the kernel)
 }
 static int lds_image_bytes(const kb::Params &p, int threads, int capL);
+// sorted-bin image: where the per-island minimum of the sleep times (NB words, SLEEP kernels, idle arrays between the position
+// sweeps and the continuous step) lies -- over the bin boundaries, else over the staged pairs, else behind the image; *total
+// receives the bytes of the image including that area
+static int bins_islmin_offset(const kb::Params &p, int threads, int capL, int *total) {
+    const bool hc = p.hmask != 0 && !uses_fixed_1024(p, threads);
+    const int nw = threads / 64;
+    int tot = kb::ldsb::total(p.NB, p.NP, hc, capL, p.nhead, nw), off;
+    if (kb::ldsb::binE_size(p.nhead, nw) >= 4 * p.NB) off = kb::ldsb::binE(p.NB, p.NP, hc, capL);
+    else if (capL >= p.NB) off = kb::ldsb::con32(p.NB, p.NP, hc, capL, 0);
+    else { off = tot; if (p.allow_sleep) tot += (4 * p.NB + 15) & ~15; }
+    if (total) *total = tot;
+    return off;
+}
 static int lds_bytes_for(const kb::Params &p, int threads, int capL) {
     const int img = lds_image_bytes(p, threads, capL);
     // KB_DRIVE_MIXED: the drive law of every kilobot (one byte each) lies behind the image (Params.botlaw_off)
     return p.drive_mode == KB_DRIVE_MIXED ? ((img + 15) & ~15) + ((p.NP + 15) & ~15) : img;
 }
 static int lds_image_bytes(const kb::Params &p, int threads, int capL) {
-    if (p.M == 0 && p.drive_mode != KB_DRIVE_MIXED) {      // kernels without objects: the compact image (namespace ldsc)
-        const bool fold = uses_fixed_1024(p, threads);
-        return kb::ldsc::total(p.NB, fold ? kb::ldsc::CAPL : capL, p.NP, fold, p.nhead, threads / 64);
+    if (p.M == 0 && p.drive_mode != KB_DRIVE_MIXED) {      // kernels without objects: the sorted-bin image (namespace ldsb)
+        const bool fixed = uses_fixed_1024(p, threads);
+        int total = 0;
+        bins_islmin_offset(p, threads, fixed ? kb::ldsb::CAPL : capL, &total);
+        return total;
     }
     const bool objarea = p.M > 0 || p.drive_mode == KB_DRIVE_MIXED || uses_fixed_1024(p, threads);
     return kb::lds::total(kb::lds::fixed(objarea, threads / 64), p.NB, capL, p.NP, p.nhead, p.nmc);
@@ -438,6 +453,13 @@ int kb_create(const kb_config *cfg, kb_sim **out) {
     const int typical = 3 * p.N + 64 > 256 ? 3 * p.N + 64 : 256;
     if (capLmax > typical) capLmax = typical;
     p.capL = p.cap < capLmax ? p.cap : capLmax;
+    if (cfg->num_objects == 0 && cfg->drive_mode != KB_DRIVE_MIXED) {
+        // sorted-bin image: scratch arrays of the sort lie over the staging area (2 B per kilobot over 4 B per entry); a
+        // smaller contact_capacity still bounds what is staged (kernel: min(capL, cap))
+        int lo = ((((p.N + 3) & ~3) / 2) + 7) & ~7;
+        if (lo < 64) lo = 64;
+        if (p.capL < lo) p.capL = lo;
+    }
     p.NP = (p.N + 3) & ~3;
     p.NB = p.NP + KB_MAX_OBJECTS + 4;
     p.M = cfg->num_objects;
@@ -548,8 +570,9 @@ int kb_create(const kb_config *cfg, kb_sim **out) {
         if (fit >= 1 && lds_bytes_for(p, s->threads, c) <= LDS_CU / (fit + 1)) p.capL = c;
     }
     s->capL_regular = p.capL;
-    if (p.M == 0 && uses_fixed_1024(p, s->threads)) p.capL = ldsc::CAPL;
+    if (p.M == 0 && uses_fixed_1024(p, s->threads)) p.capL = ldsb::CAPL;
     p.lds_total = lds_bytes_for(p, s->threads, p.capL);
+    p.islmin_off = bins_islmin_offset(p, s->threads, p.capL, nullptr);
     p.botlaw_off = (lds_image_bytes(p, s->threads, p.capL) + 15) & ~15;
     s->tier = pick_tier(p, s->threads, p.lds_total);
     if (p.lds_total > LDS_CU) {
@@ -626,7 +649,7 @@ static kb_step_fn select_kernel(const kb_sim *sim, const kb::Params &p) {
     case KB_DRIVE_VELOCITY: {
         // the flagship size has its own instantiation with a compile-time LDS layout
         const bool fixed = uses_fixed_1024(p, sim->threads);
-        if (fixed && !obj && p.capL != ldsc::CAPL) return nullptr;      // (cannot happen: kb_create / kb_set_block_threads keep them in step)
+        if (fixed && !obj && p.capL != ldsb::CAPL) return nullptr;      // (cannot happen: kb_create / kb_set_block_threads keep them in step)
         return kb_pick_velocity(fixed ? (p.sense_s > 0 ? KB_PICK_FIXED_1024_SENSE : KB_PICK_FIXED_1024) : p.light_type,
                                 fixed ? ((discs ? 5 : (int)obj) | (p.allow_sleep ? KB_PICK_SLEEP : 0)) : objsel);
     }
@@ -760,7 +783,7 @@ int kb_block_threads(const kb_sim *sim) { return sim ? sim->threads : KB_EINVAL;
 int kb_set_block_threads(kb_sim *sim, int threads) {
     if (!sim || threads < 64 || threads > 64 * MAX_WAVES || (threads & 63)) return fail(KB_EINVAL, "kb_set_block_threads: multiple of 64 up to the build maximum");
     if (sim->p.N > BPT * threads) return fail(KB_EINVAL, "kb_set_block_threads: need num_bots <= bots-per-thread x threads");
-    const int capL = (sim->p.M == 0 && uses_fixed_1024(sim->p, threads)) ? ldsc::CAPL : sim->capL_regular;
+    const int capL = (sim->p.M == 0 && uses_fixed_1024(sim->p, threads)) ? ldsb::CAPL : sim->capL_regular;
     const int need = lds_bytes_for(sim->p, threads, capL);
     if (need > 160 * 1024) return fail(KB_ELDS, "kb_set_block_threads: more than 160 KiB of LDS per env at this workgroup size");
     if (sim->p.drive_mode == KB_DRIVE_MIXED && threads != 64 && threads != 64 * MAX_WAVES)
@@ -768,6 +791,7 @@ int kb_set_block_threads(kb_sim *sim, int threads) {
     sim->threads = threads;
     sim->p.capL = capL;
     sim->p.lds_total = need;
+    sim->p.islmin_off = bins_islmin_offset(sim->p, threads, capL, nullptr);
     sim->p.botlaw_off = (lds_image_bytes(sim->p, threads, capL) + 15) & ~15;
     sim->tier = pick_tier(sim->p, threads, need);
     return KB_OK;

@@ -69,7 +69,7 @@ constexpr int BIG_ISLAND = 16;        // contacts; islands from this size on are
 constexpr int KREG = KB_KREG;               // contacts a lane can keep in registers (register-resident solver)
 constexpr int CAP_LDS = 1024;         // contacts staged in LDS; denser envs stage in the global scratch slice
 
-enum { M_NCON = 0, M_TOTAL = 1, M_ANY = 2, M_STATUS = 3, M_MAXISL = 4, M_PROF = 5, M_WCNT = 8, M_WFILL = 8 + MAX_WAVES, M_COUNT = 8 + 2 * MAX_WAVES };
+enum { M_NCON = 0, M_TOTAL = 1, M_ANY = 2, M_STATUS = 3, M_MAXISL = 4, M_PROF = 5, M_XTRA = 6, M_XFILL = 7, M_WCNT = 8, M_WFILL = 8 + MAX_WAVES, M_COUNT = 8 + 2 * MAX_WAVES };
 static_assert(M_COUNT <= 64, "misc area");
 
 // ---- LDS layout ----------------------------------------------------------------------------------
@@ -156,6 +156,59 @@ __host__ __device__ inline int total(int NB, int capL, int NP, bool fold, int nc
 }
 }  // namespace ldsc
 
+// ---- sorted-bin LDS image (round 3): every kernel without objects ------------------------------------------------------
+// The broadphase is a counting sort of the kilobots by grid cell ("bins"; a hash of the cells for sparse swarms), and the
+// bodies LIVE in that order for the length of a substep: pos / vel / parent / ... are indexed by the kilobot's SLOT in the
+// sorted order, so the candidates of a stencil row are one contiguous run of slots (no list heads, no next pointers, no
+// indirection through an id).  A contact is stored at its position in the packed warm-start list of the substep
+// (newOff[owner] + slot of the owner's list), so StoreImpulses is a copy, and the previous substep's list is kept as an
+// LDS image (6 B per entry) that aliases arrays which only live between the island phase and the end of the substep.
+//   always            : misc | pos | vel
+//   parent            : union-find (emit .. sleep bookkeeping); start-of-substep angle of the TOI candidates behind it
+//   dircnt            : per-direction contact counts (find .. emit) -> island census / body depth -> startY (integrate .. TOI)
+//   botA              : [wsOff | wsCnt | idOf | (cellOfSlot: hashed bins)]; startX over its front (integrate .. TOI)
+//   botB              : [newOff | wsCntNew]
+//   con32 x 3         : lPair lInfo lAcc   (the arrival-order scratch of the sort lies over lInfo, the neighbour counters of
+//                                           the sensing pass over lAcc: both dead before the emit pass writes the records)
+//   act0              : position-solver island flags of even iterations (also "island has an awake body": cleared in the
+//                       drive phase, hence outside the aliased zone)
+//   zone              : [act1 | islWave | lOrder | lCbk]  aliased by the warm-start image [oldAcc | oldKey]
+//   binE              : bin boundaries (u16, entry i = kilobots in bins < i) -> bucket tables of the contact sort -> unused
+namespace ldsb {
+__host__ __device__ constexpr int A16(int x) { return (x + 15) & ~15; }
+__host__ __device__ constexpr int A4(int x) { return (x + 3) & ~3; }
+__host__ __device__ constexpr int pos() { return 320; }                       // (MISC 256 + WSUM 64 in front)
+__host__ __device__ constexpr int vel(int NB) { return pos() + 8 * NB; }
+__host__ __device__ constexpr int parent(int NB) { return vel(NB) + 8 * NB; }
+__host__ __device__ constexpr int dircnt(int NB) { return parent(NB) + 4 * NB; }
+__host__ __device__ constexpr int botA(int NB) { return dircnt(NB) + 4 * NB; }
+__host__ __device__ constexpr int botA_size(int NB, int NP, bool hc) { return A16((5 + (hc ? 2 : 0)) * NP > 4 * NB ? (5 + (hc ? 2 : 0)) * NP : 4 * NB); }
+__host__ __device__ constexpr int wsoff(int NB) { return botA(NB); }
+__host__ __device__ constexpr int wscnt(int NB, int NP) { return botA(NB) + 2 * NP; }
+__host__ __device__ constexpr int idof(int NB, int NP) { return botA(NB) + 3 * NP; }
+__host__ __device__ constexpr int cellofslot(int NB, int NP) { return botA(NB) + 5 * NP; }
+__host__ __device__ constexpr int botB(int NB, int NP, bool hc) { return botA(NB) + botA_size(NB, NP, hc); }
+__host__ __device__ constexpr int newoff(int NB, int NP, bool hc) { return botB(NB, NP, hc); }
+__host__ __device__ constexpr int wscntnew(int NB, int NP, bool hc) { return botB(NB, NP, hc) + 2 * NP; }
+__host__ __device__ constexpr int con32(int NB, int NP, bool hc, int capL, int k) { return A16(botB(NB, NP, hc) + 3 * NP) + 4 * capL * k; }
+__host__ __device__ constexpr int act0(int NB, int NP, bool hc, int capL) { return con32(NB, NP, hc, capL, 3); }
+__host__ __device__ constexpr int zone(int NB, int NP, bool hc, int capL) { return act0(NB, NP, hc, capL) + NB; }      // act1 follows act0 directly
+__host__ __device__ constexpr int islwave(int NB, int NP, bool hc, int capL) { return zone(NB, NP, hc, capL) + NB; }
+__host__ __device__ constexpr int order(int NB, int NP, bool hc, int capL) { return A4(islwave(NB, NP, hc, capL) + NB); }
+__host__ __device__ constexpr int cbk(int NB, int NP, bool hc, int capL) { return order(NB, NP, hc, capL) + A4(2 * capL); }
+__host__ __device__ constexpr int oldacc(int NB, int NP, bool hc, int capL) { return A4(zone(NB, NP, hc, capL)); }
+__host__ __device__ constexpr int oldkey(int NB, int NP, bool hc, int capL) { return oldacc(NB, NP, hc, capL) + 4 * capL; }
+__host__ __device__ constexpr int zone_end(int NB, int NP, bool hc, int capL) {
+    return cbk(NB, NP, hc, capL) + A4(2 * capL) > oldkey(NB, NP, hc, capL) + 2 * capL ? cbk(NB, NP, hc, capL) + A4(2 * capL) : oldkey(NB, NP, hc, capL) + 2 * capL;
+}
+__host__ __device__ constexpr int binE(int NB, int NP, bool hc, int capL) { return A16(zone_end(NB, NP, hc, capL)); }
+__host__ __device__ constexpr int bin_entries(int nbin) { return (nbin + 1 + 7) & ~7; }                 // u16 entries, whole 16-byte chunks
+__host__ __device__ constexpr int tables(int nw) { return lds::nlist(nw) + 16 - lds::BKSTART; }       // bucket tables, relative to binE
+__host__ __device__ inline int binE_size(int nbin, int nw) { return A16(2 * bin_entries(nbin) > tables(nw) ? 2 * bin_entries(nbin) : tables(nw)); }
+__host__ __device__ inline int total(int NB, int NP, bool hc, int capL, int nbin, int nw) { return binE(NB, NP, hc, capL) + binE_size(nbin, nw); }
+constexpr int CAPL = 688;                                                     // staged contacts of the fixed-size kernel
+}  // namespace ldsb
+
 struct Params {
     kb_buffers buf;
     const float *actions;
@@ -179,6 +232,7 @@ struct Params {
     int allow_sleep;                          // kb_config.allow_sleep: the SLEEP instantiations are launched
     float im_mode[5];                         // KB_DRIVE_MIXED: inverse mass of a kilobot by drive law
     int botlaw_off;                           // ... and the LDS offset of the per-kilobot law bytes (behind the image)
+    int islmin_off;                           // sorted-bin image, SLEEP: LDS offset of the per-island minimum of the sleep times (NB words)
     int sense_s;                              // IR neighbour sensing: reach of the stencil in cells (0 = off)
     float sense_r2;                           // ... and the squared radius in world units
 };
@@ -620,6 +674,93 @@ __device__ __forceinline__ unsigned block_scan_u8(const unsigned char *cnt, unsi
 }
 
 
+
+// ---- sorted bins: inclusive scan of the bin counters ------------------------------------------------------------------
+// E1[0] = 0, E1[i] (i >= 1) = kilobots counted into bin i - 1; afterwards E1[i] = kilobots in bins < i, i.e. bin b occupies the
+// slots [E1[b], E1[b + 1]).  nchunks chunks of 8 u16 entries (16 bytes, padding zero); thread t scans `per` consecutive chunks.
+// All threads must call; two workgroup barriers inside.
+template <bool ONE>
+__device__ __forceinline__ void block_scan_bins(unsigned short *E1, int nchunks, int per, unsigned *wsum) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    const int c0 = ONE ? tid : tid * per, c1 = ONE ? min(tid + 1, nchunks) : min(c0 + per, nchunks);
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    unsigned sum = 0;
+    for (int c = c0; c < c1; ++c) {
+        v = reinterpret_cast<const uint4 *>(E1)[c];
+        sum += (v.x & 0xFFFFu) + (v.x >> 16) + (v.y & 0xFFFFu) + (v.y >> 16) + (v.z & 0xFFFFu) + (v.z >> 16) + (v.w & 0xFFFFu) + (v.w >> 16);
+    }
+    const unsigned incl = wave_incl_scan(sum);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    unsigned run = incl - sum;
+    for (int w = 0; w < nw; ++w) { const unsigned s = wsum[w]; if (w < wave) run += s; }
+    for (int c = c0; c < c1; ++c) {
+        if (!ONE) v = reinterpret_cast<const uint4 *>(E1)[c];
+        uint4 o;
+        unsigned a, b;
+        a = run + (v.x & 0xFFFFu); b = a + (v.x >> 16); o.x = a | (b << 16);
+        a = b + (v.y & 0xFFFFu); b = a + (v.y >> 16); o.y = a | (b << 16);
+        a = b + (v.z & 0xFFFFu); b = a + (v.z >> 16); o.z = a | (b << 16);
+        a = b + (v.w & 0xFFFFu); b = a + (v.w >> 16); o.w = a | (b << 16);
+        run = b;
+        reinterpret_cast<uint4 *>(E1)[c] = o;
+    }
+    __syncthreads();
+}
+
+// IR-range neighbour sensing off the sorted bins (arena-sized grid, no hashing): the kilobots of the cells x0 .. x1 of a
+// grid row are ONE run of slots, two loads per row.  Slot sa walks the half stencil of reach s (its own row: the slots
+// behind it up to the end of cell cx + s; the s rows above: cells cx - s .. cx + s), meets every pair once and counts
+// both ends.  cnt16: u16 counters per slot packed in pairs (zeroed by the caller).
+__device__ __noinline__ void kb_sense_bins(const float2 *pos, const unsigned short *E1, unsigned *cnt16, int sa, int cx, int cy,
+                                           int gw, int gh, int s, float R2) {
+    const float2 pa = pos[sa];
+    unsigned mine = 0;
+    for (int dy = 0; dy <= s; ++dy) {
+        const int oy = cy + dy;
+        if (oy >= gh) break;
+        const int x0 = max(cx - s, 0), x1 = min(cx + s, gw - 1);
+        int lo = dy == 0 ? sa + 1 : (int)E1[oy * gw + x0];
+        const int hi = (int)E1[oy * gw + x1 + 1];
+        for (int b = lo; b < hi; ++b) {
+            const float2 pb = pos[b];
+            const float ex = pb.x - pa.x, ey = pb.y - pa.y;
+            const float dd = ex * ex + ey * ey;
+            if (!(dd > R2)) {
+                mine++;
+                atomicAdd(&cnt16[b >> 1], 1u << (16 * (b & 1)));
+            }
+        }
+    }
+    if (mine) atomicAdd(&cnt16[sa >> 1], mine << (16 * (sa & 1)));
+}
+// the same over hashed bins (sparse swarms): cell by cell, every candidate checked against the cell it must be in
+__device__ __noinline__ void kb_sense_bins_hashed(const float2 *pos, const unsigned short *E1, const unsigned short *cellOfSlot, unsigned *cnt16,
+                                                  int sa, int cx, int cy, int gw, int gh, int s, float R2, int hmask) {
+    const float2 pa = pos[sa];
+    unsigned mine = 0;
+    for (int dy = 0; dy <= s; ++dy) {
+        const int oy = cy + dy;
+        if (oy >= gh) break;
+        const int x0 = dy == 0 ? cx : max(cx - s, 0), x1 = min(cx + s, gw - 1);
+        for (int ox = x0; ox <= x1; ++ox) {
+            const int cell = oy * gw + ox, bin = cell & hmask;
+            const bool own = dy == 0 && ox == cx;
+            const int lo = own ? sa + 1 : (int)E1[bin], hi = (int)E1[bin + 1];
+            for (int b = lo; b < hi; ++b) {
+                if ((int)cellOfSlot[b] != cell) continue;
+                const float2 pb = pos[b];
+                const float ex = pb.x - pa.x, ey = pb.y - pa.y;
+                const float dd = ex * ex + ey * ey;
+                if (!(dd > R2)) {
+                    mine++;
+                    atomicAdd(&cnt16[b >> 1], 1u << (16 * (b & 1)));
+                }
+            }
+        }
+    }
+    if (mine) atomicAdd(&cnt16[sa >> 1], mine << (16 * (sa & 1)));
+}
 
 typedef void (*kb_step_fn)(const Params);
 constexpr int KB_PICK_SLEEP = 16;      // kb_pick_*(..., objects | KB_PICK_SLEEP): the instantiation with the sleep state

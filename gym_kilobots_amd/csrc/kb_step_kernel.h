@@ -31,9 +31,8 @@ namespace kb {
 template <int DRIVE_MODE, int LIGHT_TYPE, bool OBJ, int FN = 0, int TIER = 0, bool POLY = true, bool SENSE = true, bool SLEEP = false>
 __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1 || TIER == 3) ? 2 : ((TIER == 2 || (FN != 0 && !OBJ)) ? KB_COMPACT_WAVES_PER_SIMD : KB_MIN_WAVES_PER_SIMD)) kb_step_kernel(const Params p) {
     constexpr bool WIDE = TIER == 1 || TIER == 3;       // (256 VGPRs: no register spills)
-    constexpr bool COMPACT = !OBJ;
+    constexpr bool BINS = !OBJ;          // sorted-bin broadphase, bodies in slot order, contacts at their warm-start position (namespace ldsb)
     static_assert(!SLEEP || FN == 0 || !OBJ, "the fixed-size instantiations with objects do not carry the sleep state");
-    constexpr bool FOLD = FN != 0 && !OBJ;       // lCbk over nextb (needs capL <= NP)
     extern __shared__ __align__(16) unsigned char smem[];
     int e = blockIdx.x;
     int tid = threadIdx.x;
@@ -46,32 +45,40 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
     const float h = p.h;
 
     const int NB = FN ? ((FN + 3) & ~3) + KB_MAX_OBJECTS + 4 : p.NB;
-    const int capL_ = FOLD ? ldsc::CAPL : p.capL;
-    // LDS arrays (offsets: namespace lds in kb_common.h)
-    // (the fixed-size instantiations keep room for the object tables even without objects: all their offsets are
-    //  compile-time constants either way, two envs per CU fit both ways, and this image measured 1 % faster)
+    const int capL_ = (BINS && FN != 0) ? ldsb::CAPL : p.capL;
+    // sparse swarms: the bins are a hash of the cells (bin = cell & hmask, kb_create: a power of two >= 2 N) instead of one
+    // bin per cell of the arena; a bin may then hold kilobots of several cells and every candidate's cell is checked.
+    // The set of contacts and their canonical order (which use the cell coordinates) do not change.
+    const bool hashed = FN == 0 && p.hmask != 0;
+    // LDS arrays (offsets: namespace lds / ldsb in kb_common.h)
+    // (the fixed-size instantiations with objects keep room for the object tables: all their offsets are compile-time constants)
     const int fx = lds::fixed(OBJ || FN != 0, nw), ot_ = lds::objtab(nw);
     // positions, velocities and start-of-substep positions as (x, y) pairs: one 8-byte LDS access per body
-    float2 *pos = (float2 *)(smem + (COMPACT ? ldsc::pos(NB) : lds::body32(fx, NB, 0))), *vel = (float2 *)(smem + (COMPACT ? ldsc::vel(NB) : lds::body32(fx, NB, 2)));
-    float2 *start = (float2 *)(smem + lds::body32(fx, NB, 4));      // (not in the compact image: startX / startY below)
-    unsigned *dirCnt = (unsigned *)(smem + (COMPACT ? ldsc::dircnt(NB) : lds::body32(fx, NB, 6))), *parent = (unsigned *)(smem + (COMPACT ? ldsc::parent(NB) : lds::body32(fx, NB, 7)));
+    float2 *pos = (float2 *)(smem + (BINS ? ldsb::pos() : lds::body32(fx, NB, 0))), *vel = (float2 *)(smem + (BINS ? ldsb::vel(NB) : lds::body32(fx, NB, 2)));
+    float2 *start = (float2 *)(smem + lds::body32(fx, NB, 4));      // (not in the sorted-bin image: startX / startY below)
+    unsigned *dirCnt = (unsigned *)(smem + (BINS ? ldsb::dircnt(NB) : lds::body32(fx, NB, 6))), *parent = (unsigned *)(smem + (BINS ? ldsb::parent(NB) : lds::body32(fx, NB, 7)));
     unsigned *islCnt = dirCnt;  // alias: dirCnt is dead once the contacts are emitted
-    unsigned *lPair = (unsigned *)(smem + (COMPACT ? ldsc::con32(NB, capL_, 0) : lds::con32(fx, NB, capL_, 0))), *lInfo = (unsigned *)(smem + (COMPACT ? ldsc::con32(NB, capL_, 1) : lds::con32(fx, NB, capL_, 1)));
-    float *lAcc = (float *)(smem + (COMPACT ? ldsc::con32(NB, capL_, 2) : lds::con32(fx, NB, capL_, 2))), *oldAcc = (float *)(smem + lds::con32(fx, NB, capL_, 3));
-    unsigned short *lCbk = (unsigned short *)(smem + (COMPACT ? (FOLD ? ldsc::bot16(NB, capL_, NP, FOLD, 2) : ldsc::con16(NB, capL_, 0)) : lds::con16(fx, NB, capL_, 0)));
-    unsigned short *lOrder = (unsigned short *)(smem + (COMPACT ? ldsc::con16(NB, capL_, FOLD ? 0 : 1) : lds::con16(fx, NB, capL_, 1)));
-    unsigned short *oldKey = (unsigned short *)(smem + lds::con16(fx, NB, capL_, 2));      // (oldAcc / oldKey: not in the compact image, never touched there)
-    unsigned short *wsOff = (unsigned short *)(smem + (COMPACT ? ldsc::bot16(NB, capL_, NP, FOLD, 0) : lds::bot16(fx, NB, capL_, NP, 0))), *newOff = (unsigned short *)(smem + (COMPACT ? ldsc::bot16(NB, capL_, NP, FOLD, 1) : lds::bot16(fx, NB, capL_, NP, 1)));
-    unsigned short *nextb = (unsigned short *)(smem + (COMPACT ? ldsc::bot16(NB, capL_, NP, FOLD, 2) : lds::bot16(fx, NB, capL_, NP, 2))), *cellOf = (unsigned short *)(smem + (COMPACT ? ldsc::bot16(NB, capL_, NP, FOLD, 3) : lds::bot16(fx, NB, capL_, NP, 3)));
-    unsigned char *wsCnt = smem + (COMPACT ? ldsc::bot8(NB, capL_, NP, FOLD, 0) : lds::bot8(fx, NB, capL_, NP, 0)), *wsCntNew = smem + (COMPACT ? ldsc::bot8(NB, capL_, NP, FOLD, 1) : lds::bot8(fx, NB, capL_, NP, 1));
-    unsigned char *active = smem + (COMPACT ? ldsc::active(NB, capL_, NP, FOLD) : lds::active(fx, NB, capL_, NP));
-    unsigned char *islWave = smem + (COMPACT ? ldsc::islwave(NB, capL_, NP, FOLD) : lds::islwave(fx, NB, capL_, NP));   // wave that sweeps the island rooted at body b
-    unsigned short *head = (unsigned short *)(smem + (COMPACT ? ldsc::head(NB, capL_, NP, FOLD) : lds::head(fx, NB, capL_, NP)));   // per-cell list heads (EMPTY16 = empty)
-    // compact image: start-of-substep positions over arrays that are dead from the integration on
-    float *startX = reinterpret_cast<float *>(nextb), *startY = reinterpret_cast<float *>(dirCnt);
+    unsigned *lPair = (unsigned *)(smem + (BINS ? ldsb::con32(NB, NP, hashed, capL_, 0) : lds::con32(fx, NB, capL_, 0))), *lInfo = (unsigned *)(smem + (BINS ? ldsb::con32(NB, NP, hashed, capL_, 1) : lds::con32(fx, NB, capL_, 1)));
+    float *lAcc = (float *)(smem + (BINS ? ldsb::con32(NB, NP, hashed, capL_, 2) : lds::con32(fx, NB, capL_, 2)));
+    float *oldAcc = (float *)(smem + (BINS ? ldsb::oldacc(NB, NP, hashed, capL_) : lds::con32(fx, NB, capL_, 3)));
+    unsigned short *lCbk = (unsigned short *)(smem + (BINS ? ldsb::cbk(NB, NP, hashed, capL_) : lds::con16(fx, NB, capL_, 0)));
+    unsigned short *lOrder = (unsigned short *)(smem + (BINS ? ldsb::order(NB, NP, hashed, capL_) : lds::con16(fx, NB, capL_, 1)));
+    unsigned short *oldKey = (unsigned short *)(smem + (BINS ? ldsb::oldkey(NB, NP, hashed, capL_) : lds::con16(fx, NB, capL_, 2)));
+    unsigned short *wsOff = (unsigned short *)(smem + (BINS ? ldsb::wsoff(NB) : lds::bot16(fx, NB, capL_, NP, 0))), *newOff = (unsigned short *)(smem + (BINS ? ldsb::newoff(NB, NP, hashed) : lds::bot16(fx, NB, capL_, NP, 1)));
+    unsigned short *nextb = (unsigned short *)(smem + lds::bot16(fx, NB, capL_, NP, 2)), *cellOf = (unsigned short *)(smem + lds::bot16(fx, NB, capL_, NP, 3));   // (cell lists: kernels with objects only)
+    unsigned char *wsCnt = smem + (BINS ? ldsb::wscnt(NB, NP) : lds::bot8(fx, NB, capL_, NP, 0)), *wsCntNew = smem + (BINS ? ldsb::wscntnew(NB, NP, hashed) : lds::bot8(fx, NB, capL_, NP, 1));
+    unsigned char *active = smem + (BINS ? ldsb::act0(NB, NP, hashed, capL_) : lds::active(fx, NB, capL_, NP));
+    unsigned char *islWave = smem + (BINS ? ldsb::islwave(NB, NP, hashed, capL_) : lds::islwave(fx, NB, capL_, NP));   // wave that sweeps the island rooted at body b
+    unsigned short *head = (unsigned short *)(smem + lds::head(fx, NB, capL_, NP));   // per-cell list heads (EMPTY16 = empty; kernels with objects only)
+    // sorted-bin image: slot -> kilobot id, cell of a slot (hashed bins), bin boundaries, arrival-order scratch of the sort
+    unsigned short *idOf = (unsigned short *)(smem + ldsb::idof(NB, NP)), *cellOfSlot = (unsigned short *)(smem + ldsb::cellofslot(NB, NP));
+    unsigned short *E1 = (unsigned short *)(smem + ldsb::binE(NB, NP, hashed, capL_));
+    unsigned short *tmpSort = reinterpret_cast<unsigned short *>(lInfo);
+    // ... start-of-substep positions over arrays that are dead from the integration on
+    float *startX = reinterpret_cast<float *>(smem + ldsb::botA(NB)), *startY = reinterpret_cast<float *>(dirCnt);
     unsigned *misc = (unsigned *)(smem + lds::MISC), *wsum = (unsigned *)(smem + lds::WSUM);
-    // (compact image: the bucket tables lie over the cell heads, which are dead between the label pass and the next substep)
-    const int tb_ = COMPACT ? ldsc::head(NB, capL_, NP, FOLD) - lds::BKSTART : 0;
+    // (sorted-bin image: the bucket tables lie over the bin boundaries, which are dead between the emit pass and the next substep)
+    const int tb_ = BINS ? ldsb::binE(NB, NP, hashed, capL_) - lds::BKSTART : 0;
     unsigned *bkStart = (unsigned *)(smem + tb_ + lds::BKSTART), *bkFill = (unsigned *)(smem + tb_ + lds::bkfill(nw));
     unsigned *bkMaxRank = (unsigned *)(smem + tb_ + lds::bkmaxrank(nw));
     unsigned short *bkList = (unsigned short *)(smem + tb_ + lds::bklist(nw));
@@ -111,11 +118,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
     const int F = OBJ ? p.F : 0;          // fixtures of the objects (>= M)
 
     const kb_buffers &g = p.buf;
-    // Sparse swarms: the cell heads are a hash table of the cells (slot = cell & hmask, kb_create: a power of two >= 2 N)
-    // instead of one head per cell of the arena -- 2 494 cells of the default arena are 5 KB, 40 % of a 64-kilobot env's
-    // LDS image.  A list may then hold kilobots of several cells: every walk checks the candidate's own cell.  The set of
-    // contacts and their canonical order (which use the cell coordinates) do not change.
-    const bool hashed = FN == 0 && p.hmask != 0;
+    // (kernels with objects: the cell heads are a hash table of the cells for sparse swarms, like the bins)
     auto hix = [&](int cell_) __attribute__((always_inline)) -> int { return hashed ? (cell_ & p.hmask) : cell_; };
     // contact staging in global scratch, used when an env has more contacts than fit the LDS staging area
     unsigned *gPair, *gInfo;
@@ -149,11 +152,14 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
     float sth0[BPT];     // angle at the start of the substep (continuous step against the walls)
     float slp[BPT];      // SLEEP: b2Body::m_sleepTime; < 0: the kilobot is asleep
     int law[BPT];        // drive law of this thread's kilobots
+    int ms[BPT];         // sorted-bin image: the slot this thread's kilobots live in (the kilobot's id until the first sort)
 #define KB_LAW(q) (MIX ? law[q] : DRIVE_MODE)
+#define KB_SLOT(q, b_) (BINS ? ms[q] : (b_))     // index of kilobot b_ (= tid + q * nt) in the per-body LDS arrays
 #pragma unroll
     for (int q = 0; q < BPT; ++q) {
         const int b = tid + q * nt;
         th[q] = 0.0f; bw[q] = 0.0f; cv[q] = 0.0f; cw[q] = 0.0f; av[q] = 0.0f; aw[q] = 0.0f; slp[q] = 0.0f; law[q] = DRIVE_MODE;
+        ms[q] = b < N ? b : NB - 1;
         if (b < N) {
             pos[b].x = g.x[o + b]; pos[b].y = g.y[o + b]; th[q] = g.theta[o + b];
             if (MIX) { law[q] = min((int)g.bot_mode[o + b], 4); botLaw[b] = (unsigned char)law[q]; }
@@ -179,21 +185,6 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
             }
         }
     }
-    // Compact image: the label pass of the first substep reads the packed warm-start list of the previous launch where it
-    // lies, and by then it has left the L2 (a launch moves 0.6 GB).  Request it now, together with the state: the same trip
-    // to HBM, the lines wait in the cache hierarchy; the values themselves are dropped.
-    if (COMPACT && p.n_substeps > 0) {
-        unsigned pk[2];
-        float pa[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int i = tid + q * nt;
-            const bool in = i < capL_ && i < p.cap;
-            pk[q] = in ? g.ws_key[wo + i] : 0u;
-            pa[q] = in ? g.ws_acc[wo + i] : 0.0f;
-        }
-        asm volatile("" :: "v"(pk[0]), "v"(pk[1]), "v"(pa[0]), "v"(pa[1]));
-    }
     for (int b = N + tid; b < NP; b += nt) { wsCnt[b] = 0; wsCntNew[b] = 0; }
     // pushable objects: pose and velocity live in LDS (pos / vel / objA / objW), thread m integrates object m
     if (tid < M) {
@@ -213,7 +204,8 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
     // manifold-constraint candidate t (object pair / object-wall) is looked after by lane t of wave 0
     bool mcTouch = false;
     float *owsMine = nullptr;
-    for (int c = tid; c < p.nhead; c += nt) head[c] = EMPTY16;
+    if (BINS) { for (int c = tid; c < ldsb::bin_entries(p.nhead) / 2; c += nt) reinterpret_cast<unsigned *>(E1)[c] = 0u; }
+    else for (int c = tid; c < p.nhead; c += nt) head[c] = EMPTY16;
     if (tid == 0) misc[M_STATUS] = 0;
     float lx = 0.0f, ly = 0.0f;
     if (LIGHT_TYPE == KB_LIGHT_CIRCULAR) { lx = g.light_x[e]; ly = g.light_y[e]; }
@@ -239,7 +231,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
     __syncthreads();
     // warm-start list of the previous substep: offsets, and an LDS image of the packed entries if it fits
     unsigned oldTotal = block_scan_u8(wsCnt, wsOff, NP, wsum);
-    bool oldInLds = !COMPACT && oldTotal <= (unsigned)capL_;     // (compact image: the list is read where it lies, in HBM / L2)
+    bool oldInLds = oldTotal <= (unsigned)capL_;
     if (oldInLds) {
         for (unsigned i = tid; i < oldTotal; i += nt) {
             const unsigned k = g.ws_key[wo + i];
@@ -263,13 +255,20 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
         if (p.light_action && LIGHT_TYPE == KB_LIGHT_CIRCULAR && drive)
             kb_light_single_step(p, p.light_action + 2 * e, h, lx, ly);
         // ---- sensing + drive law + damping; grid insertion; reset per-substep scratch ----
+        // sorted bins: position, damped velocity, cell and arrival index in its bin of this thread's kilobots, kept in
+        // registers until the kilobot's slot of this substep is known
+        float sbx[BPT], sby[BPT], svx[BPT], svy[BPT];
+        int scell[BPT], sarr[BPT];       // scell: cx | cy << 12 | walls touched << 24 | outside the wall line << 28
+#define SC_CX(s_) ((s_) & 0xFFF)
+#define SC_CY(s_) (((s_) >> 12) & 0xFFF)
 #pragma unroll
         for (int q = 0; q < BPT; ++q) {
             const int b = tid + q * nt;
+            sbx[q] = 0.0f; sby[q] = 0.0f; svx[q] = 0.0f; svy[q] = 0.0f; scell[q] = 0; sarr[q] = 0;
             if (b >= N) continue;
             float bvx = 0.0f, bvy = 0.0f, bww = 0.0f;
-            const float bx = pos[b].x, by = pos[b].y;
-            if (!COMPACT) { start[b].x = bx; start[b].y = by; }
+            const float bx = pos[KB_SLOT(q, b)].x, by = pos[KB_SLOT(q, b)].y;
+            if (!BINS) { start[b].x = bx; start[b].y = by; }
             sth0[q] = th[q];
             if (drive) {
                 const float t = th[q];
@@ -341,17 +340,27 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
             }
             // b2Island::Solve: v *= 1/(1 + h c)  (SimplePhototaxisKilobot sets linearDamping = 0, kilobot.py:203)
             const float kl = (KB_LAW(q) == KB_DRIVE_SIMPLE_PHOTOTAXIS) ? 1.0f / (1.0f + h * 0.0f) : p.kl_bot;
-            vel[b].x = bvx * kl; vel[b].y = bvy * kl; bw[q] = bww * p.ka_bot;
-            parent[b] = b;
-            // broadphase: push the bot on its cell's list
+            bw[q] = bww * p.ka_bot;
             int cx = (int)floorf((bx - p.xmin) * p.inv_cell);
             int cy = (int)floorf((by - p.ymin) * p.inv_cell);
             cx = cx < 0 ? 0 : (cx >= p.gw ? p.gw - 1 : cx);
             cy = cy < 0 ? 0 : (cy >= p.gh ? p.gh - 1 : cy);
             const int cell = cy * p.gw + cx;
-            cellOf[b] = (unsigned short)cell;
-            nextb[b] = (unsigned short)kb_exch16(head, hix(cell), (unsigned)b);
-            if (SENSE && p.sense_s > 0) newOff[b] = 0;       // (dead until the scan behind the label pass: the neighbour counters of the sensing pass)
+            if (BINS) {
+                // broadphase: count the kilobot into its bin (entry bin + 1 of the boundary array; 16-bit counters, two per word)
+                sbx[q] = bx; sby[q] = by; svx[q] = bvx * kl; svy[q] = bvy * kl; scell[q] = cx | (cy << 12);
+                const int bi = (hashed ? (cell & p.hmask) : cell) + 1;
+                const unsigned old = atomicAdd(reinterpret_cast<unsigned *>(E1) + (bi >> 1), 1u << (16 * (bi & 1)));
+                sarr[q] = (int)((old >> (16 * (bi & 1))) & 0xFFFFu);
+                if (SENSE && p.sense_s > 0) reinterpret_cast<unsigned short *>(lAcc)[b] = 0;   // (dead until the emit pass: the neighbour counters of the sensing pass, by slot)
+            } else {
+                vel[b].x = bvx * kl; vel[b].y = bvy * kl;
+                parent[b] = b;
+                // broadphase: push the bot on its cell's list
+                cellOf[b] = (unsigned short)cell;
+                nextb[b] = (unsigned short)kb_exch16(head, hix(cell), (unsigned)b);
+                if (SENSE && p.sense_s > 0) newOff[b] = 0;       // (dead until the scan behind the label pass: the neighbour counters of the sensing pass)
+            }
         }
         if (tid < M) { start[N + tid].x = pos[N + tid].x; start[N + tid].y = pos[N + tid].y; objA0[tid] = objA[tid]; }
         if (tid < M) {   // b2Island::Solve damping of the objects; they keep their velocity between substeps
@@ -366,142 +375,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
         __syncthreads();
         KB_STAMP(0);
         KB_RETID();
-        // ---- IR-range neighbour sensing (kb_config.sense_radius): at the sensing point of the substep, like the light
-        //      (kilobots_env.py:174-180), off the cell lists that the contact search uses ----
-        if (SENSE && p.sense_s > 0 && drive)
-            kb_sense_pass(pos, head, nextb, cellOf, reinterpret_cast<unsigned *>(newOff), N, nt, tid, p.gw, p.gh, p.sense_s, p.sense_r2, hashed ? p.hmask : 0);
-        // object-object / object-wall manifolds (b2Contact::Update) + their velocity-constraint set-up: candidate t
-        // is lane t of wave 0; the record lives in LDS, the previous substep's impulses come from g.ows_acc
-        if (OBJ && wave == 0) {
-            mcTouch = false;
-            if (lane < NMC) {
-                owsMine = g.ows_acc + (size_t)e * (MAXOBJ * KB_OWS_COLS * KB_OWS_WORDS);
-                Arena ar;
-                ar.xmin = p.xmin; ar.ymin = p.ymin; ar.xmax = p.xmax; ar.ymax = p.ymax;
-                mcTouch = mc_detect(ox, ar, F, lane, owsMine);
-            }
-        }
-
-        // ---- narrowphase pass 1 (thread per bot): find the contacts each bot owns (5-cell half stencil + walls),
-        //      append them to the staging list, count them per direction ----
-        auto find_pass = [&](unsigned *sPair, unsigned *sInfo, int stageCap_) __attribute__((always_inline)) {
-#pragma unroll 1
-            for (int a = tid; a < N; a += nt) {
-                const int cell = cellOf[a];
-                const int cx = cell % p.gw, cy = cell / p.gw;
-                const float ax = pos[a].x, ay = pos[a].y;
-                unsigned cnt = 0, mine = 0;
-                unsigned hd[5];      // heads of the five cell lists, fetched together (one LDS round trip)
-                int tcell[5];        // (hashed heads: the cell a candidate must be in)
-#pragma unroll
-                for (int k = 0; k < 5; ++k) {
-                    const int ox = cx + dir_dx(k), oy = cy + dir_dy(k);
-                    const bool in = ox >= 0 && ox < p.gw && oy < p.gh;
-                    tcell[k] = in ? oy * p.gw + ox : cell;
-                    hd[k] = in ? (unsigned)head[hix(tcell[k])] : (unsigned)EMPTY16;
-                }
-                // the five lists are walked in lockstep: one LDS round trip serves the next candidate of every list that
-                // still has one (lists that have ended re-read the kilobot itself), so the trips of this pass are the
-                // length of the longest list, not the sum of the five
-                unsigned ckk[5] = {0u, 0u, 0u, 0u, 0u};
-                while (hd[0] != (unsigned)EMPTY16 || hd[1] != (unsigned)EMPTY16 || hd[2] != (unsigned)EMPTY16 ||
-                       hd[3] != (unsigned)EMPTY16 || hd[4] != (unsigned)EMPTY16) {
-                    float2 pbk[5];
-                    unsigned nbk[5];
-                    int cbk_[5];
-#pragma unroll
-                    for (int k = 0; k < 5; ++k) {
-                        const unsigned bb = hd[k] != (unsigned)EMPTY16 ? hd[k] : (unsigned)a;
-                        pbk[k] = pos[bb]; nbk[k] = nextb[bb];
-                        cbk_[k] = hashed ? (int)cellOf[bb] : tcell[k];
-                    }
-#pragma unroll
-                    for (int k = 0; k < 5; ++k) {
-                        const unsigned b = hd[k];
-                        if (b == (unsigned)EMPTY16) continue;
-                        if (!(k == 0 && (int)b <= a) && cbk_[k] == tcell[k]) {
-                            const float dx = pbk[k].x - ax, dy = pbk[k].y - ay;
-                            const float dd = dx * dx + dy * dy;
-                            if (!(dd > rr2)) {  // b2CollideCircles
-                                ckk[k]++;
-                                const unsigned c = atomicAdd(&misc[M_NCON], 1u);
-                                if (c < (unsigned)stageCap_) { sPair[c] = (unsigned)a | (b << 16); sInfo[c] = (unsigned)k; }
-                            }
-                        }
-                        hd[k] = nbk[k];
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < 5; ++k) {
-                    unsigned ck = ckk[k];
-                    mine += ck;
-                    if (ck > 63u) { ck = 63u; atomicOr(&misc[M_STATUS], 4u); }
-                    cnt |= ck << (6 * k);
-                }
-                // walls: b2CollideEdgeAndCircle (region AB) against the chain loop of kilobots_env.py:48-51
-#pragma unroll
-                for (int wl = 0; wl < 4; ++wl) {
-                    float dist, nx, ny;
-                    wall_geom(p, wl, ax, ay, dist, nx, ny);
-                    if (dist * dist > rw2) continue;
-                    mine++;
-                    const unsigned c = atomicAdd(&misc[M_NCON], 1u);
-                    // info bits 0-2: 5 + wall; bit 7: centre outside the wall line (manifold normal points outwards)
-                    if (c < (unsigned)stageCap_) {
-                        sPair[c] = (unsigned)(WALL_CODE + wl) | ((unsigned)a << 16);
-                        sInfo[c] = (unsigned)(5 + wl) | (dist < 0.0f ? 0x80u : 0u);
-                    }
-                }
-                // pushable objects: b2CollideCircles / b2CollidePolygonAndCircle kilobot - object m
-                // (info 9 + m; bits 8..: how many lower objects this kilobot touches)
-                unsigned nobj = 0;
-                for (int f = 0; f < F; ++f) {
-                    const float *T = objTab + f * OT_WORDS;
-                    const int m = ot_body(T);
-                    const float dx = pos[N + m].x - ax, dy = pos[N + m].y - ay;
-                    const float ro = p.r_bot + T[OT_BOUND];       // circle: contact radius; polygon: bounding radius
-                    if (dx * dx + dy * dy > ro * ro) continue;
-                    if (T[OT_KIND] != 0.0f) {
-                        V2 ln, lp;
-                        if (!collide_poly_circle(T, body_xf(ox, N + m), mk2(ax, ay), p.r_bot, ln, lp)) continue;
-                    }
-                    mine++;
-                    const unsigned pos = atomicAdd(&objCnt[f], 1u);
-                    if (pos < (unsigned)OBJ_LIST) objList[f * OBJ_LIST + pos] = (unsigned short)a;
-                    else atomicOr(&misc[M_STATUS], 4u);
-                    const unsigned c = atomicAdd(&misc[M_NCON], 1u);
-                    if (c < (unsigned)stageCap_) { sPair[c] = (unsigned)a | ((unsigned)(N + m) << 16); sInfo[c] = (unsigned)(9 + f) | (nobj << 8); }
-                    nobj++;
-                }
-                dirCnt[a] = cnt;
-                if (mine > (unsigned)S) { atomicOr(&misc[M_STATUS], 2u); mine = S; }
-                wsCntNew[a] = (unsigned char)mine;
-            }
-        };
-        bool big = p.solver_mode >= 3;
-        if (!big) {
-            find_pass(lPair, lInfo, capL_);
-            KB_STAMP_PRE(17);
-            __syncthreads();
-            big = (int)misc[M_NCON] > capL_;    // does not fit the LDS staging area: redo into the global scratch slice
-            if (big) {
-                __syncthreads();
-                if (tid == 0) misc[M_NCON] = 0;
-                if (tid < F) objCnt[tid] = 0;
-                __syncthreads();
-            }
-        }
-        if (big) {
-            find_pass(gPair, gInfo, p.cap);
-            __syncthreads();
-        }
-        KB_STAMP(1);
-        KB_RETID();
-        const int stageCap = big ? p.cap : capL_;
-        if ((int)misc[M_NCON] > stageCap && tid == 0) atomicOr(&misc[M_STATUS], 1u);
-        const int ncon = min((int)misc[M_NCON], stageCap);
-
-        // ---- narrowphase pass 2 (thread per contact): class, rank, warm-start slot + impulse, island hooking ----
+        // ---- warm start: impulse of the same pair in the previous substep (b2Contact::Update id match) ----
         auto ws_find = [&](int owner, unsigned key16) __attribute__((always_inline)) -> float {
             const int cnt = wsCnt[owner], off = wsOff[owner];
             if (oldInLds) {
@@ -517,105 +391,414 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
             }
             return -1.0f;   // accumulated impulses are >= 0
         };
-        auto label_pass = [&](unsigned *sPair, unsigned *sInfo, float *sAcc) __attribute__((always_inline)) {
-            if (OBJ && wave == 0 && lane < NMC && mcTouch && mci(ox, MC_A, lane) < WALL_CODE) {   // object - object: one island
-                unsigned ra = (unsigned)mci(ox, MC_A, lane), rb = (unsigned)mci(ox, MC_B, lane);
-                for (;;) {
-                    while (true) { unsigned t = ((volatile unsigned *)parent)[ra]; if (t == ra) break; ra = t; }
-                    while (true) { unsigned t = ((volatile unsigned *)parent)[rb]; if (t == rb) break; rb = t; }
-                    if (ra == rb) break;
-                    if (ra < rb) { unsigned t = ra; ra = rb; rb = t; }
-                    if (atomicCAS(&parent[ra], ra, rb) == ra) break;
+        bool big = false;
+        int stageCap = 0, ncon = 0;
+        unsigned newTotal = 0;        // entries of the packed warm-start list of this substep
+        if constexpr (BINS) {
+            // =============== sorted-bin broadphase + contact emission (kernels without objects) ===============
+            // 1. boundaries of the bins: inclusive scan of the counters (E1[b] .. E1[b + 1] = slots of bin b)
+            {
+                const int nchunks = ldsb::bin_entries(p.nhead) >> 3;
+                if (nchunks <= nt) block_scan_bins<true>(E1, nchunks, 1, wsum);
+                else block_scan_bins<false>(E1, nchunks, (nchunks + nt - 1) / nt, wsum);
+            }
+            // 2. scatter in arrival order ...
+#pragma unroll
+            for (int q = 0; q < BPT; ++q) {
+                const int b = tid + q * nt;
+                if (b >= N) continue;
+                const int cell = SC_CY(scell[q]) * p.gw + SC_CX(scell[q]);
+                const int bin = hashed ? (cell & p.hmask) : cell;
+                tmpSort[(int)E1[bin] + sarr[q]] = (unsigned short)b;
+            }
+            __syncthreads();
+            KB_RETID();
+            // 3. ... and settle every kilobot in its slot: inside a bin by ascending id (the canonical order of the contacts
+            //    is defined on ids).  From here to the end of the substep the kilobot's body lives at index ms[q].
+#pragma unroll
+            for (int q = 0; q < BPT; ++q) {
+                const int b = tid + q * nt;
+                if (b >= N) continue;
+                const int cell = SC_CY(scell[q]) * p.gw + SC_CX(scell[q]);
+                const int bin = hashed ? (cell & p.hmask) : cell;
+                const int s0 = (int)E1[bin], s1 = (int)E1[bin + 1];
+                int rank = 0;
+                if (s1 - s0 > 1)
+                    for (int s_ = s0; s_ < s1; ++s_) rank += ((int)tmpSort[s_] < b) ? 1 : 0;
+                const int sl = s0 + rank;
+                ms[q] = sl;
+                idOf[sl] = (unsigned short)b;
+                if (hashed) cellOfSlot[sl] = (unsigned short)cell;
+                pos[sl] = make_float2(sbx[q], sby[q]);
+                vel[sl] = make_float2(svx[q], svy[q]);
+                parent[sl] = (unsigned)sl;
+            }
+            __syncthreads();
+            KB_STAMP(0);
+            KB_RETID();
+            // ---- IR-range neighbour sensing (kb_config.sense_radius): at the sensing point of the substep, like the light
+            //      (kilobots_env.py:174-180), off the bins that the contact search uses ----
+            if (SENSE && p.sense_s > 0 && drive) {
+#pragma unroll 1
+                for (int q = 0; q < BPT; ++q) {
+                    const int b = tid + q * nt;
+                    if (b >= N) continue;
+                    const int sl = q == 0 ? ms[0] : ms[BPT - 1];
+                    const int sc = q == 0 ? scell[0] : scell[BPT - 1];
+                    if (hashed) kb_sense_bins_hashed(pos, E1, cellOfSlot, reinterpret_cast<unsigned *>(lAcc), sl, SC_CX(sc), SC_CY(sc), p.gw, p.gh, p.sense_s, p.sense_r2, p.hmask);
+                    else kb_sense_bins(pos, E1, reinterpret_cast<unsigned *>(lAcc), sl, SC_CX(sc), SC_CY(sc), p.gw, p.gh, p.sense_s, p.sense_r2);
                 }
             }
-            for (int c = tid; c < ncon; c += nt) {
-                const unsigned pr = sPair[c], inf0 = sInfo[c];
-                const int k = inf0 & 31;
-                int cls, r, slot;
-                unsigned fixbits = 0;
-                float acc;
-                if (k >= 9) {    // kilobot - object m, owned by the kilobot; all of them strictly sequential
-                    const int a = pr & 0xFFFF, m = k - 9;
-                    const float ax = pos[a].x, ay = pos[a].y;
-                    r = 0;
-                    for (int m2 = 0; m2 < m; ++m2) r += (int)min(objCnt[m2], (unsigned)OBJ_LIST);
-                    const int nm_ = (int)min(objCnt[m], (unsigned)OBJ_LIST);
-                    for (int i = 0; i < nm_; ++i) r += (objList[m * OBJ_LIST + i] < a) ? 1 : 0;
-                    const unsigned dc = dirCnt[a];
-                    slot = 0;
-#pragma unroll
-                    for (int k2 = 0; k2 < 5; ++k2) slot += (int)((dc >> (6 * k2)) & 63u);
-#pragma unroll
-                    for (int w2 = 0; w2 < 4; ++w2) {
-                        float dist, nx, ny;
-                        wall_geom(p, w2, ax, ay, dist, nx, ny);
-                        if (!(dist * dist > rw2)) slot++;
-                    }
-                    slot += (int)((inf0 >> 8) & 15u);      // lower objects this kilobot touches (counted by the find pass)
-                    cls = CLS_BOT_OBJ;
-                    acc = ws_find(a, (unsigned)(OBJ_CODE + m));
-                    fixbits = (unsigned)m << 24;      // the fixture travels with the contact (bits 24..27)
-                    unsigned ra = a, rb = pr >> 16;        // the object the fixture belongs to
-                    for (;;) {
-                        while (true) { unsigned t = ((volatile unsigned *)parent)[ra]; if (t == ra) break; ra = t; }
-                        while (true) { unsigned t = ((volatile unsigned *)parent)[rb]; if (t == rb) break; rb = t; }
-                        if (ra == rb) break;
-                        if (ra < rb) { unsigned t = ra; ra = rb; rb = t; }
-                        if (atomicCAS(&parent[ra], ra, rb) == ra) break;
-                    }
-                } else if (k >= 5) {   // wall contact, owned by the bot
-                    const int a = pr >> 16, wl = k - 5;
-                    const float ax = pos[a].x, ay = pos[a].y;
-                    const unsigned dc = dirCnt[a];
-                    int nbots = 0;
-#pragma unroll
-                    for (int k2 = 0; k2 < 5; ++k2) nbots += (int)((dc >> (6 * k2)) & 63u);
-                    r = 0;
-#pragma unroll
-                    for (int w2 = 0; w2 < 3; ++w2) {
-                        float dist, nx, ny;
-                        wall_geom(p, w2, ax, ay, dist, nx, ny);
-                        if (w2 < wl && !(dist * dist > rw2)) r++;
-                    }
-                    cls = CLS_WALL | (int)(inf0 & 0x80u);
-                    slot = nbots + r;
-                    acc = ws_find(a, (unsigned)(WALL_CODE + wl));
+            // ---- narrowphase, pass 1 (thread per kilobot): the contacts the kilobot owns -- touching partners of the half
+            //      stencil (same cell behind it, E, N, NE, NW: contiguous runs of slots) and walls ----
+            // Candidate runs in enumeration order k = 0 .. 4.  Arena-sized grid: three runs, two cells of a grid row each
+            // ([same | E], [N | NE], [NW]); hashed bins: one run per cell.  sp = first slot of the run's second cell.
+            constexpr int NR = FN ? 3 : 5;
+            auto candidate_runs = [&](int sa, int cx, int cy, int (&lo)[NR], int (&hi)[NR], int (&sp)[NR], int (&tc)[5]) __attribute__((always_inline)) {
+                const int gw = p.gw, gh = p.gh;
+                const int cell = cy * gw + cx;
+                const bool e_ok = cx + 1 < gw, n_ok = cy + 1 < gh, w_ok = cx > 0;
+                tc[0] = cell; tc[1] = cell + 1; tc[2] = cell + gw; tc[3] = cell + gw + 1; tc[4] = cell + gw - 1;
+                if constexpr (NR == 3) {
+                    const int up = cell + gw;
+                    const int e1 = (int)E1[cell + 1], e2 = (int)E1[e_ok ? cell + 2 : cell + 1];
+                    const int u0 = (int)E1[n_ok ? (w_ok ? up - 1 : up) : 0], u1 = (int)E1[n_ok ? up : 0];
+                    const int u2 = (int)E1[n_ok ? up + 1 : 0], u3 = (int)E1[n_ok ? (e_ok ? up + 2 : up + 1) : 0];
+                    lo[0] = sa + 1; sp[0] = e1; hi[0] = e2;
+                    lo[1] = u1; sp[1] = u2; hi[1] = u3;
+                    lo[2] = u0; sp[2] = u1; hi[2] = u1;
                 } else {
-                    const int a = pr & 0xFFFF;
-                    const unsigned b = pr >> 16;
+                    const bool ok[5] = {true, e_ok, n_ok, n_ok && e_ok, n_ok && w_ok};
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) {
+                        const int bin = hashed ? (tc[k] & p.hmask) : tc[k];
+                        const int l_ = ok[k] ? (int)E1[bin] : 0, h_ = ok[k] ? (int)E1[bin + 1] : 0;
+                        lo[k] = k == 0 ? sa + 1 : l_; hi[k] = h_; sp[k] = h_;
+                    }
+                }
+            };
+            // every touching partner of the kilobot at slot sa, in enumeration order: cb(slot, k)
+            auto for_partners = [&](int sa, int cx, int cy, auto &&cb) __attribute__((always_inline)) {
+                int lo[NR], hi[NR], sp[NR], tc[5];
+                candidate_runs(sa, cx, cy, lo, hi, sp, tc);
+                int pre[NR + 1];
+                pre[0] = 0;
+#pragma unroll
+                for (int r = 0; r < NR; ++r) pre[r + 1] = pre[r] + max(hi[r] - lo[r], 0);
+                const int tot = pre[NR];
+                const float2 pa = pos[sa];
+                constexpr int BATCH = 4;      // candidates fetched together (one LDS round trip)
+                for (int base = 0; base < tot; base += BATCH) {
+                    int cs[BATCH], ck[BATCH];
+                    float2 cp[BATCH];
+                    int cc[BATCH];
+#pragma unroll
+                    for (int u = 0; u < BATCH; ++u) {
+                        const int i = base + u;
+                        int sl = lo[0] + i, spl = sp[0], kb_ = 0;
+#pragma unroll
+                        for (int r = 1; r < NR; ++r)
+                            if (i >= pre[r]) { sl = lo[r] + (i - pre[r]); spl = sp[r]; kb_ = NR == 3 ? 2 * r : r; }
+                        ck[u] = kb_ + ((NR == 3 && sl >= spl) ? 1 : 0);
+                        cs[u] = i < tot ? sl : sa;
+                        cp[u] = pos[cs[u]];
+                        cc[u] = hashed ? (int)cellOfSlot[cs[u]] : 0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < BATCH; ++u) {
+                        const float dx = cp[u].x - pa.x, dy = cp[u].y - pa.y;
+                        const float dd = dx * dx + dy * dy;
+                        bool hit = base + u < tot && !(dd > rr2);      // b2CollideCircles
+                        if (hashed) {
+                            int want = tc[0];
+#pragma unroll
+                            for (int k = 1; k < 5; ++k) if (ck[u] == k) want = tc[k];
+                            hit = hit && cc[u] == want;
+                        }
+                        if (hit) cb(cs[u], ck[u]);
+                    }
+                }
+            };
+            unsigned pl0[BPT], pl1[BPT];      // the first four partners of a kilobot: slot | k << 12, 16 bits each
+#pragma unroll
+            for (int q = 0; q < BPT; ++q) {
+                const int b = tid + q * nt;
+                pl0[q] = 0u; pl1[q] = 0u;
+                if (b >= N) continue;
+                const int sa = ms[q];
+                unsigned cnt = 0, nbb = 0, l0 = 0u, l1 = 0u;
+                for_partners(sa, SC_CX(scell[q]), SC_CY(scell[q]), [&](int sl, int k) __attribute__((always_inline)) {
+                    const unsigned e16 = (unsigned)sl | ((unsigned)k << 12);
+                    if (nbb < 2u) l0 |= e16 << (16u * nbb);
+                    else if (nbb < 4u) l1 |= e16 << (16u * (nbb - 2u));
+                    nbb++;
+                    if (((cnt >> (6 * k)) & 63u) == 63u) atomicOr(&misc[M_STATUS], 4u);
+                    else cnt += 1u << (6 * k);
+                });
+                pl0[q] = l0; pl1[q] = l1;
+                // walls: b2CollideEdgeAndCircle (region AB) against the chain loop of kilobots_env.py:48-51
+                unsigned wm = 0u;
+                const float ax = pos[sa].x, ay = pos[sa].y;
+#pragma unroll
+                for (int wl = 0; wl < 4; ++wl) {
+                    float dist, nx, ny;
+                    wall_geom(p, wl, ax, ay, dist, nx, ny);
+                    if (dist * dist > rw2) continue;
+                    wm |= (1u << wl) | (dist < 0.0f ? 16u << wl : 0u);     // (bit 4 + wl: centre outside the wall line, the manifold normal points outwards)
+                }
+                scell[q] |= (int)(wm << 24);
+                unsigned mine = nbb + (unsigned)__popc(wm & 15u);
+                dirCnt[sa] = cnt;
+                if (mine > (unsigned)S) { atomicOr(&misc[M_STATUS], 2u); atomicAdd(&misc[M_XTRA], mine - (unsigned)S); mine = S; }
+                wsCntNew[b] = (unsigned char)mine;
+            }
+            KB_STAMP_PRE(17);
+            __syncthreads();
+            // 4. offsets of the new packed warm-start list = where the contacts are staged
+            newTotal = block_scan_u8(wsCntNew, newOff, NP, wsum);   // (barriers inside)
+            KB_STAMP(1);
+            KB_RETID();
+            if (SENSE && p.sense_s > 0 && drive) {      // the neighbour counters lie where the emit pass stages the impulses
+#pragma unroll
+                for (int q = 0; q < BPT; ++q) {
+                    const int b = tid + q * nt;
+                    if (b < N) g.nbr_count[o + b] = (unsigned)reinterpret_cast<unsigned short *>(lAcc)[ms[q]];
+                }
+                __syncthreads();
+            }
+            const unsigned extras = misc[M_XTRA];      // contacts beyond the warm-start slots of their owner: solved, never stored
+            const int capS = FN ? capL_ : min(capL_, p.cap);      // (a contact_capacity below the LDS staging area still bounds the list)
+            big = p.solver_mode >= 3 || newTotal + extras > (unsigned)capS;
+            stageCap = big ? p.cap : capS;
+            if (newTotal + extras > (unsigned)stageCap && tid == 0) atomicOr(&misc[M_STATUS], 1u);
+            ncon = (int)min(newTotal + extras, (unsigned)stageCap);
+            // ---- narrowphase, pass 2 (the owner's thread): class, rank, impulse of the same pair in the previous substep,
+            //      island hooking; contact j of owner a is staged at newOff[a] + j, its position in the packed list ----
+            unsigned *sPair = big ? gPair : lPair, *sInfo = big ? gInfo : lInfo;
+            float *sAcc = big ? gAcc : lAcc;
+#pragma unroll
+            for (int q = 0; q < BPT; ++q) {
+                const int b = tid + q * nt;
+                if (b >= N) continue;
+                const int sa = ms[q], cx = SC_CX(scell[q]), cy = SC_CY(scell[q]);
+                const unsigned dc = dirCnt[sa];
+                unsigned nbb = 0;
+#pragma unroll
+                for (int k = 0; k < 5; ++k) nbb += (dc >> (6 * k)) & 63u;
+                const unsigned wm = (unsigned)scell[q] >> 24;
+                if (nbb + (wm & 15u) == 0u) continue;
+                const unsigned base = newOff[b], nst = wsCntNew[b];
+                // rank base of the (cell, direction) groups: contacts of the group owned by the kilobots of the cell in front of this one
+                unsigned rbE = 0u, rbO = 0u;      // fields k = 0, 2, 4 / k = 1, 3 at 12-bit spacing
+                {
+                    const int cell = cy * p.gw + cx;
+                    const int s0 = (int)E1[hashed ? (cell & p.hmask) : cell];
+                    for (int s_ = s0; s_ < sa; ++s_) {
+                        if (hashed && (int)cellOfSlot[s_] != cell) continue;
+                        const unsigned d2 = dirCnt[s_];
+                        rbE += d2 & 0x3F03F03Fu; rbO += (d2 >> 6) & 0x0003F03Fu;
+                    }
+                }
+                int curk = -1, jk = 0;
+                const unsigned ntot = nbb + (unsigned)__popc(wm & 15u);
+                unsigned wleft = wm & 15u;
+                for (unsigned j = 0; j < ntot; ++j) {
+                    unsigned pr, key16;
+                    int cls, r;
+                    float acc;
+                    if (j < nbb) {
+                        int sb_ = 0, k = 0;
+                        if (j < 4u) {
+                            const unsigned e16 = ((j < 2u ? pl0[q] : pl1[q]) >> (16u * (j & 1u))) & 0xFFFFu;
+                            sb_ = (int)(e16 & 0xFFFu); k = (int)(e16 >> 12);
+                        } else {          // (a dense pile: walk the candidates again up to partner j)
+                            unsigned idx = 0;
+                            for_partners(sa, cx, cy, [&](int sl, int kk) __attribute__((always_inline)) { if (idx == j) { sb_ = sl; k = kk; } idx++; });
+                        }
+                        if (k != curk) { curk = k; jk = 0; } else jk++;
+                        if (k == 0) cls = CLS_SAME;
+                        else if (k == 1) cls = CLS_E + (cx & 1);
+                        else if (k == 2) cls = CLS_N + (cy & 1);
+                        else if (k == 3) cls = CLS_NE + (cx & 1);
+                        else cls = CLS_NW + (cx & 1);
+                        const unsigned rb_ = (k & 1) ? (rbO >> (12 * (k >> 1))) & 0xFFFu : (rbE >> (12 * (k >> 1))) & 0xFFFu;
+                        r = (int)rb_ + jk;
+                        const unsigned idb = idOf[sb_];
+                        acc = ws_find(b, idb);
+                        if (acc < 0.0f) acc = ws_find((int)idb, (unsigned)b);
+                        pr = (unsigned)sa | ((unsigned)sb_ << 16);
+                        key16 = idb;
+                        // island hooking: larger root goes under the smaller one
+                        unsigned ra = (unsigned)sa, rb = (unsigned)sb_;
+                        for (;;) {
+                            while (true) { unsigned t = ((volatile unsigned *)parent)[ra]; if (t == ra) break; ra = t; }
+                            while (true) { unsigned t = ((volatile unsigned *)parent)[rb]; if (t == rb) break; rb = t; }
+                            if (ra == rb) break;
+                            if (ra < rb) { unsigned t = ra; ra = rb; rb = t; }
+                            if (atomicCAS(&parent[ra], ra, rb) == ra) break;
+                        }
+                    } else {              // wall contact, owned by the kilobot: rank = lower walls it touches
+                        const int wl = __builtin_ctz(wleft);
+                        wleft &= wleft - 1u;
+                        r = __popc(wm & ((1u << wl) - 1u) & 15u);
+                        cls = CLS_WALL | (((wm >> (4 + wl)) & 1u) ? 0x80 : 0);
+                        key16 = (unsigned)(WALL_CODE + wl);
+                        acc = ws_find(b, key16);
+                        pr = key16 | ((unsigned)sa << 16);
+                    }
+                    if (acc < 0.0f) acc = 0.0f;
+                    if (r > 255) { r = 255; atomicOr(&misc[M_STATUS], 4u); }
+                    const unsigned cid = j < nst ? base + j : newTotal + atomicAdd(&misc[M_XFILL], 1u);
+                    if (cid >= (unsigned)stageCap) continue;
+                    sPair[cid] = pr;
+                    sInfo[cid] = (unsigned)cls | ((unsigned)r << 8) | (key16 << 16);
+                    sAcc[cid] = acc;
+                }
+            }
+            KB_STAMP_PRE(18);
+            __syncthreads();
+            KB_STAMP(2);
+            KB_RETID();
+        } else {
+            // ---- IR-range neighbour sensing (kb_config.sense_radius): at the sensing point of the substep, like the light
+            //      (kilobots_env.py:174-180), off the cell lists that the contact search uses ----
+            if (SENSE && p.sense_s > 0 && drive)
+                kb_sense_pass(pos, head, nextb, cellOf, reinterpret_cast<unsigned *>(newOff), N, nt, tid, p.gw, p.gh, p.sense_s, p.sense_r2, hashed ? p.hmask : 0);
+            // object-object / object-wall manifolds (b2Contact::Update) + their velocity-constraint set-up: candidate t
+            // is lane t of wave 0; the record lives in LDS, the previous substep's impulses come from g.ows_acc
+            if (OBJ && wave == 0) {
+                mcTouch = false;
+                if (lane < NMC) {
+                    owsMine = g.ows_acc + (size_t)e * (MAXOBJ * KB_OWS_COLS * KB_OWS_WORDS);
+                    Arena ar;
+                    ar.xmin = p.xmin; ar.ymin = p.ymin; ar.xmax = p.xmax; ar.ymax = p.ymax;
+                    mcTouch = mc_detect(ox, ar, F, lane, owsMine);
+                }
+            }
+
+            // ---- narrowphase pass 1 (thread per bot): find the contacts each bot owns (5-cell half stencil + walls),
+            //      append them to the staging list, count them per direction ----
+            auto find_pass = [&](unsigned *sPair, unsigned *sInfo, int stageCap_) __attribute__((always_inline)) {
+#pragma unroll 1
+                for (int a = tid; a < N; a += nt) {
                     const int cell = cellOf[a];
                     const int cx = cell % p.gw, cy = cell / p.gw;
                     const float ax = pos[a].x, ay = pos[a].y;
-                    if (k == 0) cls = CLS_SAME;
-                    else if (k == 1) cls = CLS_E + (cx & 1);
-                    else if (k == 2) cls = CLS_N + (cy & 1);
-                    else if (k == 3) cls = CLS_NE + (cx & 1);
-                    else cls = CLS_NW + (cx & 1);
-                    const unsigned dc = dirCnt[a];
-                    int sbase = 0;
-                    for (int k2 = 0; k2 < k; ++k2) sbase += (int)((dc >> (6 * k2)) & 63u);
-                    // rank base: contacts of this (cell, direction) group owned by lower-id bots of the cell
-                    int rbase = 0;
-                    for (unsigned a2 = head[hix(cell)]; a2 != (unsigned)EMPTY16; a2 = nextb[a2])
-                        if ((int)a2 < a && (!hashed || (int)cellOf[a2] == cell)) rbase += (int)((dirCnt[a2] >> (6 * k)) & 63u);
-                    // position of b among a's touching partners of this direction, in ascending id order
-                    int j = 0;
-                    if (((dc >> (6 * k)) & 63u) > 1u) {
-                        const int oc = (cy + dir_dy(k)) * p.gw + (cx + dir_dx(k));
-                        for (unsigned b2 = head[hix(oc)]; b2 != (unsigned)EMPTY16; b2 = nextb[b2]) {
-                            if (b2 >= b || (k == 0 && (int)b2 <= a) || (hashed && (int)cellOf[b2] != oc)) continue;
-                            const float2 pb2 = pos[b2];
-                            const float ex = pb2.x - ax, ey = pb2.y - ay;
-                            if (!(ex * ex + ey * ey > rr2)) j++;
+                    unsigned cnt = 0, mine = 0;
+                    unsigned hd[5];      // heads of the five cell lists, fetched together (one LDS round trip)
+                    int tcell[5];        // (hashed heads: the cell a candidate must be in)
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) {
+                        const int ox = cx + dir_dx(k), oy = cy + dir_dy(k);
+                        const bool in = ox >= 0 && ox < p.gw && oy < p.gh;
+                        tcell[k] = in ? oy * p.gw + ox : cell;
+                        hd[k] = in ? (unsigned)head[hix(tcell[k])] : (unsigned)EMPTY16;
+                    }
+                    // the five lists are walked in lockstep: one LDS round trip serves the next candidate of every list that
+                    // still has one (lists that have ended re-read the kilobot itself), so the trips of this pass are the
+                    // length of the longest list, not the sum of the five
+                    unsigned ckk[5] = {0u, 0u, 0u, 0u, 0u};
+                    while (hd[0] != (unsigned)EMPTY16 || hd[1] != (unsigned)EMPTY16 || hd[2] != (unsigned)EMPTY16 ||
+                           hd[3] != (unsigned)EMPTY16 || hd[4] != (unsigned)EMPTY16) {
+                        float2 pbk[5];
+                        unsigned nbk[5];
+                        int cbk_[5];
+#pragma unroll
+                        for (int k = 0; k < 5; ++k) {
+                            const unsigned bb = hd[k] != (unsigned)EMPTY16 ? hd[k] : (unsigned)a;
+                            pbk[k] = pos[bb]; nbk[k] = nextb[bb];
+                            cbk_[k] = hashed ? (int)cellOf[bb] : tcell[k];
+                        }
+#pragma unroll
+                        for (int k = 0; k < 5; ++k) {
+                            const unsigned b = hd[k];
+                            if (b == (unsigned)EMPTY16) continue;
+                            if (!(k == 0 && (int)b <= a) && cbk_[k] == tcell[k]) {
+                                const float dx = pbk[k].x - ax, dy = pbk[k].y - ay;
+                                const float dd = dx * dx + dy * dy;
+                                if (!(dd > rr2)) {  // b2CollideCircles
+                                    ckk[k]++;
+                                    const unsigned c = atomicAdd(&misc[M_NCON], 1u);
+                                    if (c < (unsigned)stageCap_) { sPair[c] = (unsigned)a | (b << 16); sInfo[c] = (unsigned)k; }
+                                }
+                            }
+                            hd[k] = nbk[k];
                         }
                     }
-                    r = rbase + j;
-                    slot = sbase + j;
-                    // warm start: impulse of the same pair in the previous substep (b2Contact::Update id match)
-                    acc = ws_find(a, b);
-                    if (acc < 0.0f) acc = ws_find((int)b, (unsigned)a);
-                    // island hooking: larger root goes under the smaller one
-                    unsigned ra = a, rb = b;
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) {
+                        unsigned ck = ckk[k];
+                        mine += ck;
+                        if (ck > 63u) { ck = 63u; atomicOr(&misc[M_STATUS], 4u); }
+                        cnt |= ck << (6 * k);
+                    }
+                    // walls: b2CollideEdgeAndCircle (region AB) against the chain loop of kilobots_env.py:48-51
+#pragma unroll
+                    for (int wl = 0; wl < 4; ++wl) {
+                        float dist, nx, ny;
+                        wall_geom(p, wl, ax, ay, dist, nx, ny);
+                        if (dist * dist > rw2) continue;
+                        mine++;
+                        const unsigned c = atomicAdd(&misc[M_NCON], 1u);
+                        // info bits 0-2: 5 + wall; bit 7: centre outside the wall line (manifold normal points outwards)
+                        if (c < (unsigned)stageCap_) {
+                            sPair[c] = (unsigned)(WALL_CODE + wl) | ((unsigned)a << 16);
+                            sInfo[c] = (unsigned)(5 + wl) | (dist < 0.0f ? 0x80u : 0u);
+                        }
+                    }
+                    // pushable objects: b2CollideCircles / b2CollidePolygonAndCircle kilobot - object m
+                    // (info 9 + m; bits 8..: how many lower objects this kilobot touches)
+                    unsigned nobj = 0;
+                    for (int f = 0; f < F; ++f) {
+                        const float *T = objTab + f * OT_WORDS;
+                        const int m = ot_body(T);
+                        const float dx = pos[N + m].x - ax, dy = pos[N + m].y - ay;
+                        const float ro = p.r_bot + T[OT_BOUND];       // circle: contact radius; polygon: bounding radius
+                        if (dx * dx + dy * dy > ro * ro) continue;
+                        if (T[OT_KIND] != 0.0f) {
+                            V2 ln, lp;
+                            if (!collide_poly_circle(T, body_xf(ox, N + m), mk2(ax, ay), p.r_bot, ln, lp)) continue;
+                        }
+                        mine++;
+                        const unsigned pos = atomicAdd(&objCnt[f], 1u);
+                        if (pos < (unsigned)OBJ_LIST) objList[f * OBJ_LIST + pos] = (unsigned short)a;
+                        else atomicOr(&misc[M_STATUS], 4u);
+                        const unsigned c = atomicAdd(&misc[M_NCON], 1u);
+                        if (c < (unsigned)stageCap_) { sPair[c] = (unsigned)a | ((unsigned)(N + m) << 16); sInfo[c] = (unsigned)(9 + f) | (nobj << 8); }
+                        nobj++;
+                    }
+                    dirCnt[a] = cnt;
+                    if (mine > (unsigned)S) { atomicOr(&misc[M_STATUS], 2u); mine = S; }
+                    wsCntNew[a] = (unsigned char)mine;
+                }
+            };
+            big = p.solver_mode >= 3;
+            if (!big) {
+                find_pass(lPair, lInfo, capL_);
+                KB_STAMP_PRE(17);
+                __syncthreads();
+                big = (int)misc[M_NCON] > capL_;    // does not fit the LDS staging area: redo into the global scratch slice
+                if (big) {
+                    __syncthreads();
+                    if (tid == 0) misc[M_NCON] = 0;
+                    if (tid < F) objCnt[tid] = 0;
+                    __syncthreads();
+                }
+            }
+            if (big) {
+                find_pass(gPair, gInfo, p.cap);
+                __syncthreads();
+            }
+            KB_STAMP(1);
+            KB_RETID();
+            stageCap = big ? p.cap : capL_;
+            if ((int)misc[M_NCON] > stageCap && tid == 0) atomicOr(&misc[M_STATUS], 1u);
+            ncon = min((int)misc[M_NCON], stageCap);
+
+            // ---- narrowphase pass 2 (thread per contact): class, rank, warm-start slot + impulse, island hooking ----
+            auto label_pass = [&](unsigned *sPair, unsigned *sInfo, float *sAcc) __attribute__((always_inline)) {
+                if (OBJ && wave == 0 && lane < NMC && mcTouch && mci(ox, MC_A, lane) < WALL_CODE) {   // object - object: one island
+                    unsigned ra = (unsigned)mci(ox, MC_A, lane), rb = (unsigned)mci(ox, MC_B, lane);
                     for (;;) {
                         while (true) { unsigned t = ((volatile unsigned *)parent)[ra]; if (t == ra) break; ra = t; }
                         while (true) { unsigned t = ((volatile unsigned *)parent)[rb]; if (t == rb) break; rb = t; }
@@ -624,18 +807,116 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                         if (atomicCAS(&parent[ra], ra, rb) == ra) break;
                     }
                 }
-                if (acc < 0.0f) acc = 0.0f;
-                if (slot >= S) slot = 255;
-                if (r > 255) { r = 255; atomicOr(&misc[M_STATUS], 4u); }
-                sInfo[c] = (unsigned)cls | ((unsigned)r << 8) | ((unsigned)slot << 16) | fixbits;
-                sAcc[c] = acc;
-            }
-        };
-        if (big) label_pass(gPair, gInfo, gAcc); else label_pass(lPair, lInfo, lAcc);
-        KB_STAMP_PRE(18);
-        __syncthreads();
-        KB_STAMP(2);
-        KB_RETID();
+                for (int c = tid; c < ncon; c += nt) {
+                    const unsigned pr = sPair[c], inf0 = sInfo[c];
+                    const int k = inf0 & 31;
+                    int cls, r, slot;
+                    unsigned fixbits = 0;
+                    float acc;
+                    if (k >= 9) {    // kilobot - object m, owned by the kilobot; all of them strictly sequential
+                        const int a = pr & 0xFFFF, m = k - 9;
+                        const float ax = pos[a].x, ay = pos[a].y;
+                        r = 0;
+                        for (int m2 = 0; m2 < m; ++m2) r += (int)min(objCnt[m2], (unsigned)OBJ_LIST);
+                        const int nm_ = (int)min(objCnt[m], (unsigned)OBJ_LIST);
+                        for (int i = 0; i < nm_; ++i) r += (objList[m * OBJ_LIST + i] < a) ? 1 : 0;
+                        const unsigned dc = dirCnt[a];
+                        slot = 0;
+#pragma unroll
+                        for (int k2 = 0; k2 < 5; ++k2) slot += (int)((dc >> (6 * k2)) & 63u);
+#pragma unroll
+                        for (int w2 = 0; w2 < 4; ++w2) {
+                            float dist, nx, ny;
+                            wall_geom(p, w2, ax, ay, dist, nx, ny);
+                            if (!(dist * dist > rw2)) slot++;
+                        }
+                        slot += (int)((inf0 >> 8) & 15u);      // lower objects this kilobot touches (counted by the find pass)
+                        cls = CLS_BOT_OBJ;
+                        acc = ws_find(a, (unsigned)(OBJ_CODE + m));
+                        fixbits = (unsigned)m << 24;      // the fixture travels with the contact (bits 24..27)
+                        unsigned ra = a, rb = pr >> 16;        // the object the fixture belongs to
+                        for (;;) {
+                            while (true) { unsigned t = ((volatile unsigned *)parent)[ra]; if (t == ra) break; ra = t; }
+                            while (true) { unsigned t = ((volatile unsigned *)parent)[rb]; if (t == rb) break; rb = t; }
+                            if (ra == rb) break;
+                            if (ra < rb) { unsigned t = ra; ra = rb; rb = t; }
+                            if (atomicCAS(&parent[ra], ra, rb) == ra) break;
+                        }
+                    } else if (k >= 5) {   // wall contact, owned by the bot
+                        const int a = pr >> 16, wl = k - 5;
+                        const float ax = pos[a].x, ay = pos[a].y;
+                        const unsigned dc = dirCnt[a];
+                        int nbots = 0;
+#pragma unroll
+                        for (int k2 = 0; k2 < 5; ++k2) nbots += (int)((dc >> (6 * k2)) & 63u);
+                        r = 0;
+#pragma unroll
+                        for (int w2 = 0; w2 < 3; ++w2) {
+                            float dist, nx, ny;
+                            wall_geom(p, w2, ax, ay, dist, nx, ny);
+                            if (w2 < wl && !(dist * dist > rw2)) r++;
+                        }
+                        cls = CLS_WALL | (int)(inf0 & 0x80u);
+                        slot = nbots + r;
+                        acc = ws_find(a, (unsigned)(WALL_CODE + wl));
+                    } else {
+                        const int a = pr & 0xFFFF;
+                        const unsigned b = pr >> 16;
+                        const int cell = cellOf[a];
+                        const int cx = cell % p.gw, cy = cell / p.gw;
+                        const float ax = pos[a].x, ay = pos[a].y;
+                        if (k == 0) cls = CLS_SAME;
+                        else if (k == 1) cls = CLS_E + (cx & 1);
+                        else if (k == 2) cls = CLS_N + (cy & 1);
+                        else if (k == 3) cls = CLS_NE + (cx & 1);
+                        else cls = CLS_NW + (cx & 1);
+                        const unsigned dc = dirCnt[a];
+                        int sbase = 0;
+                        for (int k2 = 0; k2 < k; ++k2) sbase += (int)((dc >> (6 * k2)) & 63u);
+                        // rank base: contacts of this (cell, direction) group owned by lower-id bots of the cell
+                        int rbase = 0;
+                        for (unsigned a2 = head[hix(cell)]; a2 != (unsigned)EMPTY16; a2 = nextb[a2])
+                            if ((int)a2 < a && (!hashed || (int)cellOf[a2] == cell)) rbase += (int)((dirCnt[a2] >> (6 * k)) & 63u);
+                        // position of b among a's touching partners of this direction, in ascending id order
+                        int j = 0;
+                        if (((dc >> (6 * k)) & 63u) > 1u) {
+                            const int oc = (cy + dir_dy(k)) * p.gw + (cx + dir_dx(k));
+                            for (unsigned b2 = head[hix(oc)]; b2 != (unsigned)EMPTY16; b2 = nextb[b2]) {
+                                if (b2 >= b || (k == 0 && (int)b2 <= a) || (hashed && (int)cellOf[b2] != oc)) continue;
+                                const float2 pb2 = pos[b2];
+                                const float ex = pb2.x - ax, ey = pb2.y - ay;
+                                if (!(ex * ex + ey * ey > rr2)) j++;
+                            }
+                        }
+                        r = rbase + j;
+                        slot = sbase + j;
+                        // warm start: impulse of the same pair in the previous substep (b2Contact::Update id match)
+                        acc = ws_find(a, b);
+                        if (acc < 0.0f) acc = ws_find((int)b, (unsigned)a);
+                        // island hooking: larger root goes under the smaller one
+                        unsigned ra = a, rb = b;
+                        for (;;) {
+                            while (true) { unsigned t = ((volatile unsigned *)parent)[ra]; if (t == ra) break; ra = t; }
+                            while (true) { unsigned t = ((volatile unsigned *)parent)[rb]; if (t == rb) break; rb = t; }
+                            if (ra == rb) break;
+                            if (ra < rb) { unsigned t = ra; ra = rb; rb = t; }
+                            if (atomicCAS(&parent[ra], ra, rb) == ra) break;
+                        }
+                    }
+                    if (acc < 0.0f) acc = 0.0f;
+                    if (slot >= S) slot = 255;
+                    if (r > 255) { r = 255; atomicOr(&misc[M_STATUS], 4u); }
+                    sInfo[c] = (unsigned)cls | ((unsigned)r << 8) | ((unsigned)slot << 16) | fixbits;
+                    sAcc[c] = acc;
+                }
+            };
+            if (big) label_pass(gPair, gInfo, gAcc); else label_pass(lPair, lInfo, lAcc);
+            KB_STAMP_PRE(18);
+            __syncthreads();
+            KB_STAMP(2);
+            KB_RETID();
+
+        }
 
         // ---- islands: flatten roots; empty the grid for the next substep; offsets of the new ws list ----
         for (int b = tid; b < N; b += nt) {
@@ -644,10 +925,10 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
             parent[b] = r;   // only ever replaces an ancestor by an older ancestor: concurrent walks stay valid
             islCnt[b] = 0;
             islWave[b] = (unsigned char)((unsigned)b % (unsigned)nw);
-            if (!COMPACT) head[hix(cellOf[b])] = EMPTY16;     // (compact image: the area becomes the bucket tables; cleared at the end)
+            if (!BINS) head[hix(cellOf[b])] = EMPTY16;
             if (!SLEEP) active[b] = 1;
             active[NB + b] = 0;
-            if (SENSE && p.sense_s > 0 && drive) g.nbr_count[o + b] = (unsigned)newOff[b];
+            if (!BINS && SENSE && p.sense_s > 0 && drive) g.nbr_count[o + b] = (unsigned)newOff[b];
         }
         if (tid < 64) bkStart[tid] = 0;     // size-class counters of the island placement
         if (tid < 32) bkFill[tid] = 0;
@@ -667,12 +948,14 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
 #pragma unroll
             for (int q = 0; q < BPT; ++q) {
                 const int b = tid + q * nt;
-                if (b < N && !(slp[q] < 0.0f)) active[parent[b]] = 1;
+                if (b < N && !(slp[q] < 0.0f)) active[parent[KB_SLOT(q, b)]] = 1;
             }
             if (tid < M && !(objSlp[tid] < 0.0f)) active[parent[N + tid]] = 1;
         }
-        const unsigned newTotal = block_scan_u8(wsCntNew, newOff, NP, wsum);   // (barriers inside)
-        const bool newInLds = !COMPACT && newTotal <= (unsigned)capL_;
+        if (BINS) __syncthreads();
+        else newTotal = block_scan_u8(wsCntNew, newOff, NP, wsum);   // (barriers inside)
+        // is the new packed list kept as an LDS image for the next substep's lookups (sorted bins: the staged contacts ARE the list)
+        const bool newInLds = BINS ? !big : newTotal <= (unsigned)capL_;
         if (OBJ && wave == 0) {   // island of every manifold constraint
             unsigned root = 0;
             const bool on = lane < NMC && mcTouch;
@@ -1231,6 +1514,10 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
             const bool last = sub == p.n_substeps - 1;
 #pragma unroll
             for (int j = 0; j < KREG; ++j) {
+                if (BINS) {      // the contact is staged at its position in the packed list: the list goes out as a whole at the end of the substep
+                    if (rvalid[j]) lAcc[rc[j]] = racc[j];
+                    continue;
+                }
                 if (!rvalid[j] || rslot[j] == 255) continue;
                 const int a = ra[j], b = rb[j];
                 const int owner = a < WALL_CODE ? a : b;
@@ -1247,10 +1534,11 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
             // integrate positions (b2Island::Solve)
 #pragma unroll
             for (int q = 0; q < BPT; ++q) {
-                const int b = tid + q * nt;
-                if (b >= N) continue;
+                const int b_ = tid + q * nt;
+                if (b_ >= N) continue;
+                const int b = KB_SLOT(q, b_);
                 float vxx = vel[b].x, vyy = vel[b].y, ww = bw[q];
-                if (COMPACT) { startX[b] = pos[b].x; startY[b] = pos[b].y; }     // pose at the start of the substep (continuous step)
+                if (BINS) { startX[b] = pos[b].x; startY[b] = pos[b].y; }     // pose at the start of the substep (continuous step)
                 const float tx = h * vxx, ty = h * vyy;
                 if (tx * tx + ty * ty > B2_MAX_TRANSLATION_SQ) {
                     const float ratio = B2_MAX_TRANSLATION / sqrtf(tx * tx + ty * ty);
@@ -1615,7 +1903,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                 mc_store();
                 // StoreImpulses -> packed warm-start list of the next substep
                 const bool last = sub == p.n_substeps - 1;
-                for (int c = tid; c < ncon; c += nt) {
+                for (int c = tid; c < (BINS ? 0 : ncon); c += nt) {      // (sorted bins: the staged contacts are the packed list; it goes out at the end of the substep)
                     const unsigned inf = sInfo[c];
                     const int sl = (inf >> 16) & 0xFF;
                     if (sl == 255) continue;
@@ -1636,10 +1924,11 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                 // integrate positions (b2Island::Solve)
 #pragma unroll
                 for (int q = 0; q < BPT; ++q) {
-                    const int b = tid + q * nt;
-                    if (b >= N) continue;
+                    const int b_ = tid + q * nt;
+                    if (b_ >= N) continue;
+                    const int b = KB_SLOT(q, b_);
                     float vxx = vel[b].x, vyy = vel[b].y, ww = bw[q];
-                    if (COMPACT) { startX[b] = pos[b].x; startY[b] = pos[b].y; }
+                    if (BINS) { startX[b] = pos[b].x; startY[b] = pos[b].y; }
                     const float tx = h * vxx, ty = h * vyy;
                     if (tx * tx + ty * ty > B2_MAX_TRANSLATION_SQ) {
                         const float ratio = B2_MAX_TRANSLATION / sqrtf(tx * tx + ty * ty);
@@ -1777,14 +2066,16 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
             // the velocities.  Bodies of an awake island that were asleep have been woken by it (b2World::Solve).
             // Per island: minimum of the sleep times (non-negative floats order like their bit patterns) in the contact
             // staging area, which is idle between the position sweeps and the continuous step (2 capL >= NB words).
-            unsigned *islMin = lPair;
+            // (sorted-bin image: wherever NB words are idle by now -- the bin boundaries or the staged pairs, kb_create decides)
+            unsigned *islMin = BINS ? reinterpret_cast<unsigned *>(smem + (FN ? ldsb::binE(NB, NP, false, capL_) : p.islmin_off)) : lPair;
             const float linTolSqr = B2_LINEAR_SLEEP_TOL * B2_LINEAR_SLEEP_TOL, angTolSqr = B2_ANGULAR_SLEEP_TOL * B2_ANGULAR_SLEEP_TOL;
             for (int b = tid; b < N + M; b += nt) islMin[b] = 0x7F7FFFFFu;      // b2_maxFloat
             __syncthreads();
 #pragma unroll
             for (int q = 0; q < BPT; ++q) {
-                const int b = tid + q * nt;
-                if (b >= N) continue;
+                const int b_ = tid + q * nt;
+                if (b_ >= N) continue;
+                const int b = KB_SLOT(q, b_);
                 const unsigned r = parent[b];
                 if (!(islWave[r] & 2)) continue;
                 if (slp[q] < 0.0f) slp[q] = 0.0f;
@@ -1808,8 +2099,9 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
             __syncthreads();
 #pragma unroll
             for (int q = 0; q < BPT; ++q) {
-                const int b = tid + q * nt;
-                if (b >= N) continue;
+                const int b_ = tid + q * nt;
+                if (b_ >= N) continue;
+                const int b = KB_SLOT(q, b_);
                 const unsigned r = parent[b];
                 const unsigned st_ = islWave[r];
                 if ((st_ & 2) && !(st_ & 1) && __uint_as_float(islMin[r]) >= B2_TIME_TO_SLEEP) {
@@ -1831,36 +2123,42 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
         // a candidate list (in the staging area, idle after the solve) and processed one per thread, so that
         // the event logic exists once in the kernel instead of once per unrolled bot slot.
         if (p.toi_walls) {
-            // (fixed-size compact image: lCbk lies over nextb, where the start positions are by now; the order list is idle as well)
-            float *cTh0 = reinterpret_cast<float *>(lInfo), *cTh = lAcc, *cW = reinterpret_cast<float *>(FOLD ? lOrder : lCbk);
+            // candidate records (body, angle at the start of the substep, angle, angular velocity) in arrays that are idle by now;
+            // sorted-bin image: the staged impulses and keys must survive to the end of the substep (they are the packed list)
+            float *cTh0 = reinterpret_cast<float *>(BINS ? parent : lInfo), *cTh = BINS ? reinterpret_cast<float *>(lPair) : lAcc;
+            float *cW = reinterpret_cast<float *>(BINS ? lOrder : lCbk);
+            unsigned short *cSlot = reinterpret_cast<unsigned short *>(active);      // (sorted-bin image)
+            const int candMax = BINS ? min(capL_, N) : capL_ / 2;
             int cand[BPT];
             if (tid == 0) misc[M_NCON] = 0;
             __syncthreads();
 #pragma unroll
             for (int q = 0; q < BPT; ++q) {
-                const int b = tid + q * nt;
+                const int b_ = tid + q * nt;
                 cand[q] = -1;
-                if (b >= N) continue;
+                if (b_ >= N) continue;
+                const int b = KB_SLOT(q, b_);
                 if (SLEEP && slp[q] < 0.0f) continue;           // b2World::SolveTOI skips contacts without an awake dynamic body
                 const float total = p.r_bot + B2_POLYGON_RADIUS;
-                const float xa = COMPACT ? startX[b] : start[b].x, ya = COMPACT ? startY[b] : start[b].y, xb = pos[b].x, yb = pos[b].y;
+                const float xa = BINS ? startX[b] : start[b].x, ya = BINS ? startY[b] : start[b].y, xb = pos[b].x, yb = pos[b].y;
                 const float m0 = fminf(fminf(xa - p.xmin, p.xmax - xa), fminf(ya - p.ymin, p.ymax - ya));
                 const float m1 = fminf(fminf(xb - p.xmin, p.xmax - xb), fminf(yb - p.ymin, p.ymax - yb));
                 if (m0 > total && m1 > total) continue;          // stays clear of every wall: no event possible
                 const int i = (int)atomicAdd(&misc[M_NCON], 1u);
-                if (i >= capL_ / 2) { atomicOr(&misc[M_STATUS], 8u); continue; }
+                if (i >= candMax) { atomicOr(&misc[M_STATUS], 8u); continue; }
                 cand[q] = i;
-                lPair[i] = (unsigned)b; cTh0[i] = sth0[q]; cTh[i] = th[q]; cW[i] = bw[q];
+                if (BINS) cSlot[i] = (unsigned short)b; else lPair[i] = (unsigned)b;
+                cTh0[i] = sth0[q]; cTh[i] = th[q]; cW[i] = bw[q];
             }
             __syncthreads();
             KB_STAMP_PRE(26);    // ... + candidates of the continuous step collected
-            const int ncand = min((int)misc[M_NCON], capL_ / 2);
+            const int ncand = min((int)misc[M_NCON], candMax);
             for (int i = tid; i < ncand; i += nt) {
-                const int b = (int)lPair[i];
+                const int b = BINS ? (int)cSlot[i] : (int)lPair[i];
                 float R = p.r_bot, im = KB_IM_BOT(b);
                 asm volatile("" : "+v"(R), "+v"(im));   // per-lane copies: keeps the two constants out of the scalar file over the event loop
                 float x_ = pos[b].x, y_ = pos[b].y, a_ = cTh[i], vx_ = vel[b].x, vy_ = vel[b].y, w_ = cW[i];
-                kb_toi_walls_body(p, R, im, COMPACT ? startX[b] : start[b].x, COMPACT ? startY[b] : start[b].y, cTh0[i], x_, y_, a_, vx_, vy_, w_);
+                kb_toi_walls_body(p, R, im, BINS ? startX[b] : start[b].x, BINS ? startY[b] : start[b].y, cTh0[i], x_, y_, a_, vx_, vy_, w_);
                 pos[b].x = x_; pos[b].y = y_; vel[b].x = vx_; vel[b].y = vy_; cTh[i] = a_; cW[i] = w_;
             }
             if (OBJ && tid < M && !(SLEEP && objSlp[tid] < 0.0f)) {   // objects: the TOI sub-solve runs on the manifold-constraint records of their wall contacts
@@ -1888,7 +2186,26 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
         }
         // the new warm-start list becomes the old one
         for (int b = tid; b < NP; b += nt) { wsCnt[b] = wsCntNew[b]; wsOff[b] = newOff[b]; }
-        if (COMPACT) for (int c = tid; c < p.nhead; c += nt) head[c] = EMPTY16;     // the bucket tables lay over the cell heads
+        if (BINS) {
+            if (p.toi_walls) __syncthreads();      // (the candidate records of the continuous step lie where the image goes)
+            // sorted-bin image: the staged contacts 0 .. newTotal - 1 are the packed list (key = bits 16.. of the info word).
+            // It becomes the LDS image of the next substep's lookups, or goes out to the global list (last substep of the
+            // launch; always when the contacts were staged in the global scratch slice).
+            const bool last = sub == p.n_substeps - 1;
+            const unsigned *sInfo = big ? gInfo : lInfo;
+            const float *sAcc = big ? gAcc : lAcc;
+            const int nlist = (int)min(newTotal, (unsigned)stageCap);
+            for (int i = tid; i < nlist; i += nt) {
+                const unsigned key16 = sInfo[i] >> 16;
+                const float acc = sAcc[i];
+                if (newInLds && !last) { oldKey[i] = (unsigned short)key16; oldAcc[i] = acc; }
+                if (last || !newInLds) {
+                    g.ws_key[wo + i] = key16 >= (unsigned)WALL_CODE ? KEY_WALL + (key16 - WALL_CODE) : key16;
+                    g.ws_acc[wo + i] = acc;
+                }
+            }
+            for (int c = tid; c < ldsb::bin_entries(p.nhead) / 2; c += nt) reinterpret_cast<unsigned *>(E1)[c] = 0u;     // (the bucket tables lay over the bin boundaries)
+        }
         oldInLds = newInLds;
         oldTotal = newTotal;
         __syncthreads();
@@ -1901,7 +2218,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
     for (int q = 0; q < BPT; ++q) {
         const int b = tid + q * nt;
         if (b < N) {
-            g.x[o + b] = pos[b].x; g.y[o + b] = pos[b].y; g.theta[o + b] = th[q];
+            g.x[o + b] = pos[KB_SLOT(q, b)].x; g.y[o + b] = pos[KB_SLOT(q, b)].y; g.theta[o + b] = th[q];
             if (SLEEP && p.n_substeps > 0) g.sleep_time[o + b] = slp[q];
             if (p.n_substeps > 0) g.ws_cnt[o + b] = wsCnt[b];
             if (KB_LAW(q) == KB_DRIVE_ACCEL && p.n_substeps > 0 && drive) { g.v[o + b] = cv[q]; g.w[o + b] = cw[q]; }

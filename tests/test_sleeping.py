@@ -288,4 +288,4 @@ def test_benchmark_kernel_without_the_sleep_state_equals_the_sleeping_kernel_on_
             assert torch.equal(getattr(plain, f), getattr(sleepy, f)), (k, f)
     assert sleepy.sleep_time.max().item() > 0.0
     # (both are fixed-size 1024-kilobot instantiations, three envs per CU: with and without the sleep state)
-    assert plain.lds_bytes == 53168 and sleepy.lds_bytes == 53168 and sleepy.resident_envs_per_cu == 3
+    assert plain.lds_bytes == 52496 and sleepy.lds_bytes == 52496 and sleepy.resident_envs_per_cu == 3
