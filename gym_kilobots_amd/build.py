@@ -156,7 +156,7 @@ def build_profile(verbose=False):
     return _build(PROF_LIB, ['-DKB_PROFILE'], 'prof', verbose, lint=False)
 
 
-def build_variant(name, defines, only=None, verbose=False):
+def build_variant(name, defines, only=None, verbose=False, standalone=False):
     """Experiment build: libkilobots_hip_<name>.so with extra -D flags (select it with KB_HIP_LIB=...).
     only: restrict the drive-law units that are compiled (e.g. ['d0']) to save time; the others come from the release build."""
     lib = os.path.join(HERE, 'libkilobots_hip_%s.so' % name)
@@ -166,7 +166,8 @@ def build_variant(name, defines, only=None, verbose=False):
     for s in sources():
         base = os.path.basename(s)[:-4]
         if only is not None and base != 'kb_abi' and not any(base.endswith(o) for o in only):
-            reuse.append(os.path.join(HERE, '_obj', 'rel', base + '.o'))
+            if not standalone:      # (standalone: the listed units define everything the C ABI references, e.g. -DKB_ONLY_BENCH)
+                reuse.append(os.path.join(HERE, '_obj', 'rel', base + '.o'))
             continue
         jobs.append((s, os.path.join(objdir, base + '.o'), list(defines), verbose))
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:

@@ -247,6 +247,11 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
         // The thread index is re-read (through an opaque copy) at the top of every substep and of every phase: addresses
         // and predicates derived from it are then computed where they are used instead of being kept alive -- in spilled
         // registers -- across the phases.  (In the 80-VGPR kernel this alone took the spills from 35 to 11 VGPRs.)
+#ifdef KB_ABLATE      // measurement builds (tools/phase_ablation.py): the kernel ends behind phase KB_ABLATE without writing anything back
+#define KB_ABLATE_EXIT(k_) do { if (KB_ABLATE == (k_)) return; } while (0)
+#else
+#define KB_ABLATE_EXIT(k_) do { } while (0)
+#endif
 #define KB_RETID() do { int t_ = threadIdx.x; asm volatile("" : "+v"(t_)); tid = t_; lane = t_ & 63; wave = t_ >> 6; } while (0)
         KB_RETID();
         // ---- light.step: SinglePositionLight.step, light.py:59-75 (uniform per env) ----
@@ -375,6 +380,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
         __syncthreads();
         KB_STAMP(0);
         KB_RETID();
+        KB_ABLATE_EXIT(1);     // drive law + bin counters
         // ---- warm start: impulse of the same pair in the previous substep (b2Contact::Update id match) ----
         auto ws_find = [&](int owner, unsigned key16) __attribute__((always_inline)) -> float {
             const int cnt = wsCnt[owner], off = wsOff[owner];
@@ -402,6 +408,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                 if (nchunks <= nt) block_scan_bins<true>(E1, nchunks, 1, wsum);
                 else block_scan_bins<false>(E1, nchunks, (nchunks + nt - 1) / nt, wsum);
             }
+            KB_STAMP_PRE(31);    // (profile build, cumulative since the drive barrier) bin boundaries scanned
             // 2. scatter in arrival order ...
 #pragma unroll
             for (int q = 0; q < BPT; ++q) {
@@ -412,6 +419,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                 tmpSort[(int)E1[bin] + sarr[q]] = (unsigned short)b;
             }
             __syncthreads();
+            KB_STAMP_PRE(32);    // ... + arrival-order scatter and its barrier
             KB_RETID();
             // 3. ... and settle every kilobot in its slot: inside a bin by ascending id (the canonical order of the contacts
             //    is defined on ids).  From here to the end of the substep the kilobot's body lives at index ms[q].
@@ -433,9 +441,11 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                 vel[sl] = make_float2(svx[q], svy[q]);
                 parent[sl] = (unsigned)sl;
             }
+            KB_STAMP_PRE(33);    // ... + wave 0's kilobots settled in their slots
             __syncthreads();
             KB_STAMP(0);
             KB_RETID();
+            KB_ABLATE_EXIT(2);     // bins sorted
             // ---- IR-range neighbour sensing (kb_config.sense_radius): at the sensing point of the substep, like the light
             //      (kilobots_env.py:174-180), off the bins that the contact search uses ----
             if (SENSE && p.sense_s > 0 && drive) {
@@ -554,10 +564,12 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
             }
             KB_STAMP_PRE(17);
             __syncthreads();
+            KB_ABLATE_EXIT(3);     // owned contacts found
             // 4. offsets of the new packed warm-start list = where the contacts are staged
             newTotal = block_scan_u8(wsCntNew, newOff, NP, wsum);   // (barriers inside)
             KB_STAMP(1);
             KB_RETID();
+            KB_ABLATE_EXIT(4);     // offsets of the packed list
             if (SENSE && p.sense_s > 0 && drive) {      // the neighbour counters lie where the emit pass stages the impulses
 #pragma unroll
                 for (int q = 0; q < BPT; ++q) {
@@ -572,8 +584,8 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
             stageCap = big ? p.cap : capS;
             if (newTotal + extras > (unsigned)stageCap && tid == 0) atomicOr(&misc[M_STATUS], 1u);
             ncon = (int)min(newTotal + extras, (unsigned)stageCap);
-            // ---- narrowphase, pass 2 (the owner's thread): class, rank, impulse of the same pair in the previous substep,
-            //      island hooking; contact j of owner a is staged at newOff[a] + j, its position in the packed list ----
+            // ---- narrowphase, pass 2 (the owner's thread, light): stage the owned contacts -- pair, class, rank -- at their
+            //      position in the packed list: contact j of owner a at newOff[a] + j ----
             unsigned *sPair = big ? gPair : lPair, *sInfo = big ? gInfo : lInfo;
             float *sAcc = big ? gAcc : lAcc;
 #pragma unroll
@@ -590,7 +602,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                 const unsigned base = newOff[b], nst = wsCntNew[b];
                 // rank base of the (cell, direction) groups: contacts of the group owned by the kilobots of the cell in front of this one
                 unsigned rbE = 0u, rbO = 0u;      // fields k = 0, 2, 4 / k = 1, 3 at 12-bit spacing
-                {
+                if (nbb) {
                     const int cell = cy * p.gw + cx;
                     const int s0 = (int)E1[hashed ? (cell & p.hmask) : cell];
                     for (int s_ = s0; s_ < sa; ++s_) {
@@ -603,9 +615,8 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                 const unsigned ntot = nbb + (unsigned)__popc(wm & 15u);
                 unsigned wleft = wm & 15u;
                 for (unsigned j = 0; j < ntot; ++j) {
-                    unsigned pr, key16;
+                    unsigned pr;
                     int cls, r;
-                    float acc;
                     if (j < nbb) {
                         int sb_ = 0, k = 0;
                         if (j < 4u) {
@@ -623,42 +634,60 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                         else cls = CLS_NW + (cx & 1);
                         const unsigned rb_ = (k & 1) ? (rbO >> (12 * (k >> 1))) & 0xFFFu : (rbE >> (12 * (k >> 1))) & 0xFFFu;
                         r = (int)rb_ + jk;
-                        const unsigned idb = idOf[sb_];
-                        acc = ws_find(b, idb);
-                        if (acc < 0.0f) acc = ws_find((int)idb, (unsigned)b);
                         pr = (unsigned)sa | ((unsigned)sb_ << 16);
-                        key16 = idb;
-                        // island hooking: larger root goes under the smaller one
-                        unsigned ra = (unsigned)sa, rb = (unsigned)sb_;
-                        for (;;) {
-                            while (true) { unsigned t = ((volatile unsigned *)parent)[ra]; if (t == ra) break; ra = t; }
-                            while (true) { unsigned t = ((volatile unsigned *)parent)[rb]; if (t == rb) break; rb = t; }
-                            if (ra == rb) break;
-                            if (ra < rb) { unsigned t = ra; ra = rb; rb = t; }
-                            if (atomicCAS(&parent[ra], ra, rb) == ra) break;
-                        }
                     } else {              // wall contact, owned by the kilobot: rank = lower walls it touches
                         const int wl = __builtin_ctz(wleft);
                         wleft &= wleft - 1u;
                         r = __popc(wm & ((1u << wl) - 1u) & 15u);
                         cls = CLS_WALL | (((wm >> (4 + wl)) & 1u) ? 0x80 : 0);
-                        key16 = (unsigned)(WALL_CODE + wl);
-                        acc = ws_find(b, key16);
-                        pr = key16 | ((unsigned)sa << 16);
+                        pr = (unsigned)(WALL_CODE + wl) | ((unsigned)sa << 16);
                     }
-                    if (acc < 0.0f) acc = 0.0f;
                     if (r > 255) { r = 255; atomicOr(&misc[M_STATUS], 4u); }
                     const unsigned cid = j < nst ? base + j : newTotal + atomicAdd(&misc[M_XFILL], 1u);
                     if (cid >= (unsigned)stageCap) continue;
                     sPair[cid] = pr;
-                    sInfo[cid] = (unsigned)cls | ((unsigned)r << 8) | (key16 << 16);
-                    sAcc[cid] = acc;
+                    sInfo[cid] = (unsigned)cls | ((unsigned)r << 8);
                 }
+            }
+            KB_STAMP_PRE(34);    // (cumulative since the offset scan) wave 0's owned contacts staged
+            __syncthreads();
+            KB_STAMP_PRE(35);    // ... + barrier
+            KB_RETID();
+            KB_ABLATE_EXIT(5);     // contacts staged
+            // ---- narrowphase, pass 3 (thread per contact): impulse of the same pair in the previous substep, key of the new
+            //      packed list (bits 16.. of the info word), island hooking ----
+            for (int c = tid; c < ncon; c += nt) {
+                const unsigned pr = sPair[c];
+                const unsigned a = pr & 0xFFFFu, b = pr >> 16;
+                unsigned key16;
+                float acc;
+                if (a >= (unsigned)WALL_CODE) {
+                    key16 = a;
+                    acc = ws_find((int)idOf[b], key16);
+                } else {
+                    const unsigned ida = idOf[a], idb = idOf[b];
+                    acc = ws_find((int)ida, idb);
+                    if (acc < 0.0f) acc = ws_find((int)idb, ida);
+                    key16 = idb;
+                    // island hooking: larger root goes under the smaller one
+                    unsigned ra = a, rb = b;
+                    for (;;) {
+                        while (true) { unsigned t = ((volatile unsigned *)parent)[ra]; if (t == ra) break; ra = t; }
+                        while (true) { unsigned t = ((volatile unsigned *)parent)[rb]; if (t == rb) break; rb = t; }
+                        if (ra == rb) break;
+                        if (ra < rb) { unsigned t = ra; ra = rb; rb = t; }
+                        if (atomicCAS(&parent[ra], ra, rb) == ra) break;
+                    }
+                }
+                if (acc < 0.0f) acc = 0.0f;
+                sInfo[c] |= key16 << 16;
+                sAcc[c] = acc;
             }
             KB_STAMP_PRE(18);
             __syncthreads();
             KB_STAMP(2);
             KB_RETID();
+            KB_ABLATE_EXIT(6);     // impulses looked up, islands hooked
         } else {
             // ---- IR-range neighbour sensing (kb_config.sense_radius): at the sensing point of the substep, like the light
             //      (kilobots_env.py:174-180), off the cell lists that the contact search uses ----
@@ -963,6 +992,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
         }
         KB_STAMP(14);    // flatten roots + warm-start offset scan
         KB_RETID();
+        KB_ABLATE_EXIT(7);     // roots flattened
         // per contact: island size (giant islands force the cooperative sweep) and contacts per wave
         auto census = [&](const unsigned *sPair) __attribute__((always_inline)) {
             for (int c = tid; c < ncon; c += nt) {
@@ -1179,6 +1209,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
         else bucket_sort(lPair, lInfo, lCbk, lOrder);
         KB_STAMP(3);
         KB_RETID();
+        KB_ABLATE_EXIT(8);     // census, placement, contacts grouped by wave
 
         if (reg) {
             // =========================== register-resident solver ===========================
@@ -1406,6 +1437,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                 wave_sync();                                                                        \
             }
 
+            KB_ABLATE_EXIT(9);     // register set-up: light load, depth pass, dealing, full load
             // manifold constraints of this wave's islands (uniform mask)
             unsigned long long myMc = 0ull;
             if (OBJ) {
@@ -1433,6 +1465,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
             })
             if (OBJ && myMc) { mc_warm_pass(myMc, lane == 0); wave_sync(); }
             KB_STAMP_PRE(29);    // (profile build) warm start of wave 0, since the register set-up
+            KB_ABLATE_EXIT(10);    // warm start
             // SolveVelocityConstraints: friction 0, restitution 0, one manifold point.
             // Branch-free rounds: slots that are not part of the current depth level work on a scratch body, so
             // the LDS reads of all KREG slots are issued together (one LDS round trip per round).
@@ -1506,6 +1539,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
             __syncthreads();
             KB_STAMP(4);
             KB_RETID();
+            KB_ABLATE_EXIT(11);    // velocity sweeps
             mc_store();
 #ifdef KB_PROFILE
             if (tid == 0) atomicAdd(&KB_PROF(9), misc[M_PROF]);   // deepest wave of the env (replaces the contacts-per-wave slot)
@@ -1574,6 +1608,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
             __syncthreads();
             KB_STAMP(5);
             KB_RETID();
+            KB_ABLATE_EXIT(12);    // impulses stored, positions integrated
             // SolvePositionConstraints; an island stops once its minSeparation >= -3 slop.  The island flags are read
             // once per iteration; depth levels without an active contact in this wave are skipped altogether.
             for (int it = 0; it < p.pos_iters; ++it) {
@@ -2059,6 +2094,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
         __syncthreads();
         KB_STAMP_PRE(25);        // ... + waiting for the wave with the most position sweeps
         KB_RETID();
+        KB_ABLATE_EXIT(13);    // position sweeps
         if (SLEEP) {
             // ---- b2Island::Solve, the allowSleep block: a body slower than the sleep tolerances accumulates sleep time; an
             // island (awake ones only: bit 1 of islWave[root]) whose bodies have all rested for b2_timeToSleep and whose
@@ -2174,6 +2210,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
             for (int q = 0; q < BPT; ++q)
                 if (cand[q] >= 0) { th[q] = cTh[cand[q]]; bw[q] = cW[cand[q]]; }
         }
+        KB_ABLATE_EXIT(14);    // continuous step
         // The state of an object between substeps is its body origin (what one-substep launches store and load, and
         // what the specification's substep does): bodies whose centre of mass is off the origin go through the same
         // origin -> centre of mass conversion inside a fused launch, so that fusing never changes a bit.

@@ -86,6 +86,8 @@ def main():
     print('  since the register set-up: warm start %.0f, + 10 velocity sweeps of wave 0 %.0f (then the barrier)' % (fine[5], fine[6]))
     print('  since the integration: own position sweeps %.0f, + waiting for the slowest wave %.0f, + continuous-step candidates collected %.0f, '
           '+ own candidates processed %.0f, + every wave\'s %.0f (then copies, cell heads cleared, barrier)' % tuple(fine[:5]))
+    b_ = raw[:, 31:36].mean(0) * 16
+    print('  sorted bins, wave 0, cumulative since the drive barrier: boundary scan %.0f, + scatter and barrier %.0f, + slots settled %.0f; since the offset scan: contacts staged %.0f, + barrier %.0f' % tuple(b_))
     print('  wave 0 per substep: keys %.1f, depth rounds/sweep %.1f (deepest wave of the env %.1f), position sweeps %.2f, reg-path fraction %.2f' % (ex[0], ex[4], ex[1], ex[2], ex[3]))
 
 
