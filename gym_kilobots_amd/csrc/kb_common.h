@@ -67,6 +67,12 @@ constexpr int KB_LIGHT_GENERAL = 99;   // kernel template value: any light model
 constexpr int GIANT_ISLAND = 256;     // contacts; larger islands are swept by the whole workgroup
 constexpr int BIG_ISLAND = 16;        // contacts; islands from this size on are placed on waves one by one when the hash placement overloads a wave
 constexpr int KREG = KB_KREG;               // contacts a lane can keep in registers (register-resident solver)
+#ifndef KB_NSOLVE_DIV
+#define KB_NSOLVE_DIV 1                 // sweeping waves = waves of the workgroup / KB_NSOLVE_DIV (A/B knob, see kb_regsolve_bins.inc)
+#endif
+#ifndef KB_KREG_BINS
+#define KB_KREG_BINS (2 * KB_NSOLVE_DIV)                  // ... in the kernels without objects, where only half the waves of a workgroup sweep (kb_regsolve_bins.inc)
+#endif
 constexpr int CAP_LDS = 1024;         // contacts staged in LDS; denser envs stage in the global scratch slice
 
 enum { M_NCON = 0, M_TOTAL = 1, M_ANY = 2, M_STATUS = 3, M_MAXISL = 4, M_PROF = 5, M_XTRA = 6, M_XFILL = 7, M_WCNT = 8, M_WFILL = 8 + MAX_WAVES, M_COUNT = 8 + 2 * MAX_WAVES };

@@ -32,6 +32,7 @@ template <int DRIVE_MODE, int LIGHT_TYPE, bool OBJ, int FN = 0, int TIER = 0, bo
 __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1 || TIER == 3) ? 2 : ((TIER == 2 || (FN != 0 && !OBJ)) ? KB_COMPACT_WAVES_PER_SIMD : KB_MIN_WAVES_PER_SIMD)) kb_step_kernel(const Params p) {
     constexpr bool WIDE = TIER == 1 || TIER == 3;       // (256 VGPRs: no register spills)
     constexpr bool BINS = !OBJ;          // sorted-bin broadphase, bodies in slot order, contacts at their warm-start position (namespace ldsb)
+    constexpr int KRX = BINS ? KB_KREG_BINS : KREG;      // contacts per lane of the register-resident solver
     static_assert(!SLEEP || FN == 0 || !OBJ, "the fixed-size instantiations with objects do not carry the sleep state");
     extern __shared__ __align__(16) unsigned char smem[];
     int e = blockIdx.x;
@@ -39,6 +40,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
     const int nt = FN ? 64 * KB_MAX_WAVES : (int)blockDim.x;
     int lane = tid & 63, wave = tid >> 6;
     const int nw = nt >> 6;
+    const int nsolve = BINS ? (nw >= KB_NSOLVE_DIV ? nw / KB_NSOLVE_DIV : 1) : nw;      // waves that sweep the contacts (kb_regsolve_bins.inc: the solver is issue-bound, fewer waves fill their lanes better)
     const int N = FN ? FN : p.N, NP = FN ? ((FN + 3) & ~3) : p.NP, S = p.S;
     size_t o = (size_t)e * N;
     size_t wo = (size_t)e * p.cap;       // this env's slice of the packed warm-start / scratch arrays
@@ -185,6 +187,17 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
             }
         }
     }
+    // Sorted-bin image: the packed warm-start list of the previous launch is requested together with the state (the same trip
+    // to HBM); how many of its entries exist is only known behind the offset scan below.
+    unsigned pfKey[2] = {0u, 0u};
+    float pfAcc[2] = {0.0f, 0.0f};
+    if (BINS && p.n_substeps > 0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int i = tid + q * nt;
+            if (i < capL_ && i < p.cap) { pfKey[q] = g.ws_key[wo + i]; pfAcc[q] = g.ws_acc[wo + i]; }
+        }
+    }
     for (int b = N + tid; b < NP; b += nt) { wsCnt[b] = 0; wsCntNew[b] = 0; }
     // pushable objects: pose and velocity live in LDS (pos / vel / objA / objW), thread m integrates object m
     if (tid < M) {
@@ -232,8 +245,18 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
     // warm-start list of the previous substep: offsets, and an LDS image of the packed entries if it fits
     unsigned oldTotal = block_scan_u8(wsCnt, wsOff, NP, wsum);
     bool oldInLds = oldTotal <= (unsigned)capL_;
+    if (BINS && oldInLds) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const unsigned i = tid + q * nt;
+            if (i < oldTotal) {
+                oldKey[i] = (unsigned short)(pfKey[q] >= KEY_WALL ? WALL_CODE + (pfKey[q] - KEY_WALL) : pfKey[q]);
+                oldAcc[i] = pfAcc[q];
+            }
+        }
+    }
     if (oldInLds) {
-        for (unsigned i = tid; i < oldTotal; i += nt) {
+        for (unsigned i = tid + (BINS ? 2 * nt : 0); i < oldTotal; i += nt) {
             const unsigned k = g.ws_key[wo + i];
             oldKey[i] = (unsigned short)(k >= KEY_OBJ ? OBJ_CODE + (k - KEY_OBJ) : (k >= KEY_WALL ? WALL_CODE + (k - KEY_WALL) : k));
             oldAcc[i] = g.ws_acc[wo + i];
@@ -463,6 +486,8 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
             //      stencil (same cell behind it, E, N, NE, NW: contiguous runs of slots) and walls ----
             // Candidate runs in enumeration order k = 0 .. 4.  Arena-sized grid: three runs, two cells of a grid row each
             // ([same | E], [N | NE], [NW]); hashed bins: one run per cell.  sp = first slot of the run's second cell.
+            // Candidate runs in enumeration order k = 0 .. 4.  Arena-sized grid: three runs, two cells of a grid row each
+            // ([same | E], [N | NE], [NW]); hashed bins: one run per cell.  sp = first slot of the run's second cell.
             constexpr int NR = FN ? 3 : 5;
             auto candidate_runs = [&](int sa, int cx, int cy, int (&lo)[NR], int (&hi)[NR], int (&sp)[NR], int (&tc)[5]) __attribute__((always_inline)) {
                 const int gw = p.gw, gh = p.gh;
@@ -497,7 +522,10 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                 for (int r = 0; r < NR; ++r) pre[r + 1] = pre[r] + max(hi[r] - lo[r], 0);
                 const int tot = pre[NR];
                 const float2 pa = pos[sa];
-                constexpr int BATCH = 4;      // candidates fetched together (one LDS round trip)
+#ifndef KB_FIND_BATCH
+#define KB_FIND_BATCH 2
+#endif
+                constexpr int BATCH = KB_FIND_BATCH;      // candidates fetched together (one LDS round trip)
                 for (int base = 0; base < tot; base += BATCH) {
                     int cs[BATCH], ck[BATCH];
                     float2 cp[BATCH];
@@ -530,10 +558,11 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                 }
             };
             unsigned pl0[BPT], pl1[BPT];      // the first four partners of a kilobot: slot | k << 12, 16 bits each
+            unsigned snb[BPT], snm[BPT];      // ... how many it has, and how many entries of the packed list it owns (walls included, capped)
 #pragma unroll
             for (int q = 0; q < BPT; ++q) {
                 const int b = tid + q * nt;
-                pl0[q] = 0u; pl1[q] = 0u;
+                pl0[q] = 0u; pl1[q] = 0u; snb[q] = 0u; snm[q] = 0u;
                 if (b >= N) continue;
                 const int sa = ms[q];
                 unsigned cnt = 0, nbb = 0, l0 = 0u, l1 = 0u;
@@ -545,7 +574,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                     if (((cnt >> (6 * k)) & 63u) == 63u) atomicOr(&misc[M_STATUS], 4u);
                     else cnt += 1u << (6 * k);
                 });
-                pl0[q] = l0; pl1[q] = l1;
+                pl0[q] = l0; pl1[q] = l1; snb[q] = nbb;
                 // walls: b2CollideEdgeAndCircle (region AB) against the chain loop of kilobots_env.py:48-51
                 unsigned wm = 0u;
                 const float ax = pos[sa].x, ay = pos[sa].y;
@@ -561,12 +590,27 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                 dirCnt[sa] = cnt;
                 if (mine > (unsigned)S) { atomicOr(&misc[M_STATUS], 2u); atomicAdd(&misc[M_XTRA], mine - (unsigned)S); mine = S; }
                 wsCntNew[b] = (unsigned char)mine;
+                snm[q] = mine;
             }
             KB_STAMP_PRE(17);
-            __syncthreads();
-            KB_ABLATE_EXIT(3);     // owned contacts found
-            // 4. offsets of the new packed warm-start list = where the contacts are staged
-            newTotal = block_scan_u8(wsCntNew, newOff, NP, wsum);   // (barriers inside)
+            // 4. offsets of the new packed warm-start list (owners in ascending id: thread t owns kilobots t and nt + t) = where
+            //    the contacts are staged.  Every thread scans its own counts: one wave scan per kilobot row, one barrier.
+            unsigned myOff[BPT];
+            {
+                static_assert(BPT == 2 && MAX_WAVES <= 8, "two rows of per-wave sums in the 16-word scratch");
+                const unsigned inc0 = wave_incl_scan(snm[0]), inc1 = wave_incl_scan(snm[1]);
+                if (lane == 63) { wsum[wave] = inc0; wsum[8 + wave] = inc1; }
+                __syncthreads();
+                KB_ABLATE_EXIT(3);     // owned contacts found
+                unsigned b0 = 0, b1 = 0, t0 = 0, t1 = 0;
+                for (int w = 0; w < nw; ++w) {
+                    const unsigned s0 = wsum[w], s1 = wsum[8 + w];
+                    if (w < wave) { b0 += s0; b1 += s1; }
+                    t0 += s0; t1 += s1;
+                }
+                myOff[0] = b0 + inc0 - snm[0]; myOff[1] = t0 + b1 + inc1 - snm[1];
+                newTotal = t0 + t1;
+            }
             KB_STAMP(1);
             KB_RETID();
             KB_ABLATE_EXIT(4);     // offsets of the packed list
@@ -584,8 +628,10 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
             stageCap = big ? p.cap : capS;
             if (newTotal + extras > (unsigned)stageCap && tid == 0) atomicOr(&misc[M_STATUS], 1u);
             ncon = (int)min(newTotal + extras, (unsigned)stageCap);
-            // ---- narrowphase, pass 2 (the owner's thread, light): stage the owned contacts -- pair, class, rank -- at their
-            //      position in the packed list: contact j of owner a at newOff[a] + j ----
+            // ---- narrowphase, pass 2 (the owner's thread, as light as possible: its trip count is the busiest lane's): stage the
+            //      owned contacts at their position in the packed list, contact j of owner a at newOff[a] + j.  Raw record:
+            //      pair; direction k (walls: 8 + wall) | index inside the direction (walls: rank) << 4 | parity of the base
+            //      cell << 12 | "kilobots of the cell in front of the owner" << 14 | wall normal flipped << 15 ----
             unsigned *sPair = big ? gPair : lPair, *sInfo = big ? gInfo : lInfo;
             float *sAcc = big ? gAcc : lAcc;
 #pragma unroll
@@ -593,60 +639,42 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                 const int b = tid + q * nt;
                 if (b >= N) continue;
                 const int sa = ms[q], cx = SC_CX(scell[q]), cy = SC_CY(scell[q]);
-                const unsigned dc = dirCnt[sa];
-                unsigned nbb = 0;
-#pragma unroll
-                for (int k = 0; k < 5; ++k) nbb += (dc >> (6 * k)) & 63u;
+                const unsigned nbb = snb[q];
                 const unsigned wm = (unsigned)scell[q] >> 24;
-                if (nbb + (wm & 15u) == 0u) continue;
-                const unsigned base = newOff[b], nst = wsCntNew[b];
-                // rank base of the (cell, direction) groups: contacts of the group owned by the kilobots of the cell in front of this one
-                unsigned rbE = 0u, rbO = 0u;      // fields k = 0, 2, 4 / k = 1, 3 at 12-bit spacing
-                if (nbb) {
-                    const int cell = cy * p.gw + cx;
-                    const int s0 = (int)E1[hashed ? (cell & p.hmask) : cell];
-                    for (int s_ = s0; s_ < sa; ++s_) {
-                        if (hashed && (int)cellOfSlot[s_] != cell) continue;
-                        const unsigned d2 = dirCnt[s_];
-                        rbE += d2 & 0x3F03F03Fu; rbO += (d2 >> 6) & 0x0003F03Fu;
-                    }
-                }
-                int curk = -1, jk = 0;
                 const unsigned ntot = nbb + (unsigned)__popc(wm & 15u);
+                newOff[b] = (unsigned short)myOff[q];
+                if (ntot == 0u) continue;
+                const unsigned base = myOff[q], nst = snm[q];
+                const int cell = cy * p.gw + cx;
+                const unsigned common = ((unsigned)(cx & 1) << 12) | ((unsigned)(cy & 1) << 13) | (sa > (int)E1[hashed ? (cell & p.hmask) : cell] ? 1u << 14 : 0u);
+                int curk = -1;
+                unsigned jk = 0;
                 unsigned wleft = wm & 15u;
                 for (unsigned j = 0; j < ntot; ++j) {
-                    unsigned pr;
-                    int cls, r;
+                    unsigned pr, inf;
                     if (j < nbb) {
-                        int sb_ = 0, k = 0;
-                        if (j < 4u) {
-                            const unsigned e16 = ((j < 2u ? pl0[q] : pl1[q]) >> (16u * (j & 1u))) & 0xFFFFu;
-                            sb_ = (int)(e16 & 0xFFFu); k = (int)(e16 >> 12);
-                        } else {          // (a dense pile: walk the candidates again up to partner j)
-                            unsigned idx = 0;
-                            for_partners(sa, cx, cy, [&](int sl, int kk) __attribute__((always_inline)) { if (idx == j) { sb_ = sl; k = kk; } idx++; });
+                        unsigned e16;
+                        if (j < 4u) e16 = ((j < 2u ? pl0[q] : pl1[q]) >> (16u * (j & 1u))) & 0xFFFFu;
+                        else {          // (a dense pile: walk the candidates again up to partner j)
+                            unsigned idx = 0, f16 = 0;
+                            for_partners(sa, cx, cy, [&](int sl, int kk) __attribute__((always_inline)) { if (idx == j) f16 = (unsigned)sl | ((unsigned)kk << 12); idx++; });
+                            e16 = f16;
                         }
+                        const int k = (int)(e16 >> 12);
                         if (k != curk) { curk = k; jk = 0; } else jk++;
-                        if (k == 0) cls = CLS_SAME;
-                        else if (k == 1) cls = CLS_E + (cx & 1);
-                        else if (k == 2) cls = CLS_N + (cy & 1);
-                        else if (k == 3) cls = CLS_NE + (cx & 1);
-                        else cls = CLS_NW + (cx & 1);
-                        const unsigned rb_ = (k & 1) ? (rbO >> (12 * (k >> 1))) & 0xFFFu : (rbE >> (12 * (k >> 1))) & 0xFFFu;
-                        r = (int)rb_ + jk;
-                        pr = (unsigned)sa | ((unsigned)sb_ << 16);
+                        if (jk > 255u) { jk = 255u; atomicOr(&misc[M_STATUS], 4u); }
+                        pr = (unsigned)sa | ((e16 & 0xFFFu) << 16);
+                        inf = (unsigned)k | (jk << 4) | common;
                     } else {              // wall contact, owned by the kilobot: rank = lower walls it touches
                         const int wl = __builtin_ctz(wleft);
                         wleft &= wleft - 1u;
-                        r = __popc(wm & ((1u << wl) - 1u) & 15u);
-                        cls = CLS_WALL | (((wm >> (4 + wl)) & 1u) ? 0x80 : 0);
                         pr = (unsigned)(WALL_CODE + wl) | ((unsigned)sa << 16);
+                        inf = (unsigned)(8 + wl) | ((unsigned)__popc(wm & ((1u << wl) - 1u) & 15u) << 4) | (((wm >> (4 + wl)) & 1u) << 15);
                     }
-                    if (r > 255) { r = 255; atomicOr(&misc[M_STATUS], 4u); }
                     const unsigned cid = j < nst ? base + j : newTotal + atomicAdd(&misc[M_XFILL], 1u);
                     if (cid >= (unsigned)stageCap) continue;
                     sPair[cid] = pr;
-                    sInfo[cid] = (unsigned)cls | ((unsigned)r << 8);
+                    sInfo[cid] = inf;
                 }
             }
             KB_STAMP_PRE(34);    // (cumulative since the offset scan) wave 0's owned contacts staged
@@ -654,18 +682,36 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
             KB_STAMP_PRE(35);    // ... + barrier
             KB_RETID();
             KB_ABLATE_EXIT(5);     // contacts staged
-            // ---- narrowphase, pass 3 (thread per contact): impulse of the same pair in the previous substep, key of the new
-            //      packed list (bits 16.. of the info word), island hooking ----
+            // ---- narrowphase, pass 3 (thread per contact): class and rank in the canonical order, impulse of the same pair in
+            //      the previous substep, key of the new packed list (bits 16.. of the info word), island hooking ----
             for (int c = tid; c < ncon; c += nt) {
-                const unsigned pr = sPair[c];
+                const unsigned pr = sPair[c], raw = sInfo[c];
                 const unsigned a = pr & 0xFFFFu, b = pr >> 16;
-                unsigned key16;
+                unsigned key16, cls, r = (raw >> 4) & 0xFFu;
                 float acc;
                 if (a >= (unsigned)WALL_CODE) {
                     key16 = a;
+                    cls = (unsigned)CLS_WALL | ((raw >> 15) ? 0x80u : 0u);
                     acc = ws_find((int)idOf[b], key16);
                 } else {
                     const unsigned ida = idOf[a], idb = idOf[b];
+                    const int k = (int)(raw & 15u);
+                    const unsigned px = (raw >> 12) & 1u, py = (raw >> 13) & 1u;
+                    cls = k == 0 ? (unsigned)CLS_SAME : (k == 1 ? CLS_E + px : (k == 2 ? CLS_N + py : (k == 3 ? CLS_NE + px : CLS_NW + px)));
+                    if ((raw >> 14) & 1u) {
+                        // rank base of the (cell, direction) group: its contacts owned by the kilobots of the cell in front of the owner
+                        const float2 pa = pos[a];
+                        int cx = (int)floorf((pa.x - p.xmin) * p.inv_cell);
+                        int cy = (int)floorf((pa.y - p.ymin) * p.inv_cell);
+                        cx = cx < 0 ? 0 : (cx >= p.gw ? p.gw - 1 : cx);
+                        cy = cy < 0 ? 0 : (cy >= p.gh ? p.gh - 1 : cy);
+                        const int cell = cy * p.gw + cx;
+                        for (int s_ = (int)E1[hashed ? (cell & p.hmask) : cell]; s_ < (int)a; ++s_) {
+                            if (hashed && (int)cellOfSlot[s_] != cell) continue;
+                            r += (dirCnt[s_] >> (6 * k)) & 63u;
+                        }
+                        if (r > 255u) { r = 255u; atomicOr(&misc[M_STATUS], 4u); }
+                    }
                     acc = ws_find((int)ida, idb);
                     if (acc < 0.0f) acc = ws_find((int)idb, ida);
                     key16 = idb;
@@ -680,7 +726,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                     }
                 }
                 if (acc < 0.0f) acc = 0.0f;
-                sInfo[c] |= key16 << 16;
+                sInfo[c] = cls | (r << 8) | (key16 << 16);
                 sAcc[c] = acc;
             }
             KB_STAMP_PRE(18);
@@ -953,7 +999,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
             while (true) { unsigned t = ((volatile unsigned *)parent)[r]; if (t == r) break; r = t; }
             parent[b] = r;   // only ever replaces an ancestor by an older ancestor: concurrent walks stay valid
             islCnt[b] = 0;
-            islWave[b] = (unsigned char)((unsigned)b % (unsigned)nw);
+            islWave[b] = (unsigned char)((unsigned)b % (unsigned)nsolve);
             if (!BINS) head[hix(cellOf[b])] = EMPTY16;
             if (!SLEEP) active[b] = 1;
             active[NB + b] = 0;
@@ -977,7 +1023,12 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
 #pragma unroll
             for (int q = 0; q < BPT; ++q) {
                 const int b = tid + q * nt;
-                if (b < N && !(slp[q] < 0.0f)) active[parent[KB_SLOT(q, b)]] = 1;
+                if (b < N && !(slp[q] < 0.0f)) {
+                    // (sorted bins: the kilobot's slot is flattened by another thread of this phase -- walk to the root)
+                    unsigned r = (unsigned)KB_SLOT(q, b);
+                    while (true) { unsigned t = ((volatile unsigned *)parent)[r]; if (t == r) break; r = t; }
+                    active[r] = 1;
+                }
             }
             if (tid < M && !(objSlp[tid] < 0.0f)) active[parent[N + tid]] = 1;
         }
@@ -1036,13 +1087,14 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
             // last one the remaining small islands (two slots, but only one or two depth levels)
             unsigned chunk = 60u;
             if ((unsigned)ncon > 60u * (unsigned)(nw - 1) + 124u) chunk = ((unsigned)ncon - 124u + (unsigned)nw - 2u) / (unsigned)(nw - 1);
+            if (BINS) chunk = ((unsigned)ncon + (unsigned)nsolve - 1u) / (unsigned)nsolve;      // (the sweeping waves share the contacts evenly, the largest islands first)
             for (int b = tid; b < N + M; b += nt) {
                 if (parent[b] != (unsigned)b) continue;
                 const unsigned cnt_ = islCnt[b];
                 if (cnt_ == 0) continue;
                 const unsigned q_ = 32u - min(cnt_, 32u);
                 const unsigned at = szPre[q_] + atomicAdd(&szFill[q_], cnt_);
-                const unsigned w_ = min(at / max(chunk, 1u), (unsigned)nw - 1u);
+                const unsigned w_ = min(at / max(chunk, 1u), (unsigned)nsolve - 1u);
                 islWave[b] = (unsigned char)w_;
                 atomicAdd(&misc[M_WCNT + w_], cnt_);
             }
@@ -1050,8 +1102,8 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
             maxw = 0;
             for (int w = 0; w < nw; ++w) maxw = max(maxw, misc[M_WCNT + w]);
         }
-        bool reg = !coopForced && !big && maxw <= 64u * KREG && p.solver_mode == 0;
-        if (!coop && !big && maxw > 64u * KREG && p.solver_mode == 0) {
+        bool reg = !coopForced && !big && maxw <= 64u * KRX && p.solver_mode == 0;
+        if (!coop && !big && maxw > 64u * KRX && p.solver_mode == 0) {
             // The default placement (root id mod #waves) overloads a wave.  Place the islands of BIG_ISLAND contacts or
             // more one by one, largest first, each on the wave with the least load (ties: lowest root / lowest wave);
             // the small ones stay where they are.  Results do not depend on the placement, only the time does.
@@ -1079,24 +1131,24 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                     const unsigned sj = __shfl(size, j), rj = __shfl(root, j);
                     if (sj > size || (sj == size && rj < root)) rank++;
                 }
-                unsigned load = lane < nw ? misc[M_WCNT + lane] : 0u;
+                unsigned load = lane < nsolve ? misc[M_WCNT + lane] : 0u;
                 int myWave = 0;
                 for (int r = 0; r < nb; ++r) {
                     const int src = __builtin_ctzll(__ballot(lane < nb && rank == r));
                     const unsigned sz = __shfl(size, src);
-                    unsigned key = lane < nw ? ((load << 4) | (unsigned)lane) : 0xFFFFFFFFu;
+                    unsigned key = lane < nsolve ? ((load << 4) | (unsigned)lane) : 0xFFFFFFFFu;
                     for (int d = 8; d >= 1; d >>= 1) key = min(key, __shfl_xor(key, d));
                     const int wmin = (int)(__shfl(key, 0) & 15u);
                     if (lane == wmin) load += sz;
                     if (lane == src) myWave = wmin;
                 }
                 if (lane < nb) islWave[root] = (unsigned char)myWave;
-                if (lane < nw) misc[M_WCNT + lane] = load;
+                if (lane < nsolve) misc[M_WCNT + lane] = load;
             }
             __syncthreads();
             maxw = 0;
             for (int w = 0; w < nw; ++w) maxw = max(maxw, misc[M_WCNT + w]);
-            reg = maxw <= 64u * KREG;
+            reg = maxw <= 64u * KRX;
         }
         if (OBJ && wave == 0) {   // which wave sweeps which manifold constraint (slot nw: all of them)
             const bool on = lane < NMC && mcTouch && (!SLEEP || active[mci(ox, MC_ISL, lane)] != 0);
@@ -1211,7 +1263,14 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
         KB_RETID();
         KB_ABLATE_EXIT(8);     // census, placement, contacts grouped by wave
 
-        if (reg) {
+        if constexpr (BINS) {
+            if (reg) {
+                // =========================== register-resident solver, kernels without objects ===========================
+#include "kb_regsolve_bins.inc"
+            }
+        }
+        if (BINS && reg) {
+        } else if (reg) {
             // =========================== register-resident solver ===========================
             // wave w owns the contacts of the islands placed on it (islWave); lane l holds contacts l, l+64, ...
             unsigned mybase = 0;
@@ -2221,31 +2280,31 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
             const V2 cm = xf_mul(t1, mk2(objBody[tid * BT_WORDS + BT_LCX], objBody[tid * BT_WORDS + BT_LCY]));
             pos[N + tid].x = cm.x; pos[N + tid].y = cm.y;
         }
-        // the new warm-start list becomes the old one
-        for (int b = tid; b < NP; b += nt) { wsCnt[b] = wsCntNew[b]; wsOff[b] = newOff[b]; }
+        // the new warm-start list becomes the old one (nothing of this is read again behind the last substep of a launch)
+        const bool lastSub = sub == p.n_substeps - 1;
+        if (!lastSub) for (int b = tid; b < NP; b += nt) { wsCnt[b] = wsCntNew[b]; wsOff[b] = newOff[b]; }
         if (BINS) {
-            if (p.toi_walls) __syncthreads();      // (the candidate records of the continuous step lie where the image goes)
+            if (p.toi_walls && !lastSub) __syncthreads();      // (the candidate records of the continuous step lie where the image goes)
             // sorted-bin image: the staged contacts 0 .. newTotal - 1 are the packed list (key = bits 16.. of the info word).
             // It becomes the LDS image of the next substep's lookups, or goes out to the global list (last substep of the
             // launch; always when the contacts were staged in the global scratch slice).
-            const bool last = sub == p.n_substeps - 1;
             const unsigned *sInfo = big ? gInfo : lInfo;
             const float *sAcc = big ? gAcc : lAcc;
             const int nlist = (int)min(newTotal, (unsigned)stageCap);
             for (int i = tid; i < nlist; i += nt) {
                 const unsigned key16 = sInfo[i] >> 16;
                 const float acc = sAcc[i];
-                if (newInLds && !last) { oldKey[i] = (unsigned short)key16; oldAcc[i] = acc; }
-                if (last || !newInLds) {
+                if (newInLds && !lastSub) { oldKey[i] = (unsigned short)key16; oldAcc[i] = acc; }
+                if (lastSub || !newInLds) {
                     g.ws_key[wo + i] = key16 >= (unsigned)WALL_CODE ? KEY_WALL + (key16 - WALL_CODE) : key16;
                     g.ws_acc[wo + i] = acc;
                 }
             }
-            for (int c = tid; c < ldsb::bin_entries(p.nhead) / 2; c += nt) reinterpret_cast<unsigned *>(E1)[c] = 0u;     // (the bucket tables lay over the bin boundaries)
+            if (!lastSub) for (int c = tid; c < ldsb::bin_entries(p.nhead) / 2; c += nt) reinterpret_cast<unsigned *>(E1)[c] = 0u;     // (the bucket tables lay over the bin boundaries)
         }
         oldInLds = newInLds;
         oldTotal = newTotal;
-        __syncthreads();
+        if (!lastSub) __syncthreads();
         KB_STAMP(6);
     }
 
@@ -2257,7 +2316,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
         if (b < N) {
             g.x[o + b] = pos[KB_SLOT(q, b)].x; g.y[o + b] = pos[KB_SLOT(q, b)].y; g.theta[o + b] = th[q];
             if (SLEEP && p.n_substeps > 0) g.sleep_time[o + b] = slp[q];
-            if (p.n_substeps > 0) g.ws_cnt[o + b] = wsCnt[b];
+            if (p.n_substeps > 0) g.ws_cnt[o + b] = wsCntNew[b];      // (the counts of the last substep)
             if (KB_LAW(q) == KB_DRIVE_ACCEL && p.n_substeps > 0 && drive) { g.v[o + b] = cv[q]; g.w[o + b] = cw[q]; }
         }
     }

@@ -41,7 +41,10 @@ if os.environ.get('SINGLE'):
                 ostep(1, **okw)
                 gstep(1, actions=actions, light_action=light_action, **kw)
                 state['n'] += 1
-                loud(osim, gsim, 'substep %d' % state['n'], ('x', 'y', 'theta') + (tuple(OBJ_FIELDS[3:]) if osim.cfg.num_objects else ()))
+                loud(osim, gsim, 'substep %d' % state['n'], ('x', 'y', 'theta') + (('sleep_time',) if osim.cfg.allow_sleep else ()) + (tuple(OBJ_FIELDS[3:]) if osim.cfg.num_objects else ()))
+                if os.environ.get('WS'):
+                    from tests.test_parity_gpu import assert_ws_same
+                    assert_ws_same(osim, gsim, 'substep %d' % state['n'])
         osim.step, gsim.step = o_step, g_step
         return osim, gsim
     F.make_pair = make_pair

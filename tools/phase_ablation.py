@@ -24,7 +24,7 @@ PHASES = ['(launch + state load)', 'drive law + bin counters', 'bins sorted (sca
           'stage contacts (owner)', 'label: impulses + island hooking', 'flatten roots', 'census + placement + group by wave',
           'register set-up (load, depth, dealing)', 'warm start', '10 velocity sweeps', 'store + integrate', 'position sweeps',
           'continuous step', 'end of substep + write-back']
-STATE = os.path.join(ROOT, 'gpurun_out', 'abl_state.pt')
+STATE = '/tmp/kb_abl_state.pt'
 
 
 def lib(k):
