@@ -775,8 +775,8 @@ int kb_get_state(kb_sim *sim, float *d_out, void *stream) {
 int kb_lds_bytes(const kb_sim *sim) { return sim ? sim->p.lds_total : KB_EINVAL; }
 int kb_light_action_dim(const kb_sim *sim) { return sim ? sim->p.ladim : KB_EINVAL; }
 int kb_light_count(const kb_sim *sim) { return sim ? (sim->cfg.light_type == KB_LIGHT_NONE ? 0 : sim->p.lcount) : KB_EINVAL; }
-// per contact: the 16-byte staging record + normal and effective mass (12 B) for the sweeps of dense envs
-size_t kb_scratch_bytes(const kb_sim *sim) { return sim ? (size_t)sim->p.E * (size_t)sim->p.cap * 28u : 0; }
+// per contact: the 16-byte staging record + the 16-byte level-sorted record (pair, normal, impulse) of the cooperative sweeps (kernels with objects: normal and effective mass, 12 B)
+size_t kb_scratch_bytes(const kb_sim *sim) { return sim ? (size_t)sim->p.E * (size_t)sim->p.cap * 32u : 0; }
 int kb_contact_capacity(const kb_sim *sim) { return sim ? sim->p.cap : KB_EINVAL; }
 int kb_lds_staging_entries(const kb_sim *sim) { return sim ? sim->p.capL : KB_EINVAL; }
 int kb_block_threads(const kb_sim *sim) { return sim ? sim->threads : KB_EINVAL; }

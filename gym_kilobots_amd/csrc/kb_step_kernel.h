@@ -1263,13 +1263,19 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
         KB_RETID();
         KB_ABLATE_EXIT(8);     // census, placement, contacts grouped by wave
 
+        // a giant island (or the test knob): the whole workgroup sweeps, level by level (kernels without objects; one-wave
+        // workgroups keep the list sweep, their "barrier" is free)
+        const bool coopLevels = BINS && coopForced && nw > 1;
         if constexpr (BINS) {
             if (reg) {
                 // =========================== register-resident solver, kernels without objects ===========================
 #include "kb_regsolve_bins.inc"
+            } else if (coopLevels) {
+                // =========================== cooperative solver by dependency depth, kernels without objects ===========================
+#include "kb_coopsolve_bins.inc"
             }
         }
-        if (BINS && reg) {
+        if (BINS && (reg || coopLevels)) {
         } else if (reg) {
             // =========================== register-resident solver ===========================
             // wave w owns the contacts of the islands placed on it (islWave); lane l holds contacts l, l+64, ...

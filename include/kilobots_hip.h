@@ -270,7 +270,7 @@ int kb_light_count(const kb_sim *sim);          /* light components per env (0 w
 int kb_contact_capacity(const kb_sim *sim);     /* contacts (and warm-start entries) per env */
 int kb_lds_staging_entries(const kb_sim *sim);  /* contacts of one env that are staged in LDS; an env with more takes its slice of
                                                    kb_buffers.scratch for that substep (same results, slower) */
-size_t kb_scratch_bytes(const kb_sim *sim);     /* size of kb_buffers.scratch: 28 B per contact of the capacity (staging record, normal, effective mass) */
+size_t kb_scratch_bytes(const kb_sim *sim);     /* size of kb_buffers.scratch: 32 B per contact of the capacity (staging record; level-sorted record of the cooperative sweeps) */
 int kb_block_threads(const kb_sim *sim);
 int kb_resident_envs_per_cu(kb_sim *sim);        /* workgroups (= envs) of this handle's kernel that one CU holds at a time (HIP occupancy query; needs a GPU) */
 int kb_set_block_threads(kb_sim *sim, int threads);  /* multiple of 64 in [64, 512], num_bots <= 2 * threads.  kb_create picks
