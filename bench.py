@@ -218,8 +218,10 @@ def main():
         okw['sense_radius'] = args.sense
     if args.arena:
         okw.update(world_width=args.arena[0], world_height=args.arena[1])
-    if args.sleep:
-        okw['allow_sleep'] = 1
+    # The library default is the reference's world (doSleep=True, kilobots_env.py:45).  The headline times the instantiation without
+    # the sleep state -- every kilobot is commanded in every substep, so sleeping cannot change a bit of this workload (tests/
+    # test_sleeping.py) -- and reports the one that carries it beside it (`with_sleep_state`; --sleep runs everything on it).
+    okw['allow_sleep'] = 1 if args.sleep else 0
     if args.vel_iters != 10 or args.pos_iters != 10:
         okw.update(vel_iters=args.vel_iters, pos_iters=args.pos_iters)
     sim = KilobotSim(E, N, device=dev, num_objects=args.objects, toi_walls=0 if args.no_toi else 1, **okw)
@@ -358,7 +360,7 @@ def main():
     if rank == 0 and not args.no_fused and plain and world == 1:
         from gym_kilobots_amd import _native as nat
         Ej, settle_j, nj = min(E, 1024), 350, 30
-        sim3 = KilobotSim(Ej, N, nat.DRIVE_SIMPLE_PHOTOTAXIS, nat.LIGHT_CIRCULAR, device=dev, light_radius=2.0)
+        sim3 = KilobotSim(Ej, N, nat.DRIVE_SIMPLE_PHOTOTAXIS, nat.LIGHT_CIRCULAR, device=dev, light_radius=2.0, allow_sleep=0)
         sim3.x.copy_(x0[:Ej]); sim3.y.copy_(y0[:Ej]); sim3.theta.copy_(th[:Ej])
         sim3.forget_contacts()
         sim3.light_x.zero_(); sim3.light_y.zero_()
@@ -377,6 +379,59 @@ def main():
                   'contacts_per_env': contacts_per_env(sim3), 'status_flags': int(sim3.status.max().item())}
         sim3.close()
         del sim3
+
+    # the other single-GPU configurations of BASELINE.json, each with its own launch time and roofline fraction -- reported
+    # next to the headline, never mixed into `value`: cfg2 (256 envs x 64 kilobots) and cfg4 (cfg3 + 4 pushable discs, every
+    # second kilobot ramming ahead) right behind the settle AND 500 substeps later (the rammers pile up against the walls)
+    cfg2 = cfg4 = None
+    if rank == 0 and not args.no_fused and plain and world == 1:
+        def timed(sim_, acts_, n_):
+            e0_, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0_.record()
+            for k_ in range(n_):
+                sim_.step(1, actions=acts_[k_ % len(acts_)])
+            e1_.record()
+            torch.cuda.synchronize()
+            return e0_.elapsed_time(e1_) / n_
+
+        def leg(sim_, ms_, what):
+            Ee, Nn = sim_.num_envs, sim_.num_bots
+            return {'workload': what, 'ms_per_launch': ms_, 'kilobot_steps_per_s_one_gpu': Ee * Nn / (ms_ * 1e-3),
+                    'contacts_per_env': contacts_per_env(sim_), 'status_flags': int(sim_.status.max().item()),
+                    'roofline_frac': ALGO_BYTES_PER_KILOBOT_STEP * Ee * Nn / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    'resident_envs_per_cu': sim_.resident_envs_per_cu, 'workgroup_threads': sim_.block_threads}
+        # cfg2: Gaussian spawn sigma 0.15 m, 100 substeps of warm-up, 400 timed launches
+        E2, N2 = 256, 64
+        s2 = KilobotSim(E2, N2, device=dev, allow_sleep=0)
+        g2 = torch.Generator(device=dev); g2.manual_seed(4242 + args.seed)
+        s2.x.copy_((torch.randn(E2, N2, generator=g2, device=dev) * 0.15 * WORLD_SCALE).clamp_(-0.98 * WORLD_SCALE, 0.98 * WORLD_SCALE))
+        s2.y.copy_((torch.randn(E2, N2, generator=g2, device=dev) * 0.15 * WORLD_SCALE).clamp_(-0.73 * WORLD_SCALE, 0.73 * WORLD_SCALE))
+        s2.theta.copy_((torch.rand(E2, N2, generator=g2, device=dev) * 2.0 - 1.0) * float(np.pi))
+        s2.forget_contacts()
+        a2 = []
+        for _ in range(4):
+            a_ = torch.rand(E2, N2, 2, generator=g2, device=dev)
+            a_[..., 0] *= 0.01
+            a_[..., 1] = (a_[..., 1] - 0.5) * float(np.pi)
+            a2.append(a_.contiguous())
+        timed(s2, a2, 100)
+        cfg2 = leg(s2, timed(s2, a2, 400), 'cfg2: 256 envs x 64 kilobots, Gaussian spawn (sigma 0.15 m), random velocity actions, 1 substep per launch, 400 launches after 100 of warm-up')
+        s2.close()
+        del s2
+        # cfg4: the headline scene + 4 discs of radius 0.075 m at (+-0.5, +-0.35) m, every second kilobot at full speed straight ahead
+        s4 = KilobotSim(E, N, device=dev, num_objects=4, allow_sleep=0)
+        x4, y4, th4, a4 = make_scene(torch, E, N, dev, args.seed, rank, 4)
+        s4.x.copy_(x4); s4.y.copy_(y4); s4.theta.copy_(th4)
+        s4.forget_contacts()
+        s4.set_objects_m(np.tile(CFG4_OBJECTS[None, :4], (E, 1, 1)))
+        timed(s4, a4, settled)
+        ms_a = timed(s4, a4, 40)
+        c_a = leg(s4, ms_a, 'cfg4: cfg3 + 4 pushable discs, every second kilobot ramming ahead; 40 launches right behind %d substeps of settling' % settled)
+        timed(s4, a4, max(0, 500 - settled - 40))
+        ms_b = timed(s4, a4, 40)
+        cfg4 = {'after_settle': c_a, 'after_500_substeps': leg(s4, ms_b, 'the same scene, 40 launches after 500 substeps')}
+        s4.close()
+        del s4
 
     if rank != 0:
         if dist is not None:
@@ -427,6 +482,8 @@ def main():
         'fused_env_step': fused,
         'with_sleep_state': with_sleep,
         'jammed_swarm': jammed,
+        'cfg2': cfg2,
+        'cfg4': cfg4,
         'status_flags': status,
         'returns_gathered': int(all_ret.numel()),
     }

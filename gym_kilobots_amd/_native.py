@@ -181,7 +181,7 @@ def default_config(num_envs, num_bots, drive_mode=DRIVE_VELOCITY, light_type=LIG
     c.damping_model = DAMPING_PADE
     c.sense_radius = 0.0
     c.contact_capacity = 0
-    c.allow_sleep = 0      # b2World(doSleep=...): KilobotsEnv switches it on like kilobots_env.py:45
+    c.allow_sleep = 1      # b2World(gravity=(0, 0), doSleep=True) of kilobots_env.py:45; 0 drops the sleep state
     c.light_count = 1
     for i in range(MAX_LIGHTS):
         c.light_kind[i] = LIGHT_CIRCULAR

@@ -43,7 +43,12 @@ def _compile(args):
     cmd = [os.environ.get('HIPCC', 'hipcc')] + FLAGS + extra + ['-I', INC, '-I', CSRC, '-save-temps=obj', '-c', src, '-o', obj]
     if verbose:
         print(' '.join(cmd))
-    subprocess.check_call(cmd, stderr=subprocess.DEVNULL if not verbose else None)
+    if verbose:
+        subprocess.check_call(cmd)
+    else:       # keep the compiler's diagnostics: a failing build (also the automatic one on import) must say why
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        if r.returncode != 0:
+            raise RuntimeError('hipcc failed (%d) on %s:\n%s' % (r.returncode, os.path.basename(src), r.stderr.decode(errors='replace')[-4000:]))
     # of the saved temporaries only the device assembly is wanted (the rest is hundreds of MB that would travel with
     # every gpurun snapshot)
     stem = obj[:-2]

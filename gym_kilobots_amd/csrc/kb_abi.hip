@@ -215,6 +215,7 @@ __global__ void kb_reset_kernel(const Params p, const ResetArgs a) {
     }
     if (b == 0) p.buf.status[e] = 0;
     if (p.buf.sleep_time) p.buf.sleep_time[i] = 0.0f;      // new bodies are awake (b2BodyDef::awake)
+    if (p.buf.nbr_count) p.buf.nbr_count[i] = 0u;          // (the resolve step does not sense: no counts of the previous episode)
     if (p.M > 0) {      // forget the objects' manifold impulses as well
         float *ows = p.buf.ows_acc + (size_t)e * (MAXOBJ * KB_OWS_COLS * KB_OWS_WORDS);
         for (int k = b; k < MAXOBJ * KB_OWS_COLS * KB_OWS_WORDS; k += p.N) ows[k] = -1.0f;
@@ -453,6 +454,13 @@ int kb_create(const kb_config *cfg, kb_sim **out) {
     const int typical = 3 * p.N + 64 > 256 ? 3 * p.N + 64 : 256;
     if (capLmax > typical) capLmax = typical;
     p.capL = p.cap < capLmax ? p.cap : capLmax;
+    if (cfg->num_objects > 0 || cfg->drive_mode == KB_DRIVE_MIXED) {
+        // kernels with objects: the per-island minimum of the sleep times (N + M words) lies over the pair and info arrays of
+        // the LDS staging area, whatever contact_capacity says
+        int lo = ((((p.N + 3) & ~3) + KB_MAX_OBJECTS + 4 + 1) / 2 + 7) & ~7;
+        if (lo < 64) lo = 64;
+        if (p.capL < lo) p.capL = lo;
+    }
     if (cfg->num_objects == 0 && cfg->drive_mode != KB_DRIVE_MIXED) {
         // sorted-bin image: scratch arrays of the sort lie over the staging area (2 B per kilobot over 4 B per entry); a
         // smaller contact_capacity still bounds what is staged (kernel: min(capL, cap))
@@ -562,7 +570,20 @@ int kb_create(const kb_config *cfg, kb_sim **out) {
         if (p.drive_mode == KB_DRIVE_MIXED) T = p.N <= BPT * 64 ? 64 : 64 * MAX_WAVES;       // the two spill-free instantiations (256 VGPRs)
         s->threads = T;
     }
-    {   // trade a few staging entries for one more env per CU when the LDS footprint is just above a divisor of 160 KiB
+    if (p.M == 0 && p.drive_mode != KB_DRIVE_MIXED) {
+        // sorted-bin image (16 B per staged contact): give up staging entries where that lets the CU hold one more env -- a
+        // 1024-kilobot swarm down to the 688 of the fixed-size kernel (a settled swarm has ~ 0.55 contacts per kilobot; a
+        // jammed one is staged in the global slice whatever the LDS holds, and what it needs is resident envs)
+        const int lo = p.N > 512 ? ldsb::CAPL : (5 * p.N / 2 + 64 > 256 ? 5 * p.N / 2 + 64 : 256);
+        auto res = [&](int c) {
+            const int l = lds_bytes_for(p, s->threads, c);
+            const int a = resident_envs(l, s->threads, KB_MIN_WAVES_PER_SIMD), b = resident_envs(l, s->threads, KB_COMPACT_WAVES_PER_SIMD);
+            return a > b ? a : b;
+        };
+        const int r0 = res(p.capL);
+        for (int c = p.capL - 8; c >= lo; c -= 8)
+            if (res(c) > r0) { p.capL = c; break; }
+    } else {   // trade a few staging entries for one more env per CU when the LDS footprint is just above a divisor of 160 KiB
         const int fit = LDS_CU / lds_bytes_for(p, s->threads, p.capL);
         const int lo = 5 * p.N / 2 + 64 > 256 ? 5 * p.N / 2 + 64 : 256;
         int c = p.capL;

@@ -379,6 +379,14 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Workgroup barrier for phases that only exchange LDS data: __syncthreads() also drains the vector-memory counter
+// (s_waitcnt vmcnt(0)), i.e. it waits for every global load a thread has in flight -- which is exactly what a sweep that
+// requests its records several rounds ahead must not do.  No memory instruction inside: the compiler's own s_waitcnt
+// bookkeeping for the registers of outstanding loads stays valid.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // ---- wave-wide reductions / scan over all 64 lanes with DPP (data-parallel primitives: row shifts inside the four rows of
 // 16 lanes, then the row_bcast steps across rows): six VALU instructions with no trip to the LDS crossbar, where a
 // __shfl_xor / __shfl_up ladder is six dependent ds_bpermute round trips.  All 64 lanes must be active.

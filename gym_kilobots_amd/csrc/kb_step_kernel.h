@@ -415,8 +415,18 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                                      : (key16 >= (unsigned)OBJ_CODE ? KEY_OBJ + (key16 - OBJ_CODE) : key16);
                 // (entries behind the contact capacity were never stored: an env that overflowed lists more per-bot
                 //  entries than its slice holds, and the next env's slice starts right behind it)
-                for (int s = 0; s < cnt && off + s < p.cap; ++s)
-                    if (g.ws_key[wo + off + s] == key32) return g.ws_acc[wo + off + s];
+                // four probes are requested together: one trip to L2 / HBM instead of up to four dependent ones
+                for (int s0 = 0; s0 < cnt; s0 += 4) {
+                    unsigned k4[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int idx = off + s0 + u;
+                        k4[u] = (s0 + u < cnt && idx < p.cap) ? g.ws_key[wo + idx] : 0xFFFFFFFFu;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (k4[u] == key32) return g.ws_acc[wo + off + s0 + u];
+                }
             }
             return -1.0f;   // accumulated impulses are >= 0
         };

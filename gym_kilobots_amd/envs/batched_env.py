@@ -28,6 +28,8 @@ class BatchedKilobotsEnv(object):
         self.num_envs, self.num_kilobots = int(num_envs), int(num_kilobots)
         self.world_width, self.world_height = world_size
         self.spawn_std, self.spawn_mean = spawn_std, np.asarray(spawn_mean, dtype=np.float64)
+        if seed is None:        # (gym convention: no seed given -> draw one; the device reset needs an integer key)
+            seed = int(np.random.SeedSequence().entropy) & 0x7FFFFFFF
         self._rng = np.random.RandomState(seed)
         self._seed = seed
         self._resets = 0

@@ -1678,6 +1678,7 @@ int kbo_reset(const kbo_config *cfg, kbo_state *st, const kbo_reset_params *rp) 
             st->theta[i] = th;
             st->ws_cnt[i] = 0;
             if (cfg->allow_sleep && st->sleep_time) st->sleep_time[i] = 0.0f;          /* new bodies are awake (b2BodyDef::awake) */
+            if (st->nbr_count) st->nbr_count[i] = 0u;                                  /* (the resolve step does not sense) */
             const int law = cfg->drive_mode == KBO_DRIVE_MIXED ? st->bot_mode[i] : cfg->drive_mode;
             if (law == KBO_DRIVE_VELOCITY || law == KBO_DRIVE_ACCEL) {
                 float v = 0.0f, w = 0.0f;

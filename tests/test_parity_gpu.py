@@ -19,6 +19,7 @@ def make_pair(E, N, mode=O.DRIVE_VELOCITY, light=O.LIGHT_NONE, xy=None, th=None,
     from gym_kilobots_amd.sim import KilobotSim
     if objects is not None:
         kw['num_objects'] = objects.shape[-2]
+    kw.setdefault('allow_sleep', 0)      # (the library default is the reference's doSleep=True; the sleeping tests and the fuzz ask for it)
     osim = O.OracleSim(O.default_config(E, N, mode, light, **kw))
     gsim = KilobotSim(E, N, mode, light, debug_outputs=True, **kw)
     if xy is not None:

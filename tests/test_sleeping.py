@@ -273,7 +273,7 @@ def test_benchmark_kernel_without_the_sleep_state_equals_the_sleeping_kernel_on_
     from gym_kilobots_amd.sim import KilobotSim
     E, N = 6, 1024
     xy, th = scenes.lattice_spawn(E, N, seed=9)
-    plain = KilobotSim(E, N)
+    plain = KilobotSim(E, N, allow_sleep=0)
     sleepy = KilobotSim(E, N, allow_sleep=1)
     for s in (plain, sleepy):
         s.set_poses_m(xy, th)

@@ -43,7 +43,7 @@ def settle():
     from gym_kilobots_amd.sim import KilobotSim
     dev = torch.device('cuda:0')
     E, N = 4096, 1024
-    sim = KilobotSim(E, N, device=dev)
+    sim = KilobotSim(E, N, device=dev, allow_sleep=0)
     x, y, th, acts = bench.make_scene(torch, E, N, dev, 0, 0, 0)
     sim.x.copy_(x); sim.y.copy_(y); sim.theta.copy_(th)
     sim.forget_contacts()
@@ -59,7 +59,7 @@ def run(k, launches):
     from gym_kilobots_amd.sim import KilobotSim
     dev = torch.device('cuda:0')
     st = torch.load(STATE)
-    sim = KilobotSim(4096, 1024, device=dev)
+    sim = KilobotSim(4096, 1024, device=dev, allow_sleep=0)
     for f in ('x', 'y', 'theta', 'v', 'w', 'ws_key', 'ws_acc', 'ws_cnt'):
         getattr(sim, f).copy_(st[f].to(dev))
     a = st['actions'].to(dev)

@@ -38,11 +38,11 @@ def main():
         okw = dict(obj_shape=[1] * args.objects, obj_nverts=[4] * args.objects, obj_verts=[[[0.075 * 25.0, 0.075 * 25.0]]] * args.objects)
     if args.cluster:
         from gym_kilobots_amd import _native as nat
-        sim = KilobotSim(E, N, nat.DRIVE_SIMPLE_PHOTOTAXIS, nat.LIGHT_CIRCULAR, light_radius=2.0)
+        sim = KilobotSim(E, N, nat.DRIVE_SIMPLE_PHOTOTAXIS, nat.LIGHT_CIRCULAR, light_radius=2.0, allow_sleep=0)
         sim.light_x.zero_()
         sim.light_y.zero_()
     else:
-        sim = KilobotSim(E, N, num_objects=args.objects, **okw)
+        sim = KilobotSim(E, N, num_objects=args.objects, allow_sleep=0, **okw)
     sim.status = torch.zeros(E + 40 * E, dtype=torch.int32, device=sim.device)   # status + stamp area
     sim._bind()
     xy1, th1 = scenes.lattice_spawn(8, N, seed=1000)
