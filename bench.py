@@ -28,6 +28,7 @@ import json
 import os
 import socket
 import subprocess
+import tempfile
 import sys
 import time
 
@@ -94,7 +95,11 @@ def launch_ranks(n, argv):
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         out = None if r == 0 else subprocess.DEVNULL
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, stdout=out))
+        # every rank's stderr goes to a temporary file: the tail of a failing rank's is forwarded with the exit message
+        err = tempfile.TemporaryFile(mode='w+')
+        p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, stdout=out, stderr=err)
+        p.kb_rank, p.kb_err = r, err
+        procs.append(p)
     rc = 0
     deadline = time.time() + 3000
     pending = list(procs)
@@ -104,10 +109,16 @@ def launch_ranks(n, argv):
             if c is None:
                 continue
             pending.remove(p)
+            p.kb_err.seek(0)
+            tail = p.kb_err.read()[-4000:]
             if c != 0:
+                if rc == 0:                # the first failure is the cause; the ranks terminated because of it only echo it
+                    sys.stderr.write('bench.py: rank %d of %d exited with code %d; the end of its stderr:\n%s\n' % (p.kb_rank, n, c, tail))
                 rc = rc or c
                 for q in pending:          # one rank died: the others would wait in a collective for ever
                     q.terminate()
+            elif p.kb_rank == 0 and tail:
+                sys.stderr.write(tail)     # (warnings of a healthy run stay visible)
         if time.time() > deadline:
             for q in pending:
                 q.kill()
@@ -486,6 +497,9 @@ def main():
         'cfg4': cfg4,
         'status_flags': status,
         'returns_gathered': int(all_ret.numel()),
+        'returns_expected': int(total_envs),
+        'collective_world_size': int(dist.get_world_size()) if dist is not None else 1,
+        'collective_backend': (dist.get_backend() if dist is not None else None),
     }
     if cpu_start is not None:
         out['cpu_baseline'] = cpu_baseline(args, N, cpu_start)

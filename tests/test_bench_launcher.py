@@ -49,3 +49,6 @@ def test_failing_rank_fails_the_launch():
                         '--steps', '1', '--warmup', '0', '--no-cpu-baseline'], env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, timeout=240)
     assert p.returncode != 0
+    # ... and say which rank died and why (the tail of its stderr travels with the exit message)
+    err = p.stderr.decode()
+    assert 'exited with code' in err and 'the end of its stderr' in err and ('Error' in err or 'error' in err), err[-1500:]

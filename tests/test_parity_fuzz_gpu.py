@@ -12,6 +12,24 @@ from tests.test_parity_gpu import make_pair, assert_same, assert_ws_same, cpu, d
 
 pytestmark = pytest.mark.gpu
 
+# how many scenes of a sweep leave at the capacity early-return (the overflow region must be measurable): counted
+# per process, written behind the last scene to gpurun_out/fuzz_summary.txt (and printed with `pytest -s`)
+COUNTS = {'scenes': 0, 'capacity_flag': 0, 'device_limit_flag': 0}
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _fuzz_summary():
+    yield
+    line = ('fuzz sweep: %(scenes)d scenes, %(capacity_flag)d left at the contact-capacity flag (status bit 0, oracle and device agree on it), '
+            '%(device_limit_flag)d at a device-only staging limit (status bit 2)' % COUNTS)
+    print(line)
+    try:
+        os.makedirs('gpurun_out', exist_ok=True)
+        with open(os.path.join('gpurun_out', 'fuzz_summary.txt'), 'a') as f:
+            f.write(line + '\n')
+    except OSError:
+        pass
+
 
 def _random_objects(rng):
     """Random bodies: circles, boxes, triangles and two-/three-part compounds; fixtures shuffled across bodies."""
@@ -143,7 +161,10 @@ def test_random_scene(seed):
             gsim.step(n_sub, light_action=None if la is None else dev(la))
         torch.cuda.synchronize()
         so, sg = osim.status, cpu(gsim.status)
+        if k == 0:
+            COUNTS['scenes'] += 1
         if ((so | sg) & 1).any() or (sg & 4).any():
+            COUNTS['capacity_flag' if ((so | sg) & 1).any() else 'device_limit_flag'] += 1
             # contact capacity exceeded (absurdly dense spawn) or more kilobots on one fixture / in one rank group than
             # the device stages: which contacts are dropped is unspecified, only the flag is
             assert ((so & 1) == (sg & 1)).all(), 'capacity flag differs: %s vs %s' % (so, sg)
