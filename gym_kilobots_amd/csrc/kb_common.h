@@ -75,7 +75,7 @@ constexpr int KREG = KB_KREG;               // contacts a lane can keep in regis
 #endif
 constexpr int CAP_LDS = 1024;         // contacts staged in LDS; denser envs stage in the global scratch slice
 
-enum { M_NCON = 0, M_TOTAL = 1, M_ANY = 2, M_STATUS = 3, M_MAXISL = 4, M_PROF = 5, M_XTRA = 6, M_XFILL = 7, M_WCNT = 8, M_WFILL = 8 + MAX_WAVES, M_COUNT = 8 + 2 * MAX_WAVES };
+enum { M_NCON = 0, M_TOTAL = 1, M_ANY = 2, M_STATUS = 3, M_MAXISL = 4, M_PROF = 5, M_XTRA = 6, M_XFILL = 7, M_WCNT = 8, M_WAKE = 32 /* .. 63: one bit per kilobot (sleeping; the -DKB_PROFILE build keeps its stamps there and does not implement the wake rule) */, M_WFILL = 8 + MAX_WAVES, M_COUNT = 8 + 2 * MAX_WAVES };
 static_assert(M_COUNT <= 64, "misc area");
 
 // ---- LDS layout ----------------------------------------------------------------------------------

@@ -4,6 +4,7 @@
 namespace kb {
 kb_step_fn kb_pick_velocity(int light_type, int objects) {
 #ifdef KB_ONLY_BENCH      // measurement builds: only the benchmark instantiation (fixed size, no objects, no sleep state, no sensing)
+    if (light_type == KB_PICK_FIXED_1024 && objects == KB_PICK_SLEEP) return kb_step_kernel<KB_DRIVE_VELOCITY, KB_LIGHT_NONE, false, 1024, 0, true, false, true>;
     return (light_type == KB_PICK_FIXED_1024 && objects == 0) ? kb_step_kernel<KB_DRIVE_VELOCITY, KB_LIGHT_NONE, false, 1024, 0, true, false> : nullptr;
 #else
     if ((objects & ~KB_PICK_SLEEP) >= 5) return kb_pick_velocity_discs(light_type, objects);      // all objects are discs: kb_inst_d0_discs.hip

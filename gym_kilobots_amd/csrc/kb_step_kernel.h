@@ -399,6 +399,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
         }
         if (OBJ && tid >= M && tid < F) objCnt[tid] = 0;
         if (tid < M_COUNT && tid != M_STATUS) misc[tid] = 0;
+        if (SLEEP && tid < 32) misc[M_WAKE + tid] = 0;      // kilobots woken by a contact that stopped touching (one bit each)
         KB_STAMP_PRE(16);
         __syncthreads();
         KB_STAMP(0);
@@ -409,7 +410,11 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
             const int cnt = wsCnt[owner], off = wsOff[owner];
             if (oldInLds) {
                 for (int s = 0; s < cnt; ++s)
-                    if (oldKey[off + s] == (unsigned short)key16) return oldAcc[off + s];
+                    if (oldKey[off + s] == (unsigned short)key16) {
+                        const float a_ = oldAcc[off + s];
+                        if (SLEEP) oldAcc[off + s] = -1.0f - a_;      // (matched: b2Contact::Update "was touching and still is"; impulses are >= 0)
+                        return a_;
+                    }
             } else {
                 const unsigned key32 = key16 >= (unsigned)WALL_CODE ? KEY_WALL + (key16 - WALL_CODE)
                                      : (key16 >= (unsigned)OBJ_CODE ? KEY_OBJ + (key16 - OBJ_CODE) : key16);
@@ -425,7 +430,11 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
-                        if (k4[u] == key32) return g.ws_acc[wo + off + s0 + u];
+                        if (k4[u] == key32) {
+                            const float a_ = g.ws_acc[wo + off + s0 + u];
+                            if (SLEEP) g.ws_acc[wo + off + s0 + u] = -1.0f - a_;
+                            return a_;
+                        }
                 }
             }
             return -1.0f;   // accumulated impulses are >= 0
@@ -758,6 +767,19 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                     Arena ar;
                     ar.xmin = p.xmin; ar.ymin = p.ymin; ar.xmax = p.xmax; ar.ymax = p.ymax;
                     mcTouch = mc_detect(ox, ar, F, lane, owsMine);
+                    if (SLEEP && !mcTouch) {
+                        // b2Contact::Update: an object pair that was touching in the previous step (a stored manifold) and is not any
+                        // more wakes both bodies (the island seeds are planted two barriers later)
+                        int owner_, col_;
+                        mc_candidate(F, lane, owner_, col_);
+                        if (col_ < 8 && owsMine[(owner_ * KB_OWS_COLS + col_) * KB_OWS_WORDS] >= 0.0f) {
+                            const int m1_ = ot_body(objTab + owner_ * OT_WORDS), m2_ = ot_body(objTab + col_ * OT_WORDS);
+                            if (m1_ != m2_) {
+                                if (objSlp[m1_] < 0.0f) objSlp[m1_] = 0.0f;
+                                if (objSlp[m2_] < 0.0f) objSlp[m2_] = 0.0f;
+                            }
+                        }
+                    }
                 }
             }
 
@@ -1003,6 +1025,36 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
 
         }
 
+        if (SLEEP) {
+            // ---- b2Contact::Update (b2ContactManager::Collide, ahead of b2World::Solve): a contact that was touching in the previous
+            // step and is not any more wakes BOTH bodies.  "Was touching" = an entry of the previous substep's packed list that no
+            // contact of this substep matched (the lookups above flipped the sign of the ones they found).  The owner wakes itself,
+            // its partner through a bit (kilobots) or its sleep time in LDS (objects); walls are static.  The awake seeds of the
+            // islands are planted behind the next barrier. ----
+#pragma unroll
+            for (int q = 0; q < BPT; ++q) {
+                const int b = tid + q * nt;
+                if (b >= N) continue;
+                const int cnt = wsCnt[b], off = wsOff[b];
+                for (int s_ = 0; s_ < cnt && off + s_ < p.cap; ++s_) {
+                    const float a_ = oldInLds ? oldAcc[off + s_] : g.ws_acc[wo + off + s_];
+                    if (a_ < 0.0f) continue;      // matched: still touching
+                    unsigned key = oldInLds ? (unsigned)oldKey[off + s_] : g.ws_key[wo + off + s_];
+                    if (!oldInLds) key = key >= KEY_OBJ ? OBJ_CODE + (key - KEY_OBJ) : (key >= KEY_WALL ? WALL_CODE + (key - KEY_WALL) : key);
+                    if (key >= (unsigned)WALL_CODE) continue;
+                    if (slp[q] < 0.0f) slp[q] = 0.0f;
+                    if (key >= (unsigned)OBJ_CODE) {
+                        if (OBJ) { const int m_ = ot_body(objTab + (key - OBJ_CODE) * OT_WORDS); if (objSlp[m_] < 0.0f) objSlp[m_] = 0.0f; }
+                    } else atomicOr(&misc[M_WAKE + (key >> 5)], 1u << (key & 31u));
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < BPT; ++q) {
+                const int b = tid + q * nt;
+                if (b < N && slp[q] < 0.0f && ((misc[M_WAKE + (b >> 5)] >> (b & 31)) & 1u)) slp[q] = 0.0f;
+            }
+        }
         // ---- islands: flatten roots; empty the grid for the next substep; offsets of the new ws list ----
         for (int b = tid; b < N; b += nt) {
             unsigned r = b;
@@ -1027,23 +1079,27 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
             if (!SLEEP) active[b] = 1;
             active[NB + b] = 0;
         }
-        if (SLEEP) {
+        if (SLEEP && !BINS) {
             // b2World::Solve: islands grow from awake seeds.  active[root] = 1 iff the island has an awake body (every writer
             // stores the same value; the flags were cleared in the drive phase); islands without one are not solved at all.
 #pragma unroll
             for (int q = 0; q < BPT; ++q) {
                 const int b = tid + q * nt;
-                if (b < N && !(slp[q] < 0.0f)) {
-                    // (sorted bins: the kilobot's slot is flattened by another thread of this phase -- walk to the root)
-                    unsigned r = (unsigned)KB_SLOT(q, b);
-                    while (true) { unsigned t = ((volatile unsigned *)parent)[r]; if (t == r) break; r = t; }
-                    active[r] = 1;
-                }
+                if (b < N && !(slp[q] < 0.0f)) active[parent[b]] = 1;
             }
             if (tid < M && !(objSlp[tid] < 0.0f)) active[parent[N + tid]] = 1;
         }
         if (BINS) __syncthreads();
         else newTotal = block_scan_u8(wsCntNew, newOff, NP, wsum);   // (barriers inside)
+        if (SLEEP && BINS) {
+            // (sorted bins: a kilobot's slot is flattened by whichever thread walks that index, so the awake seeds are planted
+            //  behind the barrier; nothing reads the flags before the next one)
+#pragma unroll
+            for (int q = 0; q < BPT; ++q) {
+                const int b = tid + q * nt;
+                if (b < N && !(slp[q] < 0.0f)) active[parent[ms[q]]] = 1;
+            }
+        }
         // is the new packed list kept as an LDS image for the next substep's lookups (sorted bins: the staged contacts ARE the list)
         const bool newInLds = BINS ? !big : newTotal <= (unsigned)capL_;
         if (OBJ && wave == 0) {   // island of every manifold constraint
@@ -2241,8 +2297,12 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
             unsigned short *cSlot = reinterpret_cast<unsigned short *>(active);      // (sorted-bin image)
             const int candMax = BINS ? min(capL_, N) : capL_ / 2;
             int cand[BPT];
-            if (tid == 0) misc[M_NCON] = 0;
-            __syncthreads();
+            // (sorted bins: nothing has counted on misc[M_NCON] since the drive phase zeroed it, and the arrays the candidates
+            //  go to have been idle since the barrier behind the position sweeps)
+            if (!BINS) {
+                if (tid == 0) misc[M_NCON] = 0;
+                __syncthreads();
+            }
 #pragma unroll
             for (int q = 0; q < BPT; ++q) {
                 const int b_ = tid + q * nt;

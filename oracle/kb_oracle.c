@@ -22,7 +22,9 @@
  *     cross(r, n) is ~1e-8 there), so kilobots never receive torque from contacts.
  *   - arena walls are the four infinite lines of the closed chain loop of
  *     kilobots_env.py:46-51 with exact axis normals.
- *   - no sleeping (world is created with doSleep=True, kilobots_env.py:45).
+ *   - sleeping (b2World doSleep=True, kilobots_env.py:45) is restated: b2Island::Solve's allowSleep block, the awake seeds of
+ *     b2World::Solve, the wake rules of the velocity setters and of b2Contact::Update (a contact that stops touching wakes
+ *     both bodies); kbo_config.allow_sleep = 0 drops the state.
  *   - continuous step (b2World::SolveTOI) only against the static walls, which is all Box2D does for
  *     non-bullet bodies; b2TimeOfImpact's control flow is followed with closed-form wall distances (circle
  *     centre; support vertex of a polygon, i.e. the e_faceA separation function on the wall) instead of GJK.
@@ -466,6 +468,7 @@ typedef struct {
     /* sleeping (b2Island::Solve, b2World::Solve): per body sleep time (< 0: asleep), per island root: awake / not solved / min sleep time */
     float *slp, *isl_min; unsigned char *isl_awake, *isl_unsolved;
     int *woff, *wnoff;     /* packed warm-start offsets: previous / next substep */
+    unsigned char *ws_hit; /* previous substep's packed list: entry matched by a contact of this substep (b2Contact::Update wasTouching) */
     float *x0, *y0, *a0;   /* poses at the start of the step (continuous step) */
     int status;
 } work_t;
@@ -483,7 +486,7 @@ static float ws_lookup(const kbo_state *st, const work_t *w, int e, int owner, u
     int cnt = st->ws_cnt[(size_t)e * w->N + owner];
     for (int s = 0; s < cnt && w->woff[owner] + s < w->cap; ++s) {   /* (entries behind the capacity were never stored) */
         size_t idx = (size_t)e * w->cap + (size_t)(w->woff[owner] + s);
-        if (st->ws_key[idx] == key) return st->ws_acc[idx];
+        if (st->ws_key[idx] == key) { w->ws_hit[w->woff[owner] + s] = 1; return st->ws_acc[idx]; }
     }
     return -1.0f;  /* accumulated impulses are >= 0 */
 }
@@ -776,6 +779,7 @@ static void detect_env(const kbo_config *cfg, const derived_t *d, const kbo_stat
     {   /* offsets of the previous substep's packed warm-start list */
         int run = 0;
         for (int b = 0; b < N; ++b) { w->woff[b] = run; run += st->ws_cnt[(size_t)e * N + b]; }
+        if (run > 0) memset(w->ws_hit, 0, (size_t)(run < w->cap ? run : w->cap));
     }
     /* cells */
     memset(w->cell_start, 0, sizeof(int) * (ncell + 1));
@@ -1334,6 +1338,36 @@ static void world_step_env(const kbo_config *cfg, const derived_t *d, kbo_state 
     for (int i = 0; i < w->nmc; ++i) { w->mc[i].skip = 0; if (w->mc[i].a >= 0) uf_union(w->parent, w->mc[i].a, w->mc[i].b); }
     for (int b = 0; b < T; ++b) { w->parent[b] = uf_find(w->parent, b); w->active[b] = 1; }
     if (sleeping) {
+        /* b2Contact::Update (b2ContactManager::Collide, ahead of b2World::Solve): a contact that was touching in the previous
+         * step and is not any more wakes both bodies (SetAwake(true): awake flag, m_sleepTime = 0 if it slept) -- an awake
+         * kilobot that leaves a sleeping neighbour wakes it, and with it the neighbour's resting island.  "Was touching" = an
+         * entry of the previous substep's packed list that no contact of this substep matched; for object pairs an entry of
+         * the manifold table without a manifold now.  (Contacts with the walls: the wall is static, and the kilobot that
+         * leaves it moves, i.e. is awake.) */
+        for (int b = 0; b < N; ++b) {
+            const int cnt = st->ws_cnt[(size_t)e * N + b];
+            for (int s_ = 0; s_ < cnt && w->woff[b] + s_ < w->cap; ++s_) {
+                if (w->ws_hit[w->woff[b] + s_]) continue;
+                const unsigned key = st->ws_key[(size_t)e * w->cap + (size_t)(w->woff[b] + s_)];
+                int other = -1;
+                if (key < KEY_WALL) other = (int)key;
+                else if (key >= KEY_OBJ) other = N + d->fix_body[key - KEY_OBJ];
+                if (other < 0 || other >= T) continue;
+                if (w->slp[b] < 0.0f) w->slp[b] = 0.0f;
+                if (w->slp[other] < 0.0f) w->slp[other] = 0.0f;
+            }
+        }
+        for (int f1 = 0; f1 < d->nfix; ++f1)
+            for (int f2 = f1 + 1; f2 < d->nfix; ++f2) {
+                const float *old = st->ows_acc + (((size_t)e * KBO_MAX_OBJECTS + f1) * OWS + f2) * OWW;
+                if (!(old[0] >= 0.0f) || d->fix_body[f1] == d->fix_body[f2]) continue;
+                int now = 0;
+                for (int i = 0; i < w->nmc; ++i) now |= (w->mc[i].owner == f1 && w->mc[i].col == f2);
+                if (now) continue;
+                const int b1 = N + d->fix_body[f1], b2 = N + d->fix_body[f2];
+                if (w->slp[b1] < 0.0f) w->slp[b1] = 0.0f;
+                if (w->slp[b2] < 0.0f) w->slp[b2] = 0.0f;
+            }
         /* b2World::Solve: islands grow from AWAKE seeds and wake every body they reach (b2Body::SetAwake(true): flag set,
          * m_sleepTime = 0 if it was asleep); components without an awake body are not simulated at all: their bodies do
          * not move, their contacts keep their impulses */
@@ -1870,10 +1904,11 @@ static int work_alloc(work_t *w, const kbo_config *cfg, const derived_t *d) {
     w->active = (unsigned char *)malloc(4 * (size_t)T); w->next_active = w->active + T;
     w->isl_awake = w->next_active + T; w->isl_unsolved = w->isl_awake + T;
     w->slp = (float *)malloc(sizeof(float) * T * 2); w->isl_min = w->slp + T;
-    return (w->px && w->cell && w->cell_start && w->cell_items && w->con && w->parent && w->active && w->slp) ? 0 : -1;
+    w->ws_hit = (unsigned char *)malloc((size_t)w->cap + 1);
+    return (w->px && w->cell && w->cell_start && w->cell_items && w->con && w->parent && w->active && w->slp && w->ws_hit) ? 0 : -1;
 }
 static void work_free(work_t *w) {
-    free(w->px); free(w->cell); free(w->cell_start); free(w->cell_items); free(w->con); free(w->parent); free(w->active); free(w->slp);
+    free(w->px); free(w->cell); free(w->cell_start); free(w->cell_items); free(w->con); free(w->parent); free(w->active); free(w->slp); free(w->ws_hit);
 }
 
 int kbo_step(const kbo_config *cfg, kbo_state *st, const float *light_action, int n_substeps, int flags,

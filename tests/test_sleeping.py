@@ -289,3 +289,58 @@ def test_benchmark_kernel_without_the_sleep_state_equals_the_sleeping_kernel_on_
     assert sleepy.sleep_time.max().item() > 0.0
     # (both are fixed-size 1024-kilobot instantiations, three envs per CU: with and without the sleep state)
     assert plain.lds_bytes == 52496 and sleepy.lds_bytes == 52496 and sleepy.resident_envs_per_cu == 3
+
+
+def _creeper_scene():
+    """Kilobot 0 creeps away from kilobot 1 below the sleep tolerance (0.0002 m/s = 0.005 units/s < b2_linearSleepTolerance): its tiny
+    command re-wakes it every substep, both rest, the pair falls asleep at the end of substeps 5 and 10, and substep 10 is the one in
+    which they stop touching (initial overlap 0.0044 units, 0.000463 units per substep)."""
+    xy = np.array([[[0.0, 0.0], [0.8206 / 25.0, 0.0]]])
+    th = np.array([[np.pi, 0.0]])
+    a = np.zeros((1, 2, 2), np.float32)
+    a[0, 0, 0] = 0.0002
+    return xy, th, a
+
+
+def test_a_contact_that_stops_touching_wakes_the_sleeping_partner():
+    """b2Contact::Update: `if (touching != wasTouching) { bodyA->SetAwake(true); bodyB->SetAwake(true); }` -- ADVICE r02 (medium).
+    In substep 11 the creeper wakes up (its command), finds the contact gone, and that wakes kilobot 1 although no island reaches it
+    any more: its sleep time restarts (0.1 .. 0.4, asleep again at the end of substep 15).  Without the rule it would stay asleep."""
+    xy, th, a = _creeper_scene()
+    s = _sim(1, 2, xy[0], th=th, allow_sleep=1)
+    s.set_actions(a)
+    trace = []
+    for k in range(20):
+        s.step(1)
+        trace.append(s.sleep_time[0].copy())
+    trace = np.array(trace)
+    assert (trace[4] < 0).all() and (trace[9] < 0).all()                       # asleep together at the end of substeps 5 and 10
+    assert np.allclose(trace[10:14, 1], [0.1, 0.2, 0.3, 0.4], atol=1e-6)       # woken by the contact that ended
+    assert trace[14, 1] < 0 and (trace[15:, 1] < 0).all()                      # ... asleep again, and left alone by the creeper from then on
+    assert np.allclose(trace[15:19, 0], [0.1, 0.2, 0.3, 0.4], atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_contact_end_wake_rule_on_the_device():
+    from tests.test_parity_gpu import assert_same, assert_ws_same, dev, make_pair
+    xy, th, a = _creeper_scene()
+    E = 3                                                 # the same pair three times, padded with far-away kilobots in envs 1 and 2
+    N = 8
+    XY = np.zeros((E, N, 2)); TH = np.zeros((E, N)); A = np.zeros((E, N, 2), np.float32)
+    XY[:, :, 0] = 0.3 + 0.08 * np.arange(N)[None]
+    XY[:, :, 1] = 0.4
+    for e in range(E):
+        XY[e, 2 * e:2 * e + 2] = xy[0] + [0.1 * e, -0.2 * e]
+        TH[e, 2 * e:2 * e + 2] = th[0]
+        A[e, 2 * e] = a[0, 0]
+    osim, gsim = make_pair(E, N, O.DRIVE_VELOCITY, O.LIGHT_NONE, xy=XY, th=TH, allow_sleep=1)
+    osim.set_actions(A)
+    gsim.set_actions(dev(A))
+    woken = False
+    for k in range(20):
+        osim.step(1)
+        gsim.step(1)
+        assert_same(osim, gsim, 'substep %d' % k, SLEEP_FIELDS)
+        woken = woken or (k == 11 and bool((osim.sleep_time[np.arange(E), 2 * np.arange(E) + 1] > 0).all()))
+    assert woken
+    assert_ws_same(osim, gsim, 'end')

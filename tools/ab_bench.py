@@ -16,7 +16,7 @@ def one():
     from gym_kilobots_amd.sim import KilobotSim
     dev = torch.device('cuda:0')
     E, N = 4096, 1024
-    sim = KilobotSim(E, N, device=dev, allow_sleep=0)
+    sim = KilobotSim(E, N, device=dev, allow_sleep=int(os.environ.get('KB_AB_SLEEP', '0')))
     x, y, th, acts = bench.make_scene(torch, E, N, dev, 0, 0, 0)
     sim.x.copy_(x); sim.y.copy_(y); sim.theta.copy_(th)
     sim.forget_contacts()

@@ -649,7 +649,11 @@ class Contact:
         new = self.fn(self.fA.shape, bA.xf, self.fB.shape, bB.xf)
         if new.type is None:
             new.points = []
+        was_touching = self.touching
         self.touching = len(new.points) > 0
+        if self.touching != was_touching:          # b2Contact::Update: "if (touching != wasTouching) { bodyA->SetAwake(true); bodyB->SetAwake(true); }"
+            bA.set_awake(True)
+            bB.set_awake(True)
         for mp in new.points:
             for op in old.points:
                 if op.id == mp.id:

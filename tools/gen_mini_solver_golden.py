@@ -64,6 +64,15 @@ SCENES = {
                                       commands=[[6, [[0.0, 0.0], [0.0, 0.0]]], [16, [[0.0003, 0.0], [0.0, 0.0]]], [24, [[0.008, -0.3], [0.0, 0.0]]]]),
     'sleeping_bot_woken_by_a_pusher': dict(kilobots=[[0.0, 0.0, 0.0, 0.0, 0.0], [1.5, 0.05, math.pi, 0.0, 0.0]], objects=[], steps=60, tol=5e-5, sleep=True,
                                            commands=[[8, [[0.0, 0.0], [0.01, 0.0]]]]),
+    # b2Contact::Update: a contact that stops touching wakes both bodies -- kilobot 2 rests against kilobots 0 and 1, all three fall
+    # asleep, then it is commanded away: its departure (the contacts end) wakes the two it leaves behind, whose sleep times restart
+    'mover_leaves_a_sleeping_pair': dict(kilobots=[[0.0, 0.0, 0.0, 0.0, 0.0], [0.0, 0.82, 0.0, 0.0, 0.0], [0.71, 0.41, 0.0, 0.0, 0.0]], objects=[],
+                                         steps=40, tol=5e-5, sleep=True, commands=[[14, [[0.0, 0.0], [0.0, 0.0], [0.01, 0.0]]]]),
+    # ... and the case in which ONLY that rule wakes the sleeper: kilobot 0 creeps away from kilobot 1 below the sleep tolerance (its
+    # tiny command re-wakes it every step, b2Body::SetLinearVelocity); both rest, fall asleep together at the end of step 10 -- the
+    # step in which they stop touching -- and in step 11 the creeper's wake-up finds the contact gone: kilobot 1 is woken although no
+    # island reaches it any more, and sleeps again five steps later
+    'creeper_leaves_a_sleeper': dict(kilobots=[[0.0, 0.0, math.pi, 0.0002, 0.0], [0.8206, 0.0, 0.0, 0.0, 0.0]], objects=[], steps=20, tol=2e-5, sleep=True),
     'disc_coasts_to_sleep': dict(kilobots=[[20.0, 15.0, 0.0, 0.0, 0.0]], objects=[dict(shape='circle', r=1.5, x=0.0, y=0.0, theta=0.0, vx=0.6, vy=0.2, w=0.3)],
                                  steps=70, tol=5e-5, sleep=True, contact_free=True),
     # kilobots of different classes: fixture density 2 (SimpleVelocityControlKilobot, kilobot.py:214) against density 1 (Kilobot,
