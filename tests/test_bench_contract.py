@@ -58,3 +58,19 @@ def test_bench_line_reports_the_legs_next_to_the_headline():
     assert j['contacts_per_env'] > 2000 and j['status_flags'] == 0          # one island, far beyond the LDS staging
     assert abs(j['kilobot_steps_per_s_one_gpu'] - 1024 * 1024 / (j['ms_per_launch'] * 1e-3)) < 1e-6 * j['kilobot_steps_per_s_one_gpu']
     assert j['kilobot_steps_per_s_one_gpu'] < d['value']                    # the slow corner, reported as such
+
+
+def test_bench_line_reports_the_small_and_the_object_configuration():
+    """cfg2 (the reference's own CPU-sized case) and cfg4 (cfg3 + pushable objects) are legs of the same line since round 3;
+    each states its launch time, the rate that follows from it and the share of the HBM roofline, none of them is the value."""
+    d = json.loads(open(_latest('bench_line.json')).readline())
+    c2 = d['cfg2']
+    assert '256 envs x 64 kilobots' in c2['workload'] and c2['status_flags'] == 0
+    assert abs(c2['kilobot_steps_per_s_one_gpu'] - 256 * 64 / (c2['ms_per_launch'] * 1e-3)) < 1e-6 * c2['kilobot_steps_per_s_one_gpu']
+    for leg in ('after_settle', 'after_500_substeps'):
+        c4 = d['cfg4'][leg]
+        assert c4['status_flags'] == 0 and c4['contacts_per_env'] > 450
+        assert abs(c4['kilobot_steps_per_s_one_gpu'] - 4096 * 1024 / (c4['ms_per_launch'] * 1e-3)) < 1e-6 * c4['kilobot_steps_per_s_one_gpu']
+        assert abs(c4['roofline_frac'] - 48.0 * c4['kilobot_steps_per_s_one_gpu'] / 8e12) < 1e-3 * c4['roofline_frac']
+        assert c4['kilobot_steps_per_s_one_gpu'] < d['value']
+    assert d['returns_expected'] == d['returns_gathered'] == 4096 and d['collective_world_size'] == 1
