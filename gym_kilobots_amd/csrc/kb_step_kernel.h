@@ -157,22 +157,54 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
     int ms[BPT];         // sorted-bin image: the slot this thread's kilobots live in (the kilobot's id until the first sort)
 #define KB_LAW(q) (MIX ? law[q] : DRIVE_MODE)
 #define KB_SLOT(q, b_) (BINS ? ms[q] : (b_))     // index of kilobot b_ (= tid + q * nt) in the per-body LDS arrays
+    // Every load of the kernel start is issued before the first store: the set_action stores (g.v / g.w) may alias anything as far
+    // as the compiler can tell, and loads that follow them in program order would wait for the previous kilobot's round trip to
+    // HBM -- four dependent trips per thread (state, action, state, action) instead of one.
+    float ldx[BPT], ldy[BPT];
+    unsigned ldc[BPT];
+    float2 lda[BPT];
 #pragma unroll
     for (int q = 0; q < BPT; ++q) {
         const int b = tid + q * nt;
         th[q] = 0.0f; bw[q] = 0.0f; cv[q] = 0.0f; cw[q] = 0.0f; av[q] = 0.0f; aw[q] = 0.0f; slp[q] = 0.0f; law[q] = DRIVE_MODE;
+        float z_ = 0.0f;
+        asm volatile("" : "+v"(z_));     // (opaque: keeps the clamping of the action behind all loads instead of behind its own)
+        ldx[q] = 0.0f; ldy[q] = 0.0f; ldc[q] = 0u; lda[q] = make_float2(z_, z_);
         ms[q] = b < N ? b : NB - 1;
         if (b < N) {
-            pos[b].x = g.x[o + b]; pos[b].y = g.y[o + b]; th[q] = g.theta[o + b];
-            if (MIX) { law[q] = min((int)g.bot_mode[o + b], 4); botLaw[b] = (unsigned char)law[q]; }
+            ldx[q] = g.x[o + b]; ldy[q] = g.y[o + b]; th[q] = g.theta[o + b];
+            if (MIX) law[q] = min((int)g.bot_mode[o + b], 4);
             if (SLEEP) slp[q] = g.sleep_time[o + b];
-            wsCnt[b] = g.ws_cnt[o + b];
+            ldc[q] = g.ws_cnt[o + b];
             // (a velocity action replaces the stored command: nothing to load then)
             const bool velmode = KB_LAW(q) == KB_DRIVE_VELOCITY || KB_LAW(q) == KB_DRIVE_ACCEL;
             if (velmode && !(KB_LAW(q) == KB_DRIVE_VELOCITY && p.actions)) { cv[q] = g.v[o + b]; cw[q] = g.w[o + b]; }
             if (KB_LAW(q) == KB_DRIVE_ACCEL) { av[q] = g.acc_v[o + b]; aw[q] = g.acc_w[o + b]; }
-            if (p.actions) {
-                const float2 a = reinterpret_cast<const float2 *>(p.actions)[o + b];
+            if (p.actions && velmode) lda[q] = reinterpret_cast<const float2 *>(p.actions)[o + b];
+        }
+    }
+    // Sorted-bin image: the packed warm-start list of the previous launch is requested together with the state (the same trip
+    // to HBM); how many of its entries exist is only known behind the offset scan below.
+    unsigned pfKey[2] = {0u, 0u};
+    float pfAcc[2] = {0.0f, 0.0f};
+    if (BINS && p.n_substeps > 0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int i = tid + q * nt;
+            if (i < capL_ && i < p.cap) { pfKey[q] = g.ws_key[wo + i]; pfAcc[q] = g.ws_acc[wo + i]; }
+        }
+    }
+    int hasAct = __builtin_amdgcn_readfirstlane((int)(p.actions != nullptr));
+    asm volatile("" : "+s"(hasAct));      // (opaque: the two "is there an action" branches must not be merged again)
+#pragma unroll
+    for (int q = 0; q < BPT; ++q) {
+        const int b = tid + q * nt;
+        if (b < N) {
+            pos[b] = make_float2(ldx[q], ldy[q]);
+            if (MIX) botLaw[b] = (unsigned char)law[q];
+            wsCnt[b] = (unsigned char)ldc[q];
+            if (hasAct) {
+                const float2 a = lda[q];
                 const float mw = 0.5f * 3.14159265358979323846f;
                 if (KB_LAW(q) == KB_DRIVE_VELOCITY) {
                     cv[q] = fmaxf(fminf(a.x, 0.01f), 0.0f);
@@ -185,17 +217,6 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                     g.acc_v[o + b] = av[q]; g.acc_w[o + b] = aw[q];
                 }
             }
-        }
-    }
-    // Sorted-bin image: the packed warm-start list of the previous launch is requested together with the state (the same trip
-    // to HBM); how many of its entries exist is only known behind the offset scan below.
-    unsigned pfKey[2] = {0u, 0u};
-    float pfAcc[2] = {0.0f, 0.0f};
-    if (BINS && p.n_substeps > 0) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int i = tid + q * nt;
-            if (i < capL_ && i < p.cap) { pfKey[q] = g.ws_key[wo + i]; pfAcc[q] = g.ws_acc[wo + i]; }
         }
     }
     for (int b = N + tid; b < NP; b += nt) { wsCnt[b] = 0; wsCntNew[b] = 0; }
@@ -483,6 +504,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                 vel[sl] = make_float2(svx[q], svy[q]);
                 parent[sl] = (unsigned)sl;
             }
+            if (tid < 4) vel[NB - 5 + tid] = make_float2(0.0f, 0.0f);   // the four walls as bodies at rest (kb_regsolve_bins.inc)
             KB_STAMP_PRE(33);    // ... + wave 0's kilobots settled in their slots
             __syncthreads();
             KB_STAMP(0);
