@@ -405,6 +405,12 @@ int kb_create(const kb_config *cfg, kb_sim **out) {
     p.r_bot = cfg->bot_radius * WORLD_SCALE;
     const float m = cfg->bot_density * B2_PI * p.r_bot * p.r_bot;  // b2CircleShape::ComputeMass
     p.im_bot = m > 0.0f ? 1.0f / m : 0.0f;
+    {
+        const float rr = p.r_bot + p.r_bot, rw = B2_POLYGON_RADIUS + p.r_bot;
+        p.rr2 = rr * rr; p.rw2 = rw * rw; p.rw_tot = p.r_bot + B2_POLYGON_RADIUS;
+        const float kbb = p.im_bot + p.im_bot, kwb = 0.0f + p.im_bot;
+        p.nm_bb = kbb > 0.0f ? 1.0f / kbb : 0.0f; p.nm_wb = kwb > 0.0f ? 1.0f / kwb : 0.0f;
+    }
     for (int k = 0; k < 5; ++k) {       // KB_DRIVE_MIXED: the classes have different fixture densities (kilobot.py:25 / :214)
         p.im_mode[k] = p.im_bot;
         if (cfg->drive_mode == KB_DRIVE_MIXED && cfg->mode_density[k] > 0.0f) {

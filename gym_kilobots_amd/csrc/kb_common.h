@@ -241,6 +241,10 @@ struct Params {
     int islmin_off;                           // sorted-bin image, SLEEP: LDS offset of the per-island minimum of the sleep times (NB words)
     int sense_s;                              // IR neighbour sensing: reach of the stencil in cells (0 = off)
     float sense_r2;                           // ... and the squared radius in world units
+    // uniform constants of the contact search and the solver, evaluated once on the host (same fp32 expressions): as kernel
+    // arguments they live in scalar registers -- computed in the kernel they would hold a vector register each
+    float rr2, rw2, rw_tot;                   // (r + r)^2;  (polygonRadius + r)^2;  r + polygonRadius
+    float nm_bb, nm_wb;                       // effective mass of a kilobot-kilobot and of a wall-kilobot contact
 };
 
 
@@ -667,8 +671,10 @@ __device__ __forceinline__ int dir_dy(int k) { return (k >= 2) ? 1 : 0; }
 
 // exclusive scan of NP (multiple of 4, <= 4 * blockDim.x) u8 counts into u16 offsets; returns the total.
 // All threads must call; contains two workgroup barriers.
-__device__ __forceinline__ unsigned block_scan_u8(const unsigned char *cnt, unsigned short *off, int NP, unsigned *wsum) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+// (tid: the caller's copy of threadIdx.x -- inside the substep loop an opaque one, so that nothing derived from it is hoisted
+//  out of the loop and kept in spilled registers)
+__device__ __forceinline__ unsigned block_scan_u8(const unsigned char *cnt, unsigned short *off, int NP, unsigned *wsum, int tid) {
+    const int lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const bool in = 4 * tid < NP;
     const unsigned c4 = in ? *reinterpret_cast<const unsigned *>(cnt + 4 * tid) : 0u;
     const unsigned c0 = c4 & 255u, c1 = (c4 >> 8) & 255u, c2 = (c4 >> 16) & 255u, c3 = c4 >> 24;
@@ -694,8 +700,8 @@ __device__ __forceinline__ unsigned block_scan_u8(const unsigned char *cnt, unsi
 // slots [E1[b], E1[b + 1]).  nchunks chunks of 8 u16 entries (16 bytes, padding zero); thread t scans `per` consecutive chunks.
 // All threads must call; two workgroup barriers inside.
 template <bool ONE>
-__device__ __forceinline__ void block_scan_bins(unsigned short *E1, int nchunks, int per, unsigned *wsum) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+__device__ __forceinline__ void block_scan_bins(unsigned short *E1, int nchunks, int per, unsigned *wsum, int tid) {
+    const int lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const int c0 = ONE ? tid : tid * per, c1 = ONE ? min(tid + 1, nchunks) : min(c0 + per, nchunks);
     uint4 v = make_uint4(0u, 0u, 0u, 0u);
     unsigned sum = 0;

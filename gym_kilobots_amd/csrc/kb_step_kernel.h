@@ -156,6 +156,10 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
     int law[BPT];        // drive law of this thread's kilobots
     int ms[BPT];         // sorted-bin image: the slot this thread's kilobots live in (the kilobot's id until the first sort)
 #define KB_LAW(q) (MIX ? law[q] : DRIVE_MODE)
+    // Velocity control, sorted-bin image: the command (v, omega) of a kilobot waits for the drive phase in the LDS velocity array
+    // (idle between the substeps, indexed by id) instead of in two registers that the allocator would keep in scratch memory
+    // from the kernel start on; between fused substeps it is read again from g.v / g.w, where the kernel start left it.
+    constexpr bool PARK = BINS && !MIX && DRIVE_MODE == KB_DRIVE_VELOCITY;
 #define KB_SLOT(q, b_) (BINS ? ms[q] : (b_))     // index of kilobot b_ (= tid + q * nt) in the per-body LDS arrays
     // Every load of the kernel start is issued before the first store: the set_action stores (g.v / g.w) may alias anything as far
     // as the compiler can tell, and loads that follow them in program order would wait for the previous kilobot's round trip to
@@ -217,6 +221,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                     g.acc_v[o + b] = av[q]; g.acc_w[o + b] = aw[q];
                 }
             }
+            if (PARK) vel[b] = make_float2(cv[q], cw[q]);
         }
     }
     for (int b = N + tid; b < NP; b += nt) { wsCnt[b] = 0; wsCntNew[b] = 0; }
@@ -260,11 +265,10 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
         kb_light_general_sense(p, glx, gly, sx, sy, val, gx, gy);
     };
     const bool drive = !(p.flags & KB_STEP_NO_DRIVE);
-    const float rr = p.r_bot + p.r_bot, rr2 = rr * rr;
-    const float rw = B2_POLYGON_RADIUS + p.r_bot, rw2 = rw * rw;
+    const float rr2 = p.rr2, rw2 = p.rw2;     // (r + r)^2, (polygonRadius + r)^2: host-evaluated, scalar registers
     __syncthreads();
     // warm-start list of the previous substep: offsets, and an LDS image of the packed entries if it fits
-    unsigned oldTotal = block_scan_u8(wsCnt, wsOff, NP, wsum);
+    unsigned oldTotal = block_scan_u8(wsCnt, wsOff, NP, wsum, tid);
     bool oldInLds = oldTotal <= (unsigned)capL_;
     if (BINS && oldInLds) {
 #pragma unroll
@@ -349,8 +353,11 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                 case KB_DRIVE_VELOCITY: {  // kilobot.py:253-258
                     float s, c;
                     kb_sincosf(t, s, c);
-                    float sp = cv[q] * WORLD_SCALE;
-                    bvx = c * sp; bvy = s * sp; bww = cw[q];
+                    float cvq = cv[q], cwq = cw[q];
+                    if (PARK) { const float2 c_ = vel[b]; cvq = c_.x; cwq = c_.y; }
+                    asm volatile("" : "+v"(cvq));     // (keeps the product below inside the substep loop: hoisted, it is one more register spilled across the launch)
+                    float sp = cvq * WORLD_SCALE;
+                    bvx = c * sp; bvy = s * sp; bww = cwq;
                 } break;
                 case KB_DRIVE_PHOTOTAXIS: {  // kilobot.py:318-333
                     int upd = g.pt_update[o + b];
@@ -468,8 +475,8 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
             // 1. boundaries of the bins: inclusive scan of the counters (E1[b] .. E1[b + 1] = slots of bin b)
             {
                 const int nchunks = ldsb::bin_entries(p.nhead) >> 3;
-                if (nchunks <= nt) block_scan_bins<true>(E1, nchunks, 1, wsum);
-                else block_scan_bins<false>(E1, nchunks, (nchunks + nt - 1) / nt, wsum);
+                if (nchunks <= nt) block_scan_bins<true>(E1, nchunks, 1, wsum, tid);
+                else block_scan_bins<false>(E1, nchunks, (nchunks + nt - 1) / nt, wsum, tid);
             }
             KB_STAMP_PRE(31);    // (profile build, cumulative since the drive barrier) bin boundaries scanned
             // 2. scatter in arrival order ...
@@ -504,7 +511,11 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                 vel[sl] = make_float2(svx[q], svy[q]);
                 parent[sl] = (unsigned)sl;
             }
-            if (tid < 4) vel[NB - 5 + tid] = make_float2(0.0f, 0.0f);   // the four walls as bodies at rest (kb_regsolve_bins.inc)
+            if (tid < 4) {      // the four walls as bodies at rest (kb_regsolve_bins.inc)
+                float z_ = 0.0f;
+                asm volatile("" : "+v"(z_));      // (a zero made here, not a register pair kept -- in scratch memory -- from the kernel start on)
+                vel[NB - 5 + tid] = make_float2(z_, z_);
+            }
             KB_STAMP_PRE(33);    // ... + wave 0's kilobots settled in their slots
             __syncthreads();
             KB_STAMP(0);
@@ -1112,7 +1123,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
             if (tid < M && !(objSlp[tid] < 0.0f)) active[parent[N + tid]] = 1;
         }
         if (BINS) __syncthreads();
-        else newTotal = block_scan_u8(wsCntNew, newOff, NP, wsum);   // (barriers inside)
+        else newTotal = block_scan_u8(wsCntNew, newOff, NP, wsum, tid);   // (barriers inside)
         if (SLEEP && BINS) {
             // (sorted bins: a kilobot's slot is flattened by whichever thread walks that index, so the awake seeds are planted
             //  behind the barrier; nothing reads the flags before the next one)
@@ -1378,8 +1389,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
             float rrAx[KREG], rrAy[KREG], rlnx[KREG], rlny[KREG], rlpx[KREG], rlpy[KREG];
             unsigned mlo = 0, mhi = 0;
             // without objects the masses / radii of a contact follow from "is A a wall": no registers needed
-            const float kbb_ = p.im_bot + p.im_bot, kwb_ = 0.0f + p.im_bot;
-            const float nm_bb = kbb_ > 0.0f ? 1.0f / kbb_ : 0.0f, nm_wb = kwb_ > 0.0f ? 1.0f / kwb_ : 0.0f;
+            const float nm_bb = p.nm_bb, nm_wb = p.nm_wb;
 #define R_IMA(j) (OBJ ? rima[j] : (ra[j] < WALL_CODE ? p.im_bot : 0.0f))
 #define R_IMB(j) (OBJ ? rimb[j] : p.im_bot)
 #define R_RA(j) (OBJ ? rra[j] : (ra[j] < WALL_CODE ? p.r_bot : B2_POLYGON_RADIUS))
@@ -2332,7 +2342,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                 if (b_ >= N) continue;
                 const int b = KB_SLOT(q, b_);
                 if (SLEEP && slp[q] < 0.0f) continue;           // b2World::SolveTOI skips contacts without an awake dynamic body
-                const float total = p.r_bot + B2_POLYGON_RADIUS;
+                const float total = p.rw_tot;       // r + polygonRadius
                 const float xa = BINS ? startX[b] : start[b].x, ya = BINS ? startY[b] : start[b].y, xb = pos[b].x, yb = pos[b].y;
                 const float m0 = fminf(fminf(xa - p.xmin, p.xmax - xa), fminf(ya - p.ymin, p.ymax - ya));
                 const float m1 = fminf(fminf(xb - p.xmin, p.xmax - xb), fminf(yb - p.ymin, p.ymax - yb));
@@ -2380,6 +2390,13 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
         }
         // the new warm-start list becomes the old one (nothing of this is read again behind the last substep of a launch)
         const bool lastSub = sub == p.n_substeps - 1;
+        if (PARK && !lastSub) {      // the commands of the next substep's drive phase (the velocity array is idle behind the last barrier)
+#pragma unroll
+            for (int q = 0; q < BPT; ++q) {
+                const int b = tid + q * nt;
+                if (b < N) vel[b] = make_float2(g.v[o + b], g.w[o + b]);
+            }
+        }
         if (!lastSub) for (int b = tid; b < NP; b += nt) { wsCnt[b] = wsCntNew[b]; wsOff[b] = newOff[b]; }
         if (BINS) {
             if (p.toi_walls && !lastSub) __syncthreads();      // (the candidate records of the continuous step lie where the image goes)
