@@ -1519,6 +1519,16 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                 const unsigned lo = wave_or((unsigned)mine), hi = wave_or((unsigned)(mine >> 32));
                 slotLevels[j] = ((unsigned long long)hi << 32) | (unsigned long long)lo;
             }
+            // The levels of a slot are a contiguous range (the dealing above; without it everything sits in slot 0) and the ranges
+            // of successive slots follow each other: a sweep is slot 0's levels in order, then slot 1's, ... -- contacts of one
+            // level never share a body, so a level split over two slots may run in two rounds.  (kb_regsolve_bins.inc)
+            int dlo[KREG], dhi[KREG];
+#pragma unroll
+            for (int j = 0; j < KREG; ++j) {
+                const unsigned long long lv = slotLevels[j] >> 1;      // (level 0: contacts of sleeping islands, in no round)
+                dlo[j] = lv ? (int)__builtin_ctzll(lv) + 1 : 1;
+                dhi[j] = lv ? ((lv >> 62) ? maxD : 64 - (int)__builtin_clzll(lv)) : 0;
+            }
             // ---- full load of the contacts ----
             // Kernels with objects (except the spill-free WIDE ones): lanes without a contact in slot j load a copy of the
             // wave's first contact and drop it again, so that the slot loads run under the full EXEC mask.  (These kernels
@@ -1594,11 +1604,11 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
             KB_STAMP(7);     // register load + depth sweep of wave 0 (no barrier: wave-local time)
 #endif
 #define KB_REG_ROUNDS(...)                                                                          \
-            for (int d_ = 1; d_ <= maxD; ++d_) {                                                    \
-                _Pragma("unroll") for (int j = 0; j < KREG; ++j)                                    \
+            _Pragma("unroll") for (int j = 0; j < KREG; ++j)                                        \
+                for (int d_ = dlo[j]; d_ <= dhi[j]; ++d_) {                                         \
                     if (rvalid[j] && rdepth[j] == d_) { __VA_ARGS__ }                               \
-                wave_sync();                                                                        \
-            }
+                    wave_sync();                                                                    \
+                }
 
             KB_ABLATE_EXIT(9);     // register set-up: light load, depth pass, dealing, full load
             // manifold constraints of this wave's islands (uniform mask)
@@ -1629,72 +1639,49 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
             if (OBJ && myMc) { mc_warm_pass(myMc, lane == 0); wave_sync(); }
             KB_STAMP_PRE(29);    // (profile build) warm start of wave 0, since the register set-up
             KB_ABLATE_EXIT(10);    // warm start
-            // SolveVelocityConstraints: friction 0, restitution 0, one manifold point.
-            // Branch-free rounds: slots that are not part of the current depth level work on a scratch body, so
-            // the LDS reads of all KREG slots are issued together (one LDS round trip per round).
+            // SolveVelocityConstraints: friction 0, restitution 0, one manifold point.  Slot by slot, level by level; only the
+            // lanes whose contact is of the round's level execute (EXEC mask).
             const int DUMMY = NB - 1;
-            int iaS[KREG], ibS[KREG];
-#pragma unroll
-            for (int j = 0; j < KREG; ++j) {
-                iaS[j] = (rvalid[j] && ra[j] < WALL_CODE) ? ra[j] : DUMMY;
-                ibS[j] = rvalid[j] ? rb[j] : DUMMY;
-            }
-#define KB_VEL_ROUND(J0, J1)                                                                        \
-                    {                                                                               \
-                        int ia[KREG], ib[KREG];                                                     \
-                        float vax[KREG], vay[KREG], vbx[KREG], vby[KREG];                           \
-                        _Pragma("unroll") for (int j = J0; j < J1; ++j) {                           \
-                            const bool on = rdepth[j] == d_ && !(OBJ && rpoly[j]);                  \
-                            ia[j] = on ? iaS[j] : DUMMY; ib[j] = on ? ibS[j] : DUMMY;               \
-                            vax[j] = vel[ia[j]].x; vay[j] = vel[ia[j]].y; vbx[j] = vel[ib[j]].x; vby[j] = vel[ib[j]].y; \
-                        }                                                                           \
-                        _Pragma("unroll") for (int j = J0; j < J1; ++j) {                           \
-                            const bool on = rdepth[j] == d_ && !(OBJ && rpoly[j]);                  \
-                            const bool wallA = ra[j] >= WALL_CODE;                                  \
-                            const float nx = rnx[j], ny = rny[j];                                   \
-                            const float ima = R_IMA(j), imb = R_IMB(j);                             \
-                            const float ax_ = wallA ? 0.0f : vax[j], ay_ = wallA ? 0.0f : vay[j];   \
-                            const float dvx = vbx[j] - ax_, dvy = vby[j] - ay_;                     \
-                            const float vn = dvx * nx + dvy * ny;                                   \
-                            float lambda = -(R_NM(j) * vn);                                         \
-                            const float accOld = racc[j];                                           \
-                            const float newimp = fmaxf(accOld + lambda, 0.0f);                      \
-                            lambda = newimp - accOld;                                               \
-                            racc[j] = on ? newimp : accOld;                                         \
-                            const float Px = lambda * nx, Py = lambda * ny;                         \
-                            vel[ia[j]].x = ax_ - ima * Px; vel[ia[j]].y = ay_ - ima * Py;           \
-                            vel[ib[j]].x = vbx[j] + imb * Px; vel[ib[j]].y = vby[j] + imb * Py;     \
-                        }                                                                           \
-                    }
             for (int it = 0; it < p.vel_iters; ++it) {
-                for (int d_ = 1; d_ <= maxD; ++d_) {
-                    // which slots hold contacts of this level (branch-free inside a slot set: its LDS reads go out together)
-                    const int lv = min(d_, 63);
-                    const bool s0 = (slotLevels[0] >> lv) & 1ull, s1 = KREG > 1 && ((slotLevels[KREG > 1 ? 1 : 0] >> lv) & 1ull);
-                    if (KREG != 2) KB_VEL_ROUND(0, KREG)
-                    else if (s0 && s1) KB_VEL_ROUND(0, 2)
-                    else if (s1) KB_VEL_ROUND(1, 2)
-                    else KB_VEL_ROUND(0, 1)
-                    if (OBJ) {   // kilobot - polygon contacts of this depth level: one point, friction sqrt(0 * f) = 0
 #pragma unroll
-                        for (int j = 0; j < KREG; ++j) {
-                            if (!(rpoly[j] && rdepth[j] == d_)) continue;
-                            const int a = ra[j], b = rb[j], m = b - N;
-                            const float wA = objW[m];
-                            const float dvx = (vel[a].x - vel[b].x) - (-wA * rrAy[j]), dvy = (vel[a].y - vel[b].y) - (wA * rrAx[j]);
-                            const float vn = dvx * rnx[j] + dvy * rny[j];
-                            float lambda = -(rnm[j] * vn);
-                            const float accOld = racc[j];
-                            const float newimp = fmaxf(accOld + lambda, 0.0f);
-                            lambda = newimp - accOld;
-                            racc[j] = newimp;
-                            const float Px = lambda * rnx[j], Py = lambda * rny[j];
-                            vel[b].x -= rimb[j] * Px; vel[b].y -= rimb[j] * Py;
-                            objW[m] = wA - objBody[m * BT_WORDS + BT_II] * (rrAx[j] * Py - rrAy[j] * Px);
-                            vel[a].x += rima[j] * Px; vel[a].y += rima[j] * Py;
+                for (int j = 0; j < KREG; ++j) {
+                    for (int d_ = dlo[j]; d_ <= dhi[j]; ++d_) {
+                        if (rvalid[j] && rdepth[j] == d_) {
+                            if (OBJ && rpoly[j]) {   // kilobot - polygon contact: one point, friction sqrt(0 * f) = 0
+                                const int a = ra[j], b = rb[j], m = b - N;
+                                const float wA = objW[m];
+                                const float dvx = (vel[a].x - vel[b].x) - (-wA * rrAy[j]), dvy = (vel[a].y - vel[b].y) - (wA * rrAx[j]);
+                                const float vn = dvx * rnx[j] + dvy * rny[j];
+                                float lambda = -(rnm[j] * vn);
+                                const float accOld = racc[j];
+                                const float newimp = fmaxf(accOld + lambda, 0.0f);
+                                lambda = newimp - accOld;
+                                racc[j] = newimp;
+                                const float Px = lambda * rnx[j], Py = lambda * rny[j];
+                                vel[b].x -= rimb[j] * Px; vel[b].y -= rimb[j] * Py;
+                                objW[m] = wA - objBody[m * BT_WORDS + BT_II] * (rrAx[j] * Py - rrAy[j] * Px);
+                                vel[a].x += rima[j] * Px; vel[a].y += rima[j] * Py;
+                            } else {
+                                const bool wallA = ra[j] >= WALL_CODE;
+                                const int ia = wallA ? DUMMY : ra[j], ib = rb[j];
+                                const float2 va_ = vel[ia], vb_ = vel[ib];
+                                const float nx = rnx[j], ny = rny[j];
+                                const float ima = R_IMA(j), imb = R_IMB(j);
+                                const float ax_ = wallA ? 0.0f : va_.x, ay_ = wallA ? 0.0f : va_.y;
+                                const float dvx = vb_.x - ax_, dvy = vb_.y - ay_;
+                                const float vn = dvx * nx + dvy * ny;
+                                float lambda = -(R_NM(j) * vn);
+                                const float accOld = racc[j];
+                                const float newimp = fmaxf(accOld + lambda, 0.0f);
+                                lambda = newimp - accOld;
+                                racc[j] = newimp;
+                                const float Px = lambda * nx, Py = lambda * ny;
+                                vel[ia] = make_float2(ax_ - ima * Px, ay_ - ima * Py);
+                                vel[ib] = make_float2(vb_.x + imb * Px, vb_.y + imb * Py);
+                            }
                         }
+                        wave_sync();
                     }
-                    wave_sync();
                 }
                 if (OBJ && myMc) { mc_velocity_pass(myMc, lane == 0); wave_sync(); }
             }
@@ -1780,14 +1767,10 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                 bool ron[KREG];
 #pragma unroll
                 for (int j = 0; j < KREG; ++j) ron[j] = rvalid[j] && act[risl[j]] != 0;
-                for (int d_ = 1; d_ <= maxD; ++d_) {
-                    bool anyOn = false;
 #pragma unroll
-                    for (int j = 0; j < KREG; ++j) anyOn |= ron[j] && rdepth[j] == d_;
-                    if (!__any(anyOn)) continue;
-#pragma unroll
-                    for (int j = 0; j < KREG; ++j) {
-                        if (!(ron[j] && rdepth[j] == d_)) continue;
+                for (int j = 0; j < KREG; ++j) {
+                    for (int d_ = dlo[j]; d_ <= dhi[j]; ++d_) {
+                        if (ron[j] && rdepth[j] == d_) {
                         const int a = ra[j], b = rb[j];
                         const int isl = risl[j];
                         if (OBJ && rpoly[j]) {   // b2PositionSolverManifold e_faceA, A = polygon b, B = kilobot a
@@ -1808,8 +1791,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                             pos[b].x -= T[BT_IM] * P.x; pos[b].y -= T[BT_IM] * P.y;
                             objA[m] -= T[BT_II] * v_cross(rA, P);
                             pos[a].x += KB_IM_BOT(a) * P.x; pos[a].y += KB_IM_BOT(a) * P.y;
-                            continue;
-                        }
+                        } else {
                         float nx, ny, sep;
                         const float ima = R_IMA(j), imb = R_IMB(j);
                         const float bx = pos[b].x, by = pos[b].y;
@@ -1835,8 +1817,10 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                         const float Px = imp * nx, Py = imp * ny;
                         if (a < WALL_CODE) { pos[a].x = axx - ima * Px; pos[a].y = ayy - ima * Py; }
                         pos[b].x = bx + imb * Px; pos[b].y = by + imb * Py;
+                        }
+                        }
+                        wave_sync();
                     }
-                    wave_sync();
                 }
                 if (OBJ && myMc) { viol |= mc_position_pass(myMc, lane == 0, act, nxt, it == p.pos_iters - 1); wave_sync(); }
 #ifdef KB_PROFILE
@@ -1850,7 +1834,6 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                 wave_sync();
             }
             KB_STAMP_PRE(24);    // (profile build) wave 0's own position sweeps, before it waits for the slowest wave
-#undef KB_VEL_ROUND
 #undef KB_REG_ROUNDS
 #undef KB_REG_KEY_ROUNDS
 #undef R_IMA

@@ -137,7 +137,7 @@ typedef struct kb_config {
                                                    the entries live in HBM (36 B each), not in LDS */
     float mode_density[5];                      /* KB_DRIVE_MIXED: fixture density of the kilobots of drive law k (Kilobot._density 1.0,
                                                    SimpleVelocityControlKilobot._density 2.0: kilobot.py:25, :214); 0 = bot_density */
-    int32_t allow_sleep;                        /* [0] b2World(gravity, doSleep=True) of kilobots_env.py:45: bodies carry
+    int32_t allow_sleep;                        /* [1 in the helpers that fill a default config; 0 leaves the state out] b2World(gravity, doSleep=True) of kilobots_env.py:45: bodies carry
                                                    b2Body::m_sleepTime (kb_buffers.sleep_time / osleep, seconds; < 0: asleep).  An
                                                    island whose bodies all stayed below b2_linearSleepTolerance /
                                                    b2_angularSleepTolerance for b2_timeToSleep = 0.5 s and whose position
