@@ -363,8 +363,8 @@ def main():
                  'kilobot_steps_per_s_one_gpu': E * N * 10 / (fms * 1e-3)}
 
     # the slow corner, reported next to the headline and never mixed into it: the same swarm driven at a light in the middle
-    # of the arena (SimplePhototaxis) jams into ONE island of ~ 2 800 contacts, which the whole workgroup sweeps key by key
-    # on records in the global staging slice (tools/cluster_probe.py, tests/test_parity_gpu.py::test_jammed_swarm_*)
+    # of the arena (SimplePhototaxis) jams into ONE island of ~ 2 800 contacts, which the whole workgroup sweeps level by level
+    # on depth-sorted records in the global staging slice (tools/cluster_probe.py, tests/test_parity_gpu.py::test_jammed_swarm_*)
     jammed = None
     plain = not (args.objects or args.sleep or args.sense > 0.0 or args.threads or args.no_toi or args.arena
                  or args.vel_iters != 10 or args.pos_iters != 10)

@@ -570,6 +570,9 @@ int kb_create(const kb_config *cfg, kb_sim **out) {
         int resident = resident_envs(ldsT, T, KB_MIN_WAVES_PER_SIMD);
         if (p.M == 0 && resident_envs(ldsT, T, KB_COMPACT_WAVES_PER_SIMD) > resident) resident = resident_envs(ldsT, T, KB_COMPACT_WAVES_PER_SIMD);
         if (T > 64 && resident < fit && p.N * 100 < T * 85) T >>= 1;
+        // 257 ... 512 kilobots without objects: two per thread in a 4-wave workgroup (measured at 512: 1.06e10 against 9.3e9 with
+        // eight waves -- an 8-wave env takes a third of the CU's wave slots whatever its LDS image is)
+        if (p.M == 0 && p.drive_mode != KB_DRIVE_MIXED && p.N > 256 && p.N <= 512) T = 256;
         // with objects, up to 128 kilobots run as one wave: that selects the spill-free 256-VGPR instantiation
         // (kb_step), measured + 6 ... 9 % at 100 kilobots and - 3 % at 128 against two-wave workgroups
         if (p.M > 0 && p.N <= BPT * 64) T = 64;
@@ -580,15 +583,18 @@ int kb_create(const kb_config *cfg, kb_sim **out) {
         // sorted-bin image (16 B per staged contact): give up staging entries where that lets the CU hold one more env -- a
         // 1024-kilobot swarm down to the 688 of the fixed-size kernel (a settled swarm has ~ 0.55 contacts per kilobot; a
         // jammed one is staged in the global slice whatever the LDS holds, and what it needs is resident envs)
-        const int lo = p.N > 512 ? ldsb::CAPL : (5 * p.N / 2 + 64 > 256 ? 5 * p.N / 2 + 64 : 256);
+        // (smaller swarms: never below one contact per kilobot + 64 -- a settled lattice has ~ 0.5, a hexagonal cluster up to 3;
+        //  the largest staging area that reaches the best residency is taken)
+        const int lo = p.N > 512 ? ldsb::CAPL : (p.N + 64 > 128 ? (p.N + 64 + 7) & ~7 : 128);
         auto res = [&](int c) {
             const int l = lds_bytes_for(p, s->threads, c);
             const int a = resident_envs(l, s->threads, KB_MIN_WAVES_PER_SIMD), b = resident_envs(l, s->threads, KB_COMPACT_WAVES_PER_SIMD);
             return a > b ? a : b;
         };
-        const int r0 = res(p.capL);
+        int best = res(p.capL), bestc = p.capL;
         for (int c = p.capL - 8; c >= lo; c -= 8)
-            if (res(c) > r0) { p.capL = c; break; }
+            if (res(c) > best) { best = res(c); bestc = c; }
+        p.capL = bestc;
     } else {   // trade a few staging entries for one more env per CU when the LDS footprint is just above a divisor of 160 KiB
         const int fit = LDS_CU / lds_bytes_for(p, s->threads, p.capL);
         const int lo = 5 * p.N / 2 + 64 > 256 ? 5 * p.N / 2 + 64 : 256;
