@@ -118,7 +118,8 @@ def test_lds_images_of_the_round_two_layouts(lib):
     assert lds(1024, num_objects=4) <= 80 * 1024       # two
     assert lds(1024, contact_capacity=12000) <= 53760      # 42 LDS granules of 1280 B: three envs per CU like the fixed-size kernel
     assert lds(64) <= 8192 + 512 and lds(16) <= 5632   # hashed cell heads: 20 / 24+ one-wave envs per CU
-    assert lds(512) <= 40 * 1024 and lds(768) <= 52 * 1024
+    assert lds(512) <= 32 * 1024 and lds(768) <= 52 * 1024     # 512 kilobots: five 4-wave envs per CU (staging down to N + 64 entries)
+    assert lds(400) <= 27 * 1024 and lds(64) <= 6400 + 256    # six envs; 24 one-wave envs
     # a small arena has fewer cells than the hash table would have entries: plain heads, still the compact image
     assert lds(100, world_width=0.6, world_height=0.6) <= lds(100) + 256
 
