@@ -370,7 +370,9 @@ def main():
                  or args.vel_iters != 10 or args.pos_iters != 10)
     if rank == 0 and not args.no_fused and plain and world == 1:
         from gym_kilobots_amd import _native as nat
-        Ej, settle_j, nj = min(E, 1024), 350, 30
+        # (as many envs as the headline: with the 1024 of rounds 2 - 3m a third of them ran alone on their CU behind the first 768,
+        #  1.8e9 instead of 2.2e9 on the same kernel)
+        Ej, settle_j, nj = E, 350, 20
         sim3 = KilobotSim(Ej, N, nat.DRIVE_SIMPLE_PHOTOTAXIS, nat.LIGHT_CIRCULAR, device=dev, light_radius=2.0, allow_sleep=0)
         sim3.x.copy_(x0[:Ej]); sim3.y.copy_(y0[:Ej]); sim3.theta.copy_(th[:Ej])
         sim3.forget_contacts()

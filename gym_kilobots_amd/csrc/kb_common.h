@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <type_traits>
 
 #include "kilobots_hip.h"
 
@@ -383,6 +384,16 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Read of an LDS word that other waves update with atomics (the union-find parents).  NOTE: through a generic pointer a `volatile`
+// access is a FLAT load with system-coherence bits and a full `s_waitcnt vmcnt(0) lgkmcnt(0)` behind it, not a ds_read_b32 (seen
+// in the label and flatten passes).  Three ways to get the ds_read were tried in round 3 (a relaxed __hip_atomic_load, a volatile
+// access through an LDS-qualified pointer, the same via the low half of the address): each made hipcc 7.2 fail in some OTHER
+// instantiation with "Illegal instruction detected: Operand has incorrect register class. V_CMP_NE_U32_e32 0, $src_shared_base",
+// so the flat form stays; it was worth ~ 0.5 % of a cfg3 launch.
+__device__ __forceinline__ unsigned lds_load_relaxed(const unsigned *p_) {
+    return *reinterpret_cast<const volatile unsigned *>(p_);
+}
+
 // Workgroup barrier for phases that only exchange LDS data: __syncthreads() also drains the vector-memory counter
 // (s_waitcnt vmcnt(0)), i.e. it waits for every global load a thread has in flight -- which is exactly what a sweep that
 // requests its records several rounds ahead must not do.  No memory instruction inside: the compiler's own s_waitcnt
@@ -574,7 +585,7 @@ __device__ __forceinline__ void kb_toi_walls_body(const Params &p, float R, floa
 __device__ __forceinline__ unsigned kb_exch16(unsigned short *base, int idx, unsigned val) {
     unsigned *word = reinterpret_cast<unsigned *>(base) + (idx >> 1);
     const int sh = (idx & 1) * 16;
-    unsigned old = *reinterpret_cast<volatile unsigned *>(word);
+    unsigned old = lds_load_relaxed(word);
     for (;;) {
         const unsigned want = (old & ~(0xFFFFu << sh)) | (val << sh);
         const unsigned seen = atomicCAS(word, old, want);

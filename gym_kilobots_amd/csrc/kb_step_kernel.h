@@ -684,8 +684,10 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
             //      owned contacts at their position in the packed list, contact j of owner a at newOff[a] + j.  Raw record:
             //      pair; direction k (walls: 8 + wall) | index inside the direction (walls: rank) << 4 | parity of the base
             //      cell << 12 | "kilobots of the cell in front of the owner" << 14 | wall normal flipped << 15 ----
-            unsigned *sPair = big ? gPair : lPair, *sInfo = big ? gInfo : lInfo;
-            float *sAcc = big ? gAcc : lAcc;
+            // (The staging arrays are LDS or the global slice.  Each pass is instantiated once per address space: through a pointer
+            //  that may be either, every access is a FLAT instruction -- slower into LDS than ds_read / ds_write, and counted on
+            //  the vector-memory counter as well, so that waiting for one waits for every global load in flight.)
+            auto stage_pass = [&](unsigned *sPair, unsigned *sInfo) __attribute__((always_inline)) {
 #pragma unroll
             for (int q = 0; q < BPT; ++q) {
                 const int b = tid + q * nt;
@@ -729,6 +731,8 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                     sInfo[cid] = inf;
                 }
             }
+            };
+            if (big) stage_pass(gPair, gInfo); else stage_pass(lPair, lInfo);
             KB_STAMP_PRE(34);    // (cumulative since the offset scan) wave 0's owned contacts staged
             __syncthreads();
             KB_STAMP_PRE(35);    // ... + barrier
@@ -736,6 +740,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
             KB_ABLATE_EXIT(5);     // contacts staged
             // ---- narrowphase, pass 3 (thread per contact): class and rank in the canonical order, impulse of the same pair in
             //      the previous substep, key of the new packed list (bits 16.. of the info word), island hooking ----
+            auto label_pass_bins = [&](unsigned *sPair, unsigned *sInfo, float *sAcc) __attribute__((always_inline)) {
             for (int c = tid; c < ncon; c += nt) {
                 const unsigned pr = sPair[c], raw = sInfo[c];
                 const unsigned a = pr & 0xFFFFu, b = pr >> 16;
@@ -770,8 +775,8 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                     // island hooking: larger root goes under the smaller one
                     unsigned ra = a, rb = b;
                     for (;;) {
-                        while (true) { unsigned t = ((volatile unsigned *)parent)[ra]; if (t == ra) break; ra = t; }
-                        while (true) { unsigned t = ((volatile unsigned *)parent)[rb]; if (t == rb) break; rb = t; }
+                        while (true) { unsigned t = lds_load_relaxed(&parent[ra]); if (t == ra) break; ra = t; }
+                        while (true) { unsigned t = lds_load_relaxed(&parent[rb]); if (t == rb) break; rb = t; }
                         if (ra == rb) break;
                         if (ra < rb) { unsigned t = ra; ra = rb; rb = t; }
                         if (atomicCAS(&parent[ra], ra, rb) == ra) break;
@@ -781,6 +786,8 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                 sInfo[c] = cls | (r << 8) | (key16 << 16);
                 sAcc[c] = acc;
             }
+            };
+            if (big) label_pass_bins(gPair, gInfo, gAcc); else label_pass_bins(lPair, lInfo, lAcc);
             KB_STAMP_PRE(18);
             __syncthreads();
             KB_STAMP(2);
@@ -940,8 +947,8 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                 if (OBJ && wave == 0 && lane < NMC && mcTouch && mci(ox, MC_A, lane) < WALL_CODE) {   // object - object: one island
                     unsigned ra = (unsigned)mci(ox, MC_A, lane), rb = (unsigned)mci(ox, MC_B, lane);
                     for (;;) {
-                        while (true) { unsigned t = ((volatile unsigned *)parent)[ra]; if (t == ra) break; ra = t; }
-                        while (true) { unsigned t = ((volatile unsigned *)parent)[rb]; if (t == rb) break; rb = t; }
+                        while (true) { unsigned t = lds_load_relaxed(&parent[ra]); if (t == ra) break; ra = t; }
+                        while (true) { unsigned t = lds_load_relaxed(&parent[rb]); if (t == rb) break; rb = t; }
                         if (ra == rb) break;
                         if (ra < rb) { unsigned t = ra; ra = rb; rb = t; }
                         if (atomicCAS(&parent[ra], ra, rb) == ra) break;
@@ -976,8 +983,8 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                         fixbits = (unsigned)m << 24;      // the fixture travels with the contact (bits 24..27)
                         unsigned ra = a, rb = pr >> 16;        // the object the fixture belongs to
                         for (;;) {
-                            while (true) { unsigned t = ((volatile unsigned *)parent)[ra]; if (t == ra) break; ra = t; }
-                            while (true) { unsigned t = ((volatile unsigned *)parent)[rb]; if (t == rb) break; rb = t; }
+                            while (true) { unsigned t = lds_load_relaxed(&parent[ra]); if (t == ra) break; ra = t; }
+                            while (true) { unsigned t = lds_load_relaxed(&parent[rb]); if (t == rb) break; rb = t; }
                             if (ra == rb) break;
                             if (ra < rb) { unsigned t = ra; ra = rb; rb = t; }
                             if (atomicCAS(&parent[ra], ra, rb) == ra) break;
@@ -1036,8 +1043,8 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
                         // island hooking: larger root goes under the smaller one
                         unsigned ra = a, rb = b;
                         for (;;) {
-                            while (true) { unsigned t = ((volatile unsigned *)parent)[ra]; if (t == ra) break; ra = t; }
-                            while (true) { unsigned t = ((volatile unsigned *)parent)[rb]; if (t == rb) break; rb = t; }
+                            while (true) { unsigned t = lds_load_relaxed(&parent[ra]); if (t == ra) break; ra = t; }
+                            while (true) { unsigned t = lds_load_relaxed(&parent[rb]); if (t == rb) break; rb = t; }
                             if (ra == rb) break;
                             if (ra < rb) { unsigned t = ra; ra = rb; rb = t; }
                             if (atomicCAS(&parent[ra], ra, rb) == ra) break;
@@ -1091,7 +1098,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
         // ---- islands: flatten roots; empty the grid for the next substep; offsets of the new ws list ----
         for (int b = tid; b < N; b += nt) {
             unsigned r = b;
-            while (true) { unsigned t = ((volatile unsigned *)parent)[r]; if (t == r) break; r = t; }
+            while (true) { unsigned t = lds_load_relaxed(&parent[r]); if (t == r) break; r = t; }
             parent[b] = r;   // only ever replaces an ancestor by an older ancestor: concurrent walks stay valid
             islCnt[b] = 0;
             islWave[b] = (unsigned char)((unsigned)b % (unsigned)nsolve);
@@ -1105,7 +1112,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
         if (tid < M) {
             const int b = N + tid;
             unsigned r = b;
-            while (true) { unsigned t = ((volatile unsigned *)parent)[r]; if (t == r) break; r = t; }
+            while (true) { unsigned t = lds_load_relaxed(&parent[r]); if (t == r) break; r = t; }
             parent[b] = r;
             islCnt[b] = 0;
             islWave[b] = (unsigned char)((unsigned)b % (unsigned)nw);
@@ -1161,8 +1168,8 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
         //   reg : every wave can hold its contacts in registers (<= KREG per lane) -> no contact arrays in the sweeps
         //   list: per-wave sweeps over the staged contact arrays
         // (a one-wave workgroup is its own cooperative group; it may still take the register path)
-        const bool coopForced = misc[M_MAXISL] > (unsigned)GIANT_ISLAND || p.solver_mode == 2 || p.solver_mode == 4;
-        const bool coop = coopForced || nw == 1;
+        bool coopForced = misc[M_MAXISL] > (unsigned)GIANT_ISLAND || p.solver_mode == 2 || p.solver_mode == 4;
+        bool coop = coopForced || nw == 1;
         if (!coop && !big && p.solver_mode == 0) {
             // Placement of the islands on the waves in order of size: the largest (= deepest) islands share the first
             // waves, the many tiny ones fill the rest.  A wave sweeps as many rounds as its deepest island has levels
@@ -1249,6 +1256,10 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
             for (int w = 0; w < nw; ++w) maxw = max(maxw, misc[M_WCNT + w]);
             reg = maxw <= 64u * KRX;
         }
+        // Kernels without objects: whatever does not fit the registers (an overloaded wave, contacts staged in the global slice) is
+        // swept by the whole workgroup level by level as well -- the per-wave list sweeps go key by key (~ 20 rounds per pass where
+        // the levels are ~ 12) and are left to the one-wave workgroups and the test knob.
+        if (BINS && nw > 1 && !reg && p.solver_mode == 0) { coopForced = true; coop = true; }
         if (OBJ && wave == 0) {   // which wave sweeps which manifold constraint (slot nw: all of them)
             const bool on = lane < NMC && mcTouch && (!SLEEP || active[mci(ox, MC_ISL, lane)] != 0);
             const unsigned w_ = on ? (unsigned)islWave[mci(ox, MC_ISL, lane)] : 0u;
@@ -2386,18 +2397,19 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
             // sorted-bin image: the staged contacts 0 .. newTotal - 1 are the packed list (key = bits 16.. of the info word).
             // It becomes the LDS image of the next substep's lookups, or goes out to the global list (last substep of the
             // launch; always when the contacts were staged in the global scratch slice).
-            const unsigned *sInfo = big ? gInfo : lInfo;
-            const float *sAcc = big ? gAcc : lAcc;
             const int nlist = (int)min(newTotal, (unsigned)stageCap);
-            for (int i = tid; i < nlist; i += nt) {
-                const unsigned key16 = sInfo[i] >> 16;
-                const float acc = sAcc[i];
-                if (newInLds && !lastSub) { oldKey[i] = (unsigned short)key16; oldAcc[i] = acc; }
-                if (lastSub || !newInLds) {
-                    g.ws_key[wo + i] = key16 >= (unsigned)WALL_CODE ? KEY_WALL + (key16 - WALL_CODE) : key16;
-                    g.ws_acc[wo + i] = acc;
+            auto list_out = [&](const unsigned *sInfo, const float *sAcc) __attribute__((always_inline)) {      // (one address space per instantiation, as above)
+                for (int i = tid; i < nlist; i += nt) {
+                    const unsigned key16 = sInfo[i] >> 16;
+                    const float acc = sAcc[i];
+                    if (newInLds && !lastSub) { oldKey[i] = (unsigned short)key16; oldAcc[i] = acc; }
+                    if (lastSub || !newInLds) {
+                        g.ws_key[wo + i] = key16 >= (unsigned)WALL_CODE ? KEY_WALL + (key16 - WALL_CODE) : key16;
+                        g.ws_acc[wo + i] = acc;
+                    }
                 }
-            }
+            };
+            if (big) list_out(gInfo, gAcc); else list_out(lInfo, lAcc);
             if (!lastSub) for (int c = tid; c < ldsb::bin_entries(p.nhead) / 2; c += nt) reinterpret_cast<unsigned *>(E1)[c] = 0u;     // (the bucket tables lay over the bin boundaries)
         }
         oldInLds = newInLds;

@@ -15,7 +15,7 @@ def one():
     from gym_kilobots_amd.sim import KilobotSim
     from gym_kilobots_amd import _native as nat
     from tests import scenes
-    E, N = 1024, 1024
+    E, N = int(os.environ.get('KB_JAM_ENVS', '1024')), 1024
     sim = KilobotSim(E, N, nat.DRIVE_SIMPLE_PHOTOTAXIS, nat.LIGHT_CIRCULAR, light_radius=2.0, ws_slots=8, allow_sleep=0)
     xy1, th1 = scenes.lattice_spawn(8, N, seed=1000)
     sim.set_poses_m(np.tile(xy1, (E // 8, 1, 1)), np.tile(th1, (E // 8, 1)))
@@ -32,7 +32,7 @@ def one():
         b.record()
         torch.cuda.synchronize()
         res.append(a.elapsed_time(b) / 20)
-    print('%s: %s ms per launch, %.1f contacts per env, status %d, envs/CU %d' % (os.environ.get('KB_HIP_LIB', 'product').split('_')[-1], ' '.join('%.4f' % r for r in res),
+    print('%s: %d envs, %s ms per launch, %.3e kilobot-steps/s, %.1f contacts per env, status %d, envs/CU %d' % (os.environ.get('KB_HIP_LIB', 'product').split('_')[-1], E, ' '.join('%.4f' % r for r in res), E * N / (min(res) * 1e-3),
           float(sim.ws_cnt.sum(dtype=torch.int64).item()) / E, int(sim.status.max().item()), sim.resident_envs_per_cu), flush=True)
 
 
