@@ -39,6 +39,10 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
     int tid = threadIdx.x;
     const int nt = FN ? 64 * KB_MAX_WAVES : (int)blockDim.x;
     int lane = tid & 63, wave = tid >> 6;
+    // the wave's index inside the workgroup in a scalar register: with it the thread index can be re-made at every phase boundary
+    // (KB_RETID) from the lane count, without the hardware's copy in v0 -- which otherwise lives across the whole kernel, in the
+    // kernels with little room in scratch memory (one exposed reload per phase)
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
     const int nw = nt >> 6;
     const int nsolve = BINS ? (nw >= KB_NSOLVE_DIV ? nw / KB_NSOLVE_DIV : 1) : nw;      // waves that sweep the contacts (kb_regsolve_bins.inc: the solver is issue-bound, fewer waves fill their lanes better)
     const int N = FN ? FN : p.N, NP = FN ? ((FN + 3) & ~3) : p.NP, S = p.S;
@@ -300,7 +304,9 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
 #else
 #define KB_ABLATE_EXIT(k_) do { } while (0)
 #endif
-#define KB_RETID() do { int t_ = threadIdx.x; asm volatile("" : "+v"(t_)); tid = t_; lane = t_ & 63; wave = t_ >> 6; } while (0)
+#define KB_RETID() do { int w_ = wave_s; asm volatile("" : "+s"(w_));                                                                  \
+                        int l_ = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); asm volatile("" : "+v"(l_));    \
+                        wave = w_; lane = l_; tid = (w_ << 6) | l_; } while (0)
         KB_RETID();
         // ---- light.step: SinglePositionLight.step, light.py:59-75 (uniform per env) ----
         if (p.light_action && LGEN && drive)
