@@ -269,7 +269,8 @@ int kb_light_action_dim(const kb_sim *sim);     /* floats per env in d_light_act
 int kb_light_count(const kb_sim *sim);          /* light components per env (0 without a light) */
 int kb_contact_capacity(const kb_sim *sim);     /* contacts (and warm-start entries) per env */
 int kb_lds_staging_entries(const kb_sim *sim);  /* contacts of one env that are staged in LDS; an env with more takes its slice of
-                                                   kb_buffers.scratch for that substep (same results, slower) */
+                                                   kb_buffers.scratch for that substep (same results, slower).  kb_create trades
+                                                   entries for resident envs per CU, never below num_bots + 64 (688 at 1024) */
 size_t kb_scratch_bytes(const kb_sim *sim);     /* size of kb_buffers.scratch: 32 B per contact of the capacity (staging record; level-sorted record of the cooperative sweeps) */
 int kb_block_threads(const kb_sim *sim);
 int kb_resident_envs_per_cu(kb_sim *sim);        /* workgroups (= envs) of this handle's kernel that one CU holds at a time (HIP occupancy query; needs a GPU) */
