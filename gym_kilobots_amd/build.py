@@ -32,7 +32,7 @@ def needs_build(lib=LIB):
     if not os.path.exists(lib):
         return True
     t = os.path.getmtime(lib)
-    deps = sources() + glob.glob(os.path.join(CSRC, '*.h')) + [os.path.join(INC, 'kilobots_hip.h')]
+    deps = sources() + glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(CSRC, '*.inc')) + [os.path.join(INC, 'kilobots_hip.h')]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -124,7 +124,7 @@ def lint_codegen(verbose=False):
     # the assembly that build() kept next to the objects it linked is the shipped code: use it while it is current
     reldir = os.path.join(HERE, '_obj', 'rel')
     kept = [_device_asm(reldir, s_) for s_ in sources() if os.path.basename(s_).startswith('kb_inst_')]
-    deps = sources() + glob.glob(os.path.join(CSRC, '*.h')) + [os.path.join(INC, 'kilobots_hip.h')]
+    deps = sources() + glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(CSRC, '*.inc')) + [os.path.join(INC, 'kilobots_hip.h')]
     if os.path.exists(LIB) and all(os.path.exists(a) and os.path.getmtime(a) >= max(os.path.getmtime(d) for d in deps) for a in kept):
         findings = []
         for a in kept:
