@@ -304,7 +304,7 @@ __global__ void __launch_bounds__(TIER == 1 ? 64 : 64 * KB_MAX_WAVES, (TIER == 1
 #else
 #define KB_ABLATE_EXIT(k_) do { } while (0)
 #endif
-#define KB_RETID() do { int w_ = wave_s; asm volatile("" : "+s"(w_));                                                                  \
+#define KB_RETID() do { int w_ = __builtin_amdgcn_readfirstlane(wave_s); asm volatile("" : "+s"(w_));                                                                  \
                         int l_ = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); asm volatile("" : "+v"(l_));    \
                         wave = w_; lane = l_; tid = (w_ << 6) | l_; } while (0)
         KB_RETID();
